@@ -1,0 +1,89 @@
+/*
+ * sift_oracle.h -- CPU restatement of the cuSIFT extraction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (cusift_amd/, include/) never links,
+ * imports or falls back to anything in oracle/.
+ *
+ * Parity status: PINNED for keypoint location/scale/orientation against the reference's own
+ * golden pair test/data/gray1 -> test/data/cusift1_check (tests/test_oracle_golden.py);
+ * "parity unpinned" for descriptors, sharpness, edgeness and RootSIFT (the reference holds no
+ * golden vector for them: test/descriptor.cpp is empty).
+ *
+ * Every function cites the reference file:line it restates (paths relative to the reference
+ * root: cuSIFT.cu = host drivers, cuSIFT_D.cu = device kernels).
+ */
+#ifndef SIFT_ORACLE_H
+#define SIFT_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cuSIFT.h:10-30 -- 147 x 4 B = 588 B, no padding. */
+typedef struct oracle_sift_point {
+  float coords2D[2];
+  float scale;
+  float sharpness;
+  float edgeness;
+  float orientation;
+  float score;
+  float ambiguity;
+  int match;
+  float match_xpos;
+  float match_ypos;
+  float match_error;
+  float subsampling;
+  float empty[3];
+  float data[128];
+  float coords3D[3];
+} oracle_sift_point;
+
+/* Public fields of SiftData (cuSIFT.h:44-51) + the two documented rules of this build. */
+typedef struct oracle_params {
+  int num_octaves;
+  double init_blur;
+  float peak_thresh;
+  float edge_thresh;
+  float lowest_scale;
+  float subsampling;   /* Extract()'s 4th argument, default 1.0f */
+  int max_pts;
+  int tex_frac_bits;   /* 8 = CUDA texture unit (1/256 fractions); 0 = exact fp32 fractions */
+} oracle_params;
+
+/* cuSIFT.cu:313-353 + cuSIFT_D.cu:37-182.  dst is (w/2) x (h/2). */
+void oracle_scale_down(const float *src, int w, int h, int src_pitch, float *dst, int dst_pitch);
+
+/* cuSIFT.cu:399-412: the 8 x 9 tap table (row stride 16 floats, taps at [16*i + j + 4]).
+ * Rule of this build (the reference yields NaN / an inverted kernel there): var <= 1e-6 => identity. */
+void oracle_laplace_taps(float init_blur, float taps[8 * 16]);
+
+/* cuSIFT.cu:399-422 + cuSIFT_D.cu:525-553: dog = 7 planes [7][h][pitch]; pad columns untouched. */
+void oracle_laplace_multi(const float *img, int w, int h, int pitch, float init_blur, float *dog);
+
+/* cuSIFT.cu:424-455 + cuSIFT_D.cu:402-523.  Appends header fields at points[*counter],
+ * raster order (y, x, scale); slots >= max_pts are dropped but *counter keeps counting. */
+void oracle_find_points_multi(const float *dog, int w, int h, int pitch, float peak_thresh, float edge_thresh,
+                              float subsampling, oracle_sift_point *points, int max_pts, int *counter);
+
+/* cuSIFT_D.cu:319-396 over points [first, last). */
+void oracle_compute_orientations(const float *img, int w, int h, int pitch, oracle_sift_point *points, int first,
+                                 int last, int tex_frac_bits);
+
+/* cuSIFT_D.cu:184-297 over points [first, last); scales coords2D/scale by subsampling at the end. */
+void oracle_extract_descriptors(const float *img, int w, int h, int pitch, oracle_sift_point *points, int first,
+                                int last, float subsampling, int tex_frac_bits);
+
+/* cuSIFT_D.cu:299-317 */
+void oracle_rootsift(oracle_sift_point *points, int n);
+
+/* cuSIFT.cu:61-120,175-270: full driver on a dense host image (row stride w). Returns numPts. */
+int oracle_extract(const float *img, int w, int h, const oracle_params *prm, oracle_sift_point *points);
+
+/* Software model of tex2D<float>(x, y) with cudaFilterModeLinear / clamp / unnormalised coords. */
+float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, int frac_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""ctypes binding of oracle/libsift_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+# cuSIFT.h:10-30 -- 588-byte record
+SIFT_POINT_DTYPE = np.dtype(
+    [
+        ("coords2D", "<f4", (2,)),
+        ("scale", "<f4"),
+        ("sharpness", "<f4"),
+        ("edgeness", "<f4"),
+        ("orientation", "<f4"),
+        ("score", "<f4"),
+        ("ambiguity", "<f4"),
+        ("match", "<i4"),
+        ("match_xpos", "<f4"),
+        ("match_ypos", "<f4"),
+        ("match_error", "<f4"),
+        ("subsampling", "<f4"),
+        ("empty", "<f4", (3,)),
+        ("data", "<f4", (128,)),
+        ("coords3D", "<f4", (3,)),
+    ]
+)
+assert SIFT_POINT_DTYPE.itemsize == 588
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("num_octaves", C.c_int),
+        ("init_blur", C.c_double),
+        ("peak_thresh", C.c_float),
+        ("edge_thresh", C.c_float),
+        ("lowest_scale", C.c_float),
+        ("subsampling", C.c_float),
+        ("max_pts", C.c_int),
+        ("tex_frac_bits", C.c_int),
+    ]
+
+
+def build_oracle():
+    """Compile the oracle if the shared objects are missing or stale (needs gcc)."""
+    src = os.path.join(ORACLE_DIR, "sift_oracle.c")
+    so = os.path.join(ORACLE_DIR, "libsift_oracle.so")
+    if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    return so
+
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class Oracle:
+    def __init__(self, variant=""):
+        build_oracle()
+        name = "libsift_oracle%s.so" % (("_" + variant) if variant else "")
+        self.lib = lib = C.CDLL(os.path.join(ORACLE_DIR, name))
+        lib.oracle_scale_down.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int]
+        lib.oracle_scale_down.restype = None
+        lib.oracle_laplace_taps.argtypes = [C.c_float, _vp]
+        lib.oracle_laplace_taps.restype = None
+        lib.oracle_laplace_multi.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp]
+        lib.oracle_laplace_multi.restype = None
+        lib.oracle_find_points_multi.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                 _vp, C.c_int, C.POINTER(C.c_int)]
+        lib.oracle_find_points_multi.restype = None
+        lib.oracle_compute_orientations.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]
+        lib.oracle_compute_orientations.restype = None
+        lib.oracle_extract_descriptors.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float,
+                                                   C.c_int]
+        lib.oracle_extract_descriptors.restype = None
+        lib.oracle_rootsift.argtypes = [_vp, C.c_int]
+        lib.oracle_rootsift.restype = None
+        lib.oracle_extract.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(OracleParams), _vp]
+        lib.oracle_extract.restype = C.c_int
+        lib.oracle_tex2d.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+        lib.oracle_tex2d.restype = C.c_float
+
+    # ---- stage functions on pitched numpy images (2-D float32 arrays, pitch = arr.shape[1]) ----
+    def scale_down(self, src, w, h):
+        src = _f32(src)
+        ow, oh = w // 2, h // 2
+        op = max(128, -(-ow // 128) * 128)
+        dst = np.zeros((max(oh, 1), op), dtype=np.float32)
+        self.lib.oracle_scale_down(src.ctypes.data, w, h, src.shape[1], dst.ctypes.data, op)
+        return dst
+
+    def laplace_taps(self, init_blur):
+        taps = np.zeros(8 * 16, dtype=np.float32)
+        self.lib.oracle_laplace_taps(init_blur, taps.ctypes.data)
+        return taps
+
+    def laplace_multi(self, img, w, h, init_blur):
+        img = _f32(img)
+        dog = np.zeros((7, h, img.shape[1]), dtype=np.float32)
+        self.lib.oracle_laplace_multi(img.ctypes.data, w, h, img.shape[1], init_blur, dog.ctypes.data)
+        return dog
+
+    def find_points_multi(self, dog, w, h, peak_thresh, edge_thresh, subsampling, max_pts, points=None, counter=0):
+        dog = _f32(dog)
+        if points is None:
+            points = np.zeros(max_pts, dtype=SIFT_POINT_DTYPE)
+        cnt = C.c_int(counter)
+        self.lib.oracle_find_points_multi(dog.ctypes.data, w, h, dog.shape[2], peak_thresh, edge_thresh, subsampling,
+                                          points.ctypes.data, max_pts, C.byref(cnt))
+        return points, cnt.value
+
+    def compute_orientations(self, img, w, h, points, first, last, frac_bits=8):
+        img = _f32(img)
+        self.lib.oracle_compute_orientations(img.ctypes.data, w, h, img.shape[1], points.ctypes.data, first, last,
+                                             frac_bits)
+
+    def extract_descriptors(self, img, w, h, points, first, last, subsampling, frac_bits=8):
+        img = _f32(img)
+        self.lib.oracle_extract_descriptors(img.ctypes.data, w, h, img.shape[1], points.ctypes.data, first, last,
+                                            subsampling, frac_bits)
+
+    def rootsift(self, points, n):
+        self.lib.oracle_rootsift(points.ctypes.data, n)
+
+    def extract(self, img, num_octaves=5, init_blur=0.0, peak_thresh=3.0, edge_thresh=10.0, lowest_scale=0.0,
+                subsampling=1.0, max_pts=32768, tex_frac_bits=8):
+        img = _f32(img)
+        h, w = img.shape
+        prm = OracleParams(num_octaves, init_blur, peak_thresh, edge_thresh, lowest_scale, subsampling, max_pts,
+                           tex_frac_bits)
+        points = np.zeros(max_pts, dtype=SIFT_POINT_DTYPE)
+        n = self.lib.oracle_extract(img.ctypes.data, w, h, C.byref(prm), points.ctypes.data)
+        return points[:n]
+
+    def tex2d(self, img, w, h, x, y, frac_bits=8):
+        img = _f32(img)
+        return self.lib.oracle_tex2d(img.ctypes.data, w, h, img.shape[1], x, y, frac_bits)
+
+
+def pitched(img):
+    """Dense (h, w) -> pitched (h, iAlignUp(w,128)) copy, pad columns zero (cuImage.cu:11-13)."""
+    img = np.asarray(img, dtype=np.float32)
+    h, w = img.shape
+    p = -(-w // 128) * 128
+    out = np.zeros((h, p), dtype=np.float32)
+    out[:, :w] = img
+    return out
