@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of the MI355X-native SIFT extraction path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]/[3]): a batch of 64 synthetic 1920x1080 8-bit-valued images per GPU
+(seeded `tile` images pre-blurred to sigma 1.0), 5 octaves, initBlur=1.0, thresh=3.0, edge=10.
+One "step" = one pass of the whole hot path over that batch: ScaleDown pyramid, 8 blurs + 7 DoG per
+octave, extrema + refinement, orientation, 128-D descriptors -- SiftData left in HBM; with N>1 ranks the
+step ends with the RCCL all-gatherv of SiftData so every rank holds all N*64 images' keypoints.
+Inputs are resident in HBM before the timed region.  Weak scaling: 64 images per GPU at every N.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description), with two extra
+objects: `roofline` (blur+DoG kernel: algorithmic bytes / HIP-event duration vs 8 TB/s) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores over a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def octave_dims(w, h, n_oct):
+    dims = [(w, h)]
+    for _ in range(1, n_oct):
+        w, h = w // 2, h // 2
+        if w < 1 or h < 1:
+            break
+        dims.append((w, h))
+    return dims
+
+
+def algorithmic_bytes(w, h, n_oct, n_img):
+    """per octave, blur+DoG 32 B/px, downsample 4 B/px in + 4 B/px out, extrema 28 B/px."""
+    dims = octave_dims(w, h, n_oct)
+    blur = sum(32 * a * b for a, b in dims) * n_img
+    find = sum(28 * a * b for a, b in dims) * n_img
+    down = sum(4 * dims[i][0] * dims[i][1] + 4 * dims[i + 1][0] * dims[i + 1][1] for i in range(len(dims) - 1)) * n_img
+    return blur, down, find
+
+
+def cpu_baseline(w, h, params_kw, preblur, budget_s):
+    """The CPU oracle (a restatement of the cuSIFT algorithm -- NOT OpenCV, which this image lacks) timed on
+    the host cores: one image per thread (the C code releases the GIL), bounded to ~budget_s of wall time."""
+    import threading
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cusift_amd import synth
+    from oracle_binding import Oracle  # checker / baseline only
+
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 32))
+    oracle = Oracle()
+    imgs = [synth.tile(5000 + i, w, h, preblur) for i in range(threads)]
+    oracle.extract(imgs[0], **params_kw)  # warm-up (page-in, first-touch)
+    counts = [0] * threads
+    done = [0] * threads
+    t_end = time.perf_counter() + budget_s
+
+    def work(i):
+        while True:
+            counts[i] += len(oracle.extract(imgs[i], **params_kw))
+            done[i] += 1
+            if time.perf_counter() >= t_end:
+                break
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    n_img = sum(done)
+    return {
+        "value": round(n_img * w * h / dt / 1e6, 3),
+        "unit": "Mpix/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d x %dx%d images (same generator/params), %d threads, %.1f s wall; CPU restatement of the "
+                  "cuSIFT algorithm (oracle/sift_oracle.c), not OpenCV" % (n_img, w, h, threads, dt),
+        "keypoints_per_s": round(sum(counts) / dt, 1),
+        "host_cores": cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--octaves", type=int, default=5)
+    ap.add_argument("--init-blur", type=float, default=1.0)
+    ap.add_argument("--thresh", type=float, default=3.0)
+    ap.add_argument("--max-pts", type=int, default=32768)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-stage-timers", action="store_true", help="do not bracket stages with HIP events")
+    ap.add_argument("--gather", choices=["p2p", "padded"], default="p2p")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from cusift_amd import capi, synth
+    from cusift_amd.batch import BatchExtractor
+    from cusift_amd.dist import allgather_siftdata
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    capi.lib()  # fail loudly if the HIP extension is missing -- there is no fallback
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w, h, B = args.width, args.height, args.batch
+    prm_kw = dict(num_octaves=args.octaves, init_blur=args.init_blur, peak_thresh=args.thresh, edge_thresh=10.0,
+                  lowest_scale=0.0, subsampling=1.0, max_pts=args.max_pts, tex_frac_bits=8)
+    ex = BatchExtractor(B, w, h, **prm_kw)
+
+    # ---- synthetic inputs, resident in HBM before anything is timed ----
+    from concurrent.futures import ThreadPoolExecutor
+
+    seeds = [1000 + rank * B + i for i in range(B)]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        host = list(pool.map(lambda s: synth.tile(s, w, h, args.init_blur), seeds))
+    d_imgs = ex.images_from_numpy(np.stack(host))
+    del host
+
+    def step():
+        pts, cnt = ex.extract(d_imgs)
+        if world > 1:
+            return allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_stage_timers:
+        ex.ctx.timing_enable(True)
+        ex.ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stage = ex.ctx.timing_read() if not args.no_stage_timers else None
+    ex.ctx.timing_enable(False)
+
+    # max over ranks
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    counts = ex.valid_counts()
+    local_kp = int(counts.sum().item())
+    kp = torch.tensor([local_kp], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(kp, op=dist.ReduceOp.SUM)
+        total_gathered = int(gathered[2][-1])
+        assert total_gathered == int(kp.item()), (total_gathered, int(kp.item()))
+    total_kp = int(kp.item())
+
+    if rank == 0:
+        K = args.steps
+        ms_per_step = elapsed / K * 1e3
+        total_pix = world * B * w * h
+        out = {
+            "metric": "Mpix/s pyramid + keypoints/s end-to-end, 1920x1080 batch",
+            "value": round(total_pix / (elapsed / K) / 1e6, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "batch of %d x %dx%d images per GPU (BASELINE configs[2]; x%d GPUs = configs[3] shape), "
+                            "%d octaves, initBlur=%.1f, thresh=%.1f, edge=10, maxPts=%d; full SIFT extraction "
+                            "(pyramid+DoG, extrema, orientation, 128-D descriptor)%s"
+                            % (B, w, h, world, args.octaves, args.init_blur, args.thresh, args.max_pts,
+                               "; + all-gatherv of SiftData (%s)" % args.gather if world > 1 else ""),
+                "images_per_gpu": B,
+                "parallelism": "image-sharded x%d" % world,
+            },
+            "keypoints_per_s": round(total_kp / (elapsed / K), 1),
+            "keypoints_per_step": total_kp,
+        }
+        blur_b, down_b, find_b = algorithmic_bytes(w, h, args.octaves, B)
+        if stage is not None:
+            lap_ms, lap_n = stage["laplace_multi"]
+            sd_ms, _ = stage["scale_down"]
+            fp_ms, _ = stage["find_points_multi"]
+            or_ms, _ = stage["compute_orientations"]
+            de_ms, _ = stage["extract_descriptors"]
+            # per launch: average algorithmic bytes / average duration over the launches of the timed region
+            achieved = (blur_b * K / lap_n) / (lap_ms * 1e-3 / lap_n) / 1e9 if lap_ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "laplace_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "kernel": "laplace_multi_kernel (8 blurs + 7 DoG)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(blur_b * K / lap_n),
+                "avg_launch_ms": round(lap_ms / lap_n, 5),
+                "launches": lap_n,
+            }
+            out["stage_ms_per_step"] = {
+                "scale_down": round(sd_ms / K, 4), "laplace_multi": round(lap_ms / K, 4),
+                "find_points_multi": round(fp_ms / K, 4), "compute_orientations": round(or_ms / K, 4),
+                "extract_descriptors": round(de_ms / K, 4), "total_events": round(stage["total"][0] / K, 4),
+            }
+            out["stage_algorithmic_GBps"] = {
+                "scale_down": round(down_b / (sd_ms / K * 1e-3) / 1e9, 1) if sd_ms > 0 else None,
+                "laplace_multi": round(blur_b / (lap_ms / K * 1e-3) / 1e9, 1) if lap_ms > 0 else None,
+                "find_points_multi": round(find_b / (fp_ms / K * 1e-3) / 1e9, 1) if fp_ms > 0 else None,
+            }
+            pyr_ms = (sd_ms + lap_ms) / K
+            out["pyramid_mpix_per_s"] = round(B * w * h / (pyr_ms * 1e-3) / 1e6, 1) if pyr_ms > 0 else None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu_kw = dict(prm_kw)
+            out["cpu_baseline"] = cpu_baseline(w, h, cpu_kw, args.init_blur, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    ex.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

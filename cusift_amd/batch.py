@@ -1,0 +1,65 @@
+"""Batched SIFT extraction on torch device tensors.
+
+torch is plumbing here (HBM allocations, the stream, torch.distributed); every kernel is launched by
+libcusift_amd.so through the C ABI on the stream this object was created on.
+"""
+import numpy as np
+import torch
+
+from . import capi
+
+
+class BatchExtractor:
+    """Extracts SiftData for a batch of equally sized, HBM-resident float32 images.
+
+    The batch form of SiftData::Extract (cuSIFT.cu:61-120): `extract()` only enqueues work -- no
+    allocation, no host read-back -- and returns device tensors:
+        points  uint8  [n, max_pts, 588]   (SiftPoint records, cuSIFT.h:10-30)
+        counts  int32  [n]                 raw counters; valid points = min(count, max_pts)
+    """
+
+    def __init__(self, n_images, w, h, params=None, device=None, pitch=None, **param_overrides):
+        if not torch.cuda.is_available():
+            raise capi.CusiftError("BatchExtractor needs a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.n, self.w, self.h = int(n_images), int(w), int(h)
+        self.pitch = capi.ialign_up(self.w, 128) if pitch is None else int(pitch)
+        self.params = params if params is not None else capi.default_params(**param_overrides)
+        self.max_pts = self.params.max_pts
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream()
+            self.ctx = capi.Context(self.device.index, stream=self.stream.cuda_stream)
+            self.ctx.reserve(self.n, self.w, self.h, self.params)
+            self.points = torch.zeros((self.n, self.max_pts, capi.SIFT_POINT_BYTES), dtype=torch.uint8,
+                                      device=self.device)
+            self.counts = torch.zeros((self.n,), dtype=torch.int32, device=self.device)
+
+    def images_from_numpy(self, imgs):
+        """(n, h, w) float32 host array -> pitched device tensor (n, h, pitch)."""
+        imgs = np.asarray(imgs, dtype=np.float32)
+        assert imgs.shape == (self.n, self.h, self.w), imgs.shape
+        dev = torch.zeros((self.n, self.h, self.pitch), dtype=torch.float32, device=self.device)
+        dev[:, :, : self.w] = torch.from_numpy(imgs).to(self.device)
+        return dev
+
+    def extract(self, d_imgs):
+        assert d_imgs.is_cuda and d_imgs.dtype == torch.float32 and d_imgs.is_contiguous()
+        assert tuple(d_imgs.shape) == (self.n, self.h, self.pitch), tuple(d_imgs.shape)
+        self.ctx.extract_batch(d_imgs.data_ptr(), self.n, self.w, self.h, self.pitch, self.h * self.pitch,
+                               self.params, self.points.data_ptr(), self.counts.data_ptr())
+        return self.points, self.counts
+
+    def valid_counts(self):
+        return torch.clamp(self.counts, max=self.max_pts)
+
+    def to_host(self):
+        """Blocking: list of numpy SiftPoint arrays, one per image."""
+        cnt = self.valid_counts().cpu().numpy()
+        out = []
+        for i in range(self.n):
+            raw = self.points[i, : int(cnt[i])].cpu().numpy()
+            out.append(raw.view(capi.SIFT_POINT_DTYPE).reshape(-1))
+        return out
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,59 @@
+"""Builds libcusift_amd.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
+
+    python -m cusift_amd.build [--force]
+
+The shared object lands next to this file so that it travels to the GPU box with the source tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcusift_amd.so")
+SOURCES = ["sift_capi.hip", "sift_kernels.hip"]
+HEADERS = [os.path.join(CSRC, "sift_types.h"), os.path.join(HERE, "..", "include", "cusift_amd.h")]
+
+# -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fPIC",
+    "-shared",
+    "-fno-gpu-rdc",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def find_hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 if missing or older than its sources. Returns the path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

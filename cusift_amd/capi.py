@@ -1,0 +1,316 @@
+"""ctypes binding of the C ABI declared in include/cusift_amd.h (libcusift_amd.so).
+
+There is no CPU fallback: if the HIP extension is missing this module raises at import of the
+library handle (`lib()`), and every call that needs a GPU fails with the library's error text.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcusift_amd.so")
+
+CUSIFT_OK = 0
+NUM_STAGES = 6
+STAGE_NAMES = ("scale_down", "laplace_multi", "find_points_multi", "compute_orientations",
+               "extract_descriptors", "total")
+
+# SiftPoint, cuSIFT.h:10-30 (588 B, no padding)
+SIFT_POINT_DTYPE = np.dtype(
+    [
+        ("coords2D", "<f4", (2,)),
+        ("scale", "<f4"),
+        ("sharpness", "<f4"),
+        ("edgeness", "<f4"),
+        ("orientation", "<f4"),
+        ("score", "<f4"),
+        ("ambiguity", "<f4"),
+        ("match", "<i4"),
+        ("match_xpos", "<f4"),
+        ("match_ypos", "<f4"),
+        ("match_error", "<f4"),
+        ("subsampling", "<f4"),
+        ("empty", "<f4", (3,)),
+        ("data", "<f4", (128,)),
+        ("coords3D", "<f4", (3,)),
+    ]
+)
+SIFT_POINT_BYTES = 588
+assert SIFT_POINT_DTYPE.itemsize == SIFT_POINT_BYTES
+
+
+class Params(C.Structure):
+    """cusift_params (include/cusift_amd.h); the public parameter fields of SiftData, cuSIFT.h:44-51."""
+
+    _fields_ = [
+        ("num_octaves", C.c_int),
+        ("init_blur", C.c_double),
+        ("peak_thresh", C.c_float),
+        ("edge_thresh", C.c_float),
+        ("lowest_scale", C.c_float),
+        ("subsampling", C.c_float),
+        ("max_pts", C.c_int),
+        ("tex_frac_bits", C.c_int),
+    ]
+
+
+class CusiftError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/cusift_amd.h declares
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_PP = C.POINTER(Params)
+SIGNATURES = {
+    "cusift_last_error": (C.c_char_p, []),
+    "cusift_version": (C.c_char_p, []),
+    "cusift_device_count": (_i, [C.POINTER(_i)]),
+    "cusift_init": (_i, [_i]),
+    "cusift_default_params": (None, [_PP]),
+    "cusift_ctx_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "cusift_ctx_destroy": (_i, [_vp]),
+    "cusift_ctx_synchronize": (_i, [_vp]),
+    "cusift_ctx_stream": (_vp, [_vp]),
+    "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
+    "cusift_ctx_arena_bytes": (_sz, [_vp]),
+    "cusift_ctx_timing_enable": (_i, [_vp, _i]),
+    "cusift_ctx_timing_read": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
+    "cusift_ctx_timing_reset": (_i, [_vp]),
+    "cusift_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "cusift_free": (_i, [_vp]),
+    "cusift_memset": (_i, [_vp, _vp, _i, _sz]),
+    "cusift_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "cusift_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "cusift_image_h2d": (_i, [_vp, _vp, _i, _vp, _i, _i]),
+    "cusift_image_d2h": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "cusift_malloc_host": (_i, [C.POINTER(_vp), _sz]),
+    "cusift_free_host": (_i, [_vp]),
+    "cusift_scale_down": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i]),
+    "cusift_laplace_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _vp, _sz, _i]),
+    "cusift_laplace_taps": (_i, [_f, _vp]),
+    "cusift_find_points_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _vp, _i, _vp, _i]),
+    "cusift_compute_orientations": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _i, _i]),
+    "cusift_extract_descriptors": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _f, _i, _i]),
+    "cusift_rootsift": (_i, [_vp, _vp, _i]),
+    "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
+    "cusift_extract": (_i, [_vp, _vp, _i, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
+    "cusift_extract_host": (_i, [_vp, _vp, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded libcusift_amd.so with typed entry points. Raises if the extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CusiftError(
+                "HIP extension %s is missing: run `python -m cusift_amd.build` (needs hipcc); "
+                "there is no CPU fallback for the extraction path" % LIB_PATH
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != CUSIFT_OK:
+        msg = lib().cusift_last_error()
+        raise CusiftError("cusift error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def default_params(**overrides):
+    p = Params()
+    lib().cusift_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().cusift_device_count(C.byref(n)))
+    return n.value
+
+
+def ialign_up(a, b):
+    """iAlignUp, cutils.h:17"""
+    return (a - a % b + b) if (a % b != 0) else a
+
+
+class Context:
+    """cusift_ctx: one device + one HIP stream + the scratch arena."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        check(lib().cusift_ctx_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None))
+        self.device = device
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise CusiftError("context already destroyed")
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().cusift_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self):
+        check(lib().cusift_ctx_synchronize(self.handle))
+
+    def reserve(self, n_images, w, h, params):
+        check(lib().cusift_ctx_reserve(self.handle, n_images, w, h, C.byref(params)))
+
+    def arena_bytes(self):
+        return lib().cusift_ctx_arena_bytes(self.handle)
+
+    # ---- timing ----
+    def timing_enable(self, on=True):
+        check(lib().cusift_ctx_timing_enable(self.handle, 1 if on else 0))
+
+    def timing_reset(self):
+        check(lib().cusift_ctx_timing_reset(self.handle))
+
+    def timing_read(self):
+        ms = (C.c_float * NUM_STAGES)()
+        n = (C.c_int * NUM_STAGES)()
+        check(lib().cusift_ctx_timing_read(self.handle, ms, n))
+        return {STAGE_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(NUM_STAGES)}
+
+    # ---- raw device memory ----
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().cusift_malloc(C.byref(p), nbytes))
+        return p.value
+
+    def free(self, ptr):
+        check(lib().cusift_free(C.c_void_p(ptr)))
+
+    def memset(self, ptr, value, nbytes):
+        check(lib().cusift_memset(self.handle, C.c_void_p(ptr), value, nbytes))
+
+    def h2d(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(lib().cusift_memcpy_h2d(self.handle, C.c_void_p(d_ptr), arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr, d_ptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(lib().cusift_memcpy_d2h(self.handle, arr.ctypes.data, C.c_void_p(d_ptr), arr.nbytes))
+
+    # ---- stage entry points (device pointers are plain ints) ----
+    def scale_down(self, d_dst, dst_pitch, d_src, w, h, src_pitch, n_images=1, dst_stride=None, src_stride=None):
+        dst_stride = (h // 2) * dst_pitch if dst_stride is None else dst_stride
+        src_stride = h * src_pitch if src_stride is None else src_stride
+        check(lib().cusift_scale_down(self.handle, d_dst, dst_pitch, dst_stride, d_src, w, h, src_pitch, src_stride,
+                                      n_images))
+
+    def laplace_multi(self, d_img, w, h, pitch, init_blur, d_dog, n_images=1, img_stride=None, dog_stride=None):
+        img_stride = h * pitch if img_stride is None else img_stride
+        dog_stride = 7 * h * pitch if dog_stride is None else dog_stride
+        check(lib().cusift_laplace_multi(self.handle, d_img, w, h, pitch, img_stride, init_blur, d_dog, dog_stride,
+                                         n_images))
+
+    def find_points_multi(self, d_dog, w, h, pitch, peak_thresh, edge_thresh, subsampling, d_points, max_pts,
+                          d_counters, n_images=1, dog_stride=None):
+        dog_stride = 7 * h * pitch if dog_stride is None else dog_stride
+        check(lib().cusift_find_points_multi(self.handle, d_dog, w, h, pitch, dog_stride, peak_thresh, edge_thresh,
+                                             subsampling, d_points, max_pts, d_counters, n_images))
+
+    def compute_orientations(self, d_img, w, h, pitch, d_points, max_pts, d_first, d_counters, tex_frac_bits=8,
+                             n_images=1, img_stride=None):
+        img_stride = h * pitch if img_stride is None else img_stride
+        check(lib().cusift_compute_orientations(self.handle, d_img, w, h, pitch, img_stride, d_points, max_pts,
+                                                d_first, d_counters, tex_frac_bits, n_images))
+
+    def extract_descriptors(self, d_img, w, h, pitch, d_points, max_pts, d_first, d_counters, subsampling,
+                            tex_frac_bits=8, n_images=1, img_stride=None):
+        img_stride = h * pitch if img_stride is None else img_stride
+        check(lib().cusift_extract_descriptors(self.handle, d_img, w, h, pitch, img_stride, d_points, max_pts,
+                                               d_first, d_counters, subsampling, tex_frac_bits, n_images))
+
+    def rootsift(self, d_points, num_pts):
+        check(lib().cusift_rootsift(self.handle, d_points, num_pts))
+
+    # ---- drivers ----
+    def extract_batch(self, d_imgs, n_images, w, h, pitch, image_stride, params, d_points, d_counters):
+        check(lib().cusift_extract_batch(self.handle, d_imgs, n_images, w, h, pitch, image_stride, C.byref(params),
+                                         d_points, d_counters))
+
+    def extract(self, d_img, w, h, pitch, params, d_points, h_points=None):
+        n = C.c_int(0)
+        hp = h_points.ctypes.data if h_points is not None else None
+        check(lib().cusift_extract(self.handle, d_img, w, h, pitch, C.byref(params), d_points, hp, C.byref(n)))
+        return n.value
+
+    def extract_host(self, img, params, d_points, h_points=None):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        h, w = img.shape
+        n = C.c_int(0)
+        hp = h_points.ctypes.data if h_points is not None else None
+        check(lib().cusift_extract_host(self.handle, img.ctypes.data, w, h, C.byref(params), d_points, hp,
+                                        C.byref(n)))
+        return n.value
+
+
+def laplace_taps(init_blur):
+    taps = np.zeros(8 * 16, dtype=np.float32)
+    check(lib().cusift_laplace_taps(init_blur, taps.ctypes.data))
+    return taps
+
+
+class DeviceBuffer:
+    """A raw HBM allocation made through the C ABI (cusift_malloc / cusift_free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.ptr = ctx.malloc(self.nbytes)
+
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, arr.nbytes)
+        ctx.h2d(buf.ptr, arr)
+        return buf
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
+        self.ctx.d2h(out, self.ptr)
+        return out
+
+    def zero(self):
+        self.ctx.memset(self.ptr, 0, self.nbytes)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,679 @@
+// sift_capi.hip -- the C ABI (include/cusift_amd.h) over the gfx950 kernels: context, scratch arena,
+// launch wrappers and the octave driver.  Host logic follows cuSIFT.cu (cited per function); nothing
+// here allocates, frees or reads back between stages once the arena is sized.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "sift_types.h"
+
+namespace cusift {
+// kernels (sift_kernels.hip)
+__global__ void scale_down_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
+__global__ void laplace_multi_kernel(const float *, float *, int, int, int, long, long, int, int, LaplaceTaps);
+__global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
+                                   FindParams);
+__global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
+                                    const unsigned int *, float, float);
+__global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
+                                   const unsigned int *, float, float, float);
+__global__ void rootsift_kernel(cusift_point *, int);
+}  // namespace cusift
+
+using namespace cusift;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess)                                                                                    \
+      return fail(CUSIFT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+#define TRY(expr)              \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != CUSIFT_OK) return rc_; \
+  } while (0)
+
+static inline int idiv_up(int a, int b) { return (a + b - 1) / b; }
+static inline int ialign_up(int a, int b) { return idiv_up(a, b) * b; }  // cutils.h:17
+static inline size_t align_up_sz(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct TimedSpan {
+  hipEvent_t start, stop;
+  int stage;
+};
+
+struct cusift_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // scratch arena (one allocation, grown on demand, never shrunk)
+  char *arena = nullptr;
+  size_t arena_bytes = 0;
+  // small persistent device scratch for the blocking single-image entry points
+  unsigned int *d_counter1 = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;       // recorded, not yet folded
+  std::vector<hipEvent_t> event_pool;  // free events
+  float ms[CUSIFT_NUM_STAGES] = {0};
+  int launches[CUSIFT_NUM_STAGES] = {0};
+};
+
+namespace {
+
+struct StageTimer {
+  cusift_ctx *ctx;
+  int stage;
+  hipEvent_t start = nullptr, stop = nullptr;
+  StageTimer(cusift_ctx *c, int s) : ctx(c), stage(s) {
+    if (!ctx->timing) return;
+    start = take();
+    stop = take();
+    if (start) (void)hipEventRecord(start, ctx->stream);
+  }
+  ~StageTimer() {
+    if (!ctx->timing || !start || !stop) return;
+    (void)hipEventRecord(stop, ctx->stream);
+    ctx->spans.push_back({start, stop, stage});
+  }
+  hipEvent_t take() {
+    if (!ctx->event_pool.empty()) {
+      hipEvent_t e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+
+int fold_spans(cusift_ctx *ctx) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto &s : ctx->spans) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, s.start, s.stop));
+    ctx->ms[s.stage] += t;
+    ctx->launches[s.stage] += 1;
+    ctx->event_pool.push_back(s.start);
+    ctx->event_pool.push_back(s.stop);
+  }
+  ctx->spans.clear();
+  return CUSIFT_OK;
+}
+
+// Octave geometry of one extraction (cuSIFT.cu:76-91,175-190).
+struct Plan {
+  int n_oct = 0;
+  int w[kMaxOctaves], h[kMaxOctaves], p[kMaxOctaves];
+  double blur[kMaxOctaves];
+  float sub[kMaxOctaves];
+  // arena offsets in bytes
+  size_t base_off[kMaxOctaves];  // octave >= 1 base images (n * h*p floats each); [0] unused
+  size_t dog_off = 0, first_off = 0, total = 0;
+  size_t dog_stride = 0;  // floats per image
+};
+
+int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm) {
+  if (!prm) return fail(CUSIFT_ERR_INVALID, "params is NULL");
+  if (n_images < 1 || w < 1 || h < 1 || pitch < w)
+    return fail(CUSIFT_ERR_INVALID, "bad geometry n=%d w=%d h=%d pitch=%d", n_images, w, h, pitch);
+  if (prm->max_pts < 1) return fail(CUSIFT_ERR_INVALID, "max_pts must be >= 1");
+  int n = std::max(1, std::min(prm->num_octaves, kMaxOctaves));
+  pl.w[0] = w;
+  pl.h[0] = h;
+  pl.p[0] = pitch;
+  pl.blur[0] = prm->init_blur;
+  pl.sub[0] = prm->subsampling;
+  pl.n_oct = 1;
+  for (int o = 1; o < n; ++o) {
+    int ww = pl.w[o - 1] / 2, hh = pl.h[o - 1] / 2;  // integer division, cuSIFT.cu:182
+    if (ww < 1 || hh < 1) break;
+    pl.w[o] = ww;
+    pl.h[o] = hh;
+    pl.p[o] = ialign_up(ww, 128);  // cuSIFT.cu:183
+    // cuSIFT.cu:188: float totInitBlur = (float)sqrt(initBlur*initBlur + 0.5f*0.5f) / 2.0f;
+    float tot = (float)sqrt(pl.blur[o - 1] * pl.blur[o - 1] + 0.5f * 0.5f) / 2.0f;
+    pl.blur[o] = tot;
+    pl.sub[o] = pl.sub[o - 1] * 2.0f;
+    pl.n_oct = o + 1;
+  }
+  size_t off = 0;
+  pl.base_off[0] = 0;
+  for (int o = 1; o < pl.n_oct; ++o) {
+    pl.base_off[o] = off;
+    off = align_up_sz(off + (size_t)n_images * pl.h[o] * pl.p[o] * sizeof(float), 256);
+  }
+  pl.dog_off = off;
+  pl.dog_stride = (size_t)kNumDog * pl.h[0] * pl.p[0];
+  off = align_up_sz(off + (size_t)n_images * pl.dog_stride * sizeof(float), 256);
+  pl.first_off = off;
+  off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
+  pl.total = off;
+  return CUSIFT_OK;
+}
+
+int ensure_arena(cusift_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->arena_bytes) return CUSIFT_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
+  ctx->arena = nullptr;
+  ctx->arena_bytes = 0;
+  hipError_t e = hipMalloc((void **)&ctx->arena, bytes);
+  if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "arena hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  ctx->arena_bytes = bytes;
+  return CUSIFT_OK;
+}
+
+// rows each wave marches: as large as possible (less halo re-read) while the launch still has
+// >= ~2 waves per SIMD on 256 CUs.
+int pick_rows(int h, int strips, int n_images, int lo, int hi) {
+  const long target_waves = 256L * 4 * 2 * 2;
+  long r = (long)h * strips * n_images / target_waves;
+  if (r < lo) r = lo;
+  if (r > hi) r = hi;
+  return (int)r;
+}
+
+void scale_down_taps(ScaleDownTaps &T) {
+  // cuSIFT.cu:320-341 with variance = 0.5 (cuSIFT.cu:185)
+  const float variance = 0.5f;
+  float k[5], sum = 0.0f;
+  for (int j = 0; j < 5; j++) {
+    k[j] = (float)expf(-(double)(j - 2) * (j - 2) / 2.0 / variance);
+    sum += k[j];
+  }
+  for (int j = 0; j < 5; j++) k[j] /= sum;
+  T.k[0] = k[0];
+  T.k[1] = k[1];
+  T.k[2] = k[2];
+}
+
+void laplace_taps_table(float init_blur, float taps[8 * 16]) {
+  // cuSIFT.cu:239-240,400-412.  Rule of this build: var <= 1e-6 => identity (the reference produces
+  // NaN taps at var == 0 and an inverted kernel at var < 0; see DESIGN.md "degenerate initBlur").
+  const float baseBlur = powf(2.0f, -1.0f / kNumScales);
+  const float diffScale = powf(2.0f, 1.0f / kNumScales);
+  float scale = baseBlur;
+  memset(taps, 0, sizeof(float) * 8 * 16);
+  for (int i = 0; i < kNumLevels; i++) {
+    float kernelSum = 0.0f;
+    float var = scale * scale - init_blur * init_blur;
+    float *k = taps + 16 * i;
+    if (var <= 1e-6f) {
+      k[kBlurRadius] = 1.0f;
+    } else {
+      for (int j = -kBlurRadius; j <= kBlurRadius; j++) {
+        k[j + kBlurRadius] = (float)expf(-(double)j * j / 2.0 / var);
+        kernelSum += k[j + kBlurRadius];
+      }
+      for (int j = -kBlurRadius; j <= kBlurRadius; j++) k[j + kBlurRadius] /= kernelSum;
+    }
+    scale *= diffScale;
+  }
+}
+
+void find_params(FindParams &P, float peak_thresh, float edge_thresh, float subsampling) {
+  // cuSIFT.cu:239-247 (sigma = baseBlur*diffScale, factor = 1/NUM_SCALES), cuSIFT.cu:432-444
+  const float baseBlur = powf(2.0f, -1.0f / kNumScales);
+  const float diffScale0 = powf(2.0f, 1.0f / kNumScales);
+  const double sigma = baseBlur * diffScale0;
+  const float factor = 1.0f / kNumScales;
+  float scale = (float)sigma;
+  const float diffScale = powf(2.0f, factor);
+  for (int i = 0; i < kNumScales; i++) {
+    P.scales[i] = scale;
+    scale *= diffScale;
+  }
+  P.thr_pos = peak_thresh;
+  P.thr_neg = -peak_thresh;
+  P.edge_limit = edge_thresh;
+  P.factor = factor;
+  P.subsampling = subsampling;
+}
+
+void frac_consts(int frac_bits, float &q, float &inv_q) {
+  if (frac_bits > 0 && frac_bits < 24) {
+    q = (float)(1 << frac_bits);
+    inv_q = 1.0f / q;
+  } else {
+    q = 0.0f;
+    inv_q = 0.0f;
+  }
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CUSIFT_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+  return CUSIFT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// process / device
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *cusift_last_error(void) { return g_err.c_str(); }
+extern "C" const char *cusift_version(void) { return "cusift_amd 0.1 (gfx950)"; }
+
+extern "C" int cusift_device_count(int *count) {
+  if (!count) return fail(CUSIFT_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  *count = n;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_init(int device) {
+  // InitCuda, cutils.h:71-92: clamp into [0, n-1], select
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(CUSIFT_ERR_NO_DEVICE, "no HIP device available");
+  device = std::max(0, std::min(n - 1, device));
+  HIP_TRY(hipSetDevice(device));
+  return CUSIFT_OK;
+}
+
+extern "C" void cusift_default_params(cusift_params *p) {
+  if (!p) return;
+  p->num_octaves = 5;
+  p->init_blur = 0.0;
+  p->peak_thresh = 3.0f;
+  p->edge_thresh = 10.0f;  // the only value the reference uses (test/detector.cpp:46)
+  p->lowest_scale = 0.0f;
+  p->subsampling = 1.0f;
+  p->max_pts = 1024;  // SiftData ctor default (cuSIFT.h:56)
+  p->tex_frac_bits = 8;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream) {
+  if (!out) return fail(CUSIFT_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(CUSIFT_ERR_NO_DEVICE, "no HIP device available");
+  if (device < 0 || device >= n) return fail(CUSIFT_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  cusift_ctx *ctx = new cusift_ctx();
+  ctx->device = device;
+  if (hip_stream) {
+    ctx->stream = (hipStream_t)hip_stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(CUSIFT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    ctx->owns_stream = true;
+  }
+  hipError_t e = hipMalloc((void **)&ctx->d_counter1, 256);
+  if (e != hipSuccess) {
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return fail(CUSIFT_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  *out = ctx;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
+  if (!ctx) return CUSIFT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &s : ctx->spans) {
+    (void)hipEventDestroy(s.start);
+    (void)hipEventDestroy(s.stop);
+  }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
+  if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_ctx_synchronize(cusift_ctx *ctx) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" void *cusift_ctx_stream(cusift_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  Plan pl;
+  TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p));
+  // + one pitched upload image for cusift_extract_host
+  return ensure_arena(ctx, pl.total + align_up_sz((size_t)h * ialign_up(w, 128) * sizeof(float), 256));
+}
+
+extern "C" size_t cusift_ctx_arena_bytes(cusift_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+extern "C" int cusift_ctx_timing_enable(cusift_ctx *ctx, int on) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!on && ctx->timing) TRY(fold_spans(ctx));
+  ctx->timing = on != 0;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGES], int launches[CUSIFT_NUM_STAGES]) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(fold_spans(ctx));
+  for (int i = 0; i < CUSIFT_NUM_STAGES; ++i) {
+    if (ms) ms[i] = ctx->ms[i];
+    if (launches) launches[i] = ctx->launches[i];
+  }
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_ctx_timing_reset(cusift_ctx *ctx) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(fold_spans(ctx));
+  for (int i = 0; i < CUSIFT_NUM_STAGES; ++i) {
+    ctx->ms[i] = 0.f;
+    ctx->launches[i] = 0;
+  }
+  return CUSIFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_malloc(void **d_ptr, size_t bytes) {
+  if (!d_ptr) return fail(CUSIFT_ERR_INVALID, "d_ptr is NULL");
+  *d_ptr = nullptr;
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+  if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_free(void *d_ptr) {
+  if (d_ptr) HIP_TRY(hipFree(d_ptr));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_malloc_host(void **h_ptr, size_t bytes) {
+  if (!h_ptr) return fail(CUSIFT_ERR_INVALID, "h_ptr is NULL");
+  *h_ptr = nullptr;
+  hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_free_host(void *h_ptr) {
+  if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_memset(cusift_ctx *ctx, void *d_ptr, int value, size_t bytes) {
+  if (!ctx || !d_ptr) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_memcpy_h2d(cusift_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+  if (!ctx || !d_dst || !h_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_memcpy_d2h(cusift_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+  if (!ctx || !h_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_image_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const float *h_src, int w, int h) {
+  if (!ctx || !d_dst || !h_src || w < 1 || h < 1 || dst_pitch < w) return fail(CUSIFT_ERR_INVALID, "bad argument");
+  // cuImage::HostToDevice, cuImage.cu:83-92: dense host rows -> pitched device rows
+  HIP_TRY(hipMemcpy2DAsync(d_dst, sizeof(float) * dst_pitch, h_src, sizeof(float) * w, sizeof(float) * w, h,
+                           hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_src, int src_pitch, int w, int h) {
+  if (!ctx || !h_dst || !d_src || w < 1 || h < 1 || src_pitch < w) return fail(CUSIFT_ERR_INVALID, "bad argument");
+  HIP_TRY(hipMemcpy2DAsync(h_dst, sizeof(float) * w, d_src, sizeof(float) * src_pitch, sizeof(float) * w, h,
+                           hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
+                                 int w, int h, int src_pitch, size_t src_stride, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "ScaleDown: missing data");  // cuSIFT.cu:315-318
+  const int ow = w / 2, oh = h / 2;
+  if (n_images < 1 || ow < 1 || oh < 1 || src_pitch < w || dst_pitch < ow)
+    return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
+  ScaleDownTaps T;
+  scale_down_taps(T);
+  const int strips = idiv_up(ow, 64);
+  const int rows = pick_rows(oh, strips, n_images, 4, 16);
+  dim3 grid(strips, idiv_up(idiv_up(oh, rows), kWavesPerBlock), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
+  hipLaunchKernelGGL(scale_down_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride, d_src, w,
+                     h, src_pitch, (long)src_stride, rows, T);
+  return check_launch("scale_down");
+}
+
+extern "C" int cusift_laplace_taps(float init_blur, float taps[8 * 16]) {
+  if (!taps) return fail(CUSIFT_ERR_INVALID, "taps is NULL");
+  laplace_taps_table(init_blur, taps);
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                                    float init_blur, float *d_dog, size_t dog_stride, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_img || !d_dog) return fail(CUSIFT_ERR_INVALID, "LaplaceMulti: missing data");
+  if (n_images < 1 || w < 1 || h < 1 || pitch < w) return fail(CUSIFT_ERR_INVALID, "LaplaceMulti: bad geometry");
+  if (n_images > 1 && dog_stride < (size_t)kNumDog * h * pitch)
+    return fail(CUSIFT_ERR_INVALID, "LaplaceMulti: dog_stride too small");
+  float taps[8 * 16];
+  laplace_taps_table(init_blur, taps);
+  LaplaceTaps T;
+  for (int s = 0; s < kNumLevels; ++s)
+    for (int j = 0; j < 5; ++j) T.k[s][j] = taps[16 * s + j];
+  const int vec_ok = (pitch % 4 == 0) && (((uintptr_t)d_img % 16) == 0) && (((uintptr_t)d_dog % 16) == 0) &&
+                     (img_stride % 4 == 0) && (dog_stride % 4 == 0) && (((size_t)h * pitch) % 4 == 0);
+  const int strips = idiv_up(w, kBlurStrip);
+  const int rows = pick_rows(h, strips, n_images, 8, 32);
+  dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_LAPLACE);
+  hipLaunchKernelGGL(laplace_multi_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
+                     (long)img_stride, (long)dog_stride, rows, vec_ok, T);
+  return check_launch("laplace_multi");
+}
+
+extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int w, int h, int pitch,
+                                        size_t dog_stride, float peak_thresh, float edge_thresh, float subsampling,
+                                        cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_dog || !d_points || !d_counters)
+    return fail(CUSIFT_ERR_INVALID, "FindPointsMulti: missing data");  // cuSIFT.cu:425-428
+  if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "FindPointsMulti: bad geometry");
+  FindParams P;
+  find_params(P, peak_thresh, edge_thresh, subsampling);
+  const int vec_ok = (pitch % 2 == 0) && (((uintptr_t)d_dog % 8) == 0) && (dog_stride % 2 == 0) &&
+                     (((size_t)h * pitch) % 2 == 0);
+  const int strips = idiv_up(w, kFindStrip);
+  const int rows = pick_rows(h, strips, n_images, 8, 32);
+  dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_FINDPOINTS);
+  hipLaunchKernelGGL(find_points_kernel, grid, dim3(256), 0, ctx->stream, d_dog, w, h, pitch, (long)dog_stride,
+                     d_points, max_pts, d_counters, rows, vec_ok, P);
+  return check_launch("find_points_multi");
+}
+
+static int keypoint_grid_x(int max_pts, int n_images) {
+  // persistent grid: enough waves to fill 256 CUs x 32 wave slots, never more than max_pts per image
+  int per_image = std::max(1, (256 * 32 * 2) / std::max(1, n_images));
+  return std::max(1, std::min(max_pts, std::min(per_image, 4096)));
+}
+
+extern "C" int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch,
+                                           size_t img_stride, cusift_point *d_points, int max_pts,
+                                           const unsigned int *d_first, const unsigned int *d_counters,
+                                           int tex_frac_bits, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ComputeOrientations: missing data");
+  if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "ComputeOrientations: bad geometry");
+  float q, inv_q;
+  frac_consts(tex_frac_bits, q, inv_q);
+  dim3 grid(keypoint_grid_x(max_pts, n_images), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_ORIENT);
+  hipLaunchKernelGGL(orientations_kernel, grid, dim3(64), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
+                     d_points, max_pts, d_first, d_counters, q, inv_q);
+  return check_launch("compute_orientations");
+}
+
+extern "C" int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch,
+                                          size_t img_stride, cusift_point *d_points, int max_pts,
+                                          const unsigned int *d_first, const unsigned int *d_counters,
+                                          float subsampling, int tex_frac_bits, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: missing data");
+  if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: bad geometry");
+  float q, inv_q;
+  frac_consts(tex_frac_bits, q, inv_q);
+  dim3 grid(keypoint_grid_x(max_pts, n_images), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_DESCR);
+  hipLaunchKernelGGL(descriptors_kernel, grid, dim3(64), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
+                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q);
+  return check_launch("extract_descriptors");
+}
+
+extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_points) return fail(CUSIFT_ERR_INVALID, "ConvertSiftToRootSift: missing data");
+  if (num_pts <= 0) return CUSIFT_OK;
+  dim3 grid(std::min(num_pts, 256 * 32));
+  hipLaunchKernelGGL(rootsift_kernel, grid, dim3(64), 0, ctx->stream, d_points, num_pts);
+  return check_launch("rootsift");
+}
+
+// ------------------------------------------------------------------------------------------------
+// drivers
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_images, int w, int h, int pitch,
+                                    size_t image_stride, const cusift_params *prm, cusift_point *d_points,
+                                    unsigned int *d_counters) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_imgs || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "extract: missing data");
+  if (n_images > 1 && image_stride < (size_t)h * pitch) return fail(CUSIFT_ERR_INVALID, "image_stride too small");
+  Plan pl;
+  TRY(make_plan(pl, n_images, w, h, pitch, prm));
+  TRY(ensure_arena(ctx, pl.total));
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  StageTimer total(ctx, CUSIFT_STAGE_TOTAL);
+  // cuSIFT.cu:69: point counter = 0
+  HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));
+
+  const float *base[kMaxOctaves];
+  size_t stride[kMaxOctaves];
+  base[0] = d_imgs;
+  stride[0] = image_stride;
+  // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest
+  for (int o = 1; o < pl.n_oct; ++o) {
+    float *dst = (float *)(ctx->arena + pl.base_off[o]);
+    stride[o] = (size_t)pl.h[o] * pl.p[o];
+    TRY(cusift_scale_down(ctx, dst, pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1], pl.p[o - 1],
+                          stride[o - 1], n_images));
+    base[o] = dst;
+  }
+  float *dog = (float *)(ctx->arena + pl.dog_off);
+  unsigned int *first = (unsigned int *)(ctx->arena + pl.first_off);
+  // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
+  for (int o = pl.n_oct - 1; o >= 0; --o) {
+    if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
+    // ExtractSiftOctave, cuSIFT.cu:204-270
+    const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
+    TRY(cusift_laplace_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], dog, dstride,
+                             n_images));
+    unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
+    HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
+    TRY(cusift_find_points_multi(ctx, dog, pl.w[o], pl.h[o], pl.p[o], dstride, prm->peak_thresh, prm->edge_thresh,
+                                 pl.sub[o], d_points, prm->max_pts, d_counters, n_images));
+    TRY(cusift_compute_orientations(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
+                                    d_counters, prm->tex_frac_bits, n_images));
+    TRY(cusift_extract_descriptors(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
+                                   d_counters, pl.sub[o], prm->tex_frac_bits, n_images));
+  }
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, const cusift_params *prm,
+                              cusift_point *d_points, cusift_point *h_points, int *num_pts) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!num_pts) return fail(CUSIFT_ERR_INVALID, "num_pts is NULL");
+  *num_pts = 0;
+  TRY(cusift_extract_batch(ctx, d_img, 1, w, h, pitch, (size_t)h * pitch, prm, d_points, ctx->d_counter1));
+  unsigned int cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, ctx->d_counter1, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // cuSIFT.cu:107-110
+  const int n = cnt < (unsigned int)prm->max_pts ? (int)cnt : prm->max_pts;
+  *num_pts = n;
+  if (h_points && n > 0) {  // SiftData::Synchronize, cuSIFT.cu:52-59
+    HIP_TRY(hipMemcpyAsync(h_points, d_points, sizeof(cusift_point) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_extract_host(cusift_ctx *ctx, const float *h_img, int w, int h, const cusift_params *prm,
+                                   cusift_point *d_points, cusift_point *h_points, int *num_pts) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!h_img) return fail(CUSIFT_ERR_INVALID, "image is NULL");
+  if (w < 1 || h < 1) return fail(CUSIFT_ERR_INVALID, "bad image size %dx%d", w, h);
+  const int pitch = ialign_up(w, 128);  // cuImage::AllocateWithHostMemory, cuImage.cu:11-13
+  Plan pl;
+  TRY(make_plan(pl, 1, w, h, pitch, prm));
+  const size_t img_bytes = align_up_sz((size_t)h * pitch * sizeof(float), 256);
+  TRY(ensure_arena(ctx, pl.total + img_bytes));
+  float *d_img = (float *)(ctx->arena + pl.total);
+  HIP_TRY(hipMemcpy2DAsync(d_img, sizeof(float) * pitch, h_img, sizeof(float) * w, sizeof(float) * w, h,
+                           hipMemcpyHostToDevice, ctx->stream));
+  return cusift_extract(ctx, d_img, w, h, pitch, prm, d_points, h_points, num_pts);
+}

@@ -1,0 +1,620 @@
+// sift_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the SIFT extraction path.
+//
+// Design (DESIGN.md has the full account):
+//  * The two HBM-bound stencils (blur+DoG, extrema) are "wave-autonomous column strips": a 64-lane
+//    wave owns a strip of columns (4 or 2 per lane, read as float4/float2 = 1 KiB/512 B per wave
+//    instruction), marches down its rows with a register sliding window and gets its horizontal
+//    neighbours from the adjacent lanes with DPP wave shifts.  No LDS, no barriers, no re-reads
+//    except the row/column halo; every wave is independent so occupancy hides HBM latency.
+//  * Keypoint kernels (orientation, descriptor) run one wave per keypoint on a persistent grid that
+//    reads the point count from device memory -- no host read-back between stages.
+//  * Arithmetic follows oracle/sift_oracle.c operation by operation (explicit fmaf chains in the
+//    filters, nothing else fused: this file is built with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+
+#include "sift_types.h"
+
+namespace cusift {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// lane i receives the value of lane i-1 (lane 0 receives 0): DPP wave_shr:1
+__device__ __forceinline__ float from_prev_lane(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+// lane i receives the value of lane i+1 (lane 63 receives 0): DPP wave_shl:1
+__device__ __forceinline__ float from_next_lane(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// ------------------------------------------------------------------------------------------------
+// ScaleDown: 5x5 separable low-pass + 2x decimation.  Reference: ScaleDown_D, cuSIFT_D.cu:37-182.
+// One lane per output column, marching down output rows; the five horizontally filtered source rows
+// (2r-1 .. 2r+3) live in registers and slide by two per output row.
+//   horizontal (cuSIFT_D.cu:111-113): k0*(S[2c-2]+S[2c+2]) + k1*(S[2c-1]+S[2c+1]) + k2*S[2c]
+//   vertical   (cuSIFT_D.cu:123-125): k2*B[2r] + k0*(B[2r+3]+B[2r+2]) + k1*(B[2r-1]+B[2r+1])
+// (the asymmetric vertical support is the reference's: yRead = yStart + tx - 1, cuSIFT_D.cu:75).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) scale_down_kernel(float *__restrict__ dst, int dst_pitch, long dst_stride,
+                                                        const float *__restrict__ src, int w, int h, int src_pitch,
+                                                        long src_stride, int rows_per_wave, ScaleDownTaps T) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int ow = w >> 1, oh = h >> 1;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = (blockIdx.y * kWavesPerBlock + wv) * rows_per_wave;
+  if (r0 >= oh) return;
+  const int r1 = min(r0 + rows_per_wave, oh);
+  src += (long)blockIdx.z * src_stride;
+  dst += (long)blockIdx.z * dst_stride;
+  const int x0 = clampi(2 * c - 2, 0, w - 1), x1 = clampi(2 * c - 1, 0, w - 1), x2 = clampi(2 * c, 0, w - 1),
+            x3 = clampi(2 * c + 1, 0, w - 1), x4 = clampi(2 * c + 2, 0, w - 1);
+  const float k0 = T.k[0], k1 = T.k[1], k2 = T.k[2];
+  auto hrow = [&](int y) -> float {
+    const float *s = src + (long)clampi(y, 0, h - 1) * src_pitch;
+    float v = k0 * (s[x0] + s[x4]);
+    v = fmaf(k1, s[x1] + s[x3], v);
+    v = fmaf(k2, s[x2], v);
+    return v;
+  };
+  float bm1 = hrow(2 * r0 - 1), b0 = hrow(2 * r0), bp1 = hrow(2 * r0 + 1);
+  for (int r = r0; r < r1; ++r) {
+    const float bp2 = hrow(2 * r + 2), bp3 = hrow(2 * r + 3);
+    float v = k2 * b0;
+    v = fmaf(k0, bp3 + bp2, v);
+    v = fmaf(k1, bm1 + bp1, v);
+    if (c < ow) dst[(long)r * dst_pitch + c] = v;
+    bm1 = bp1;
+    b0 = bp2;
+    bp1 = bp3;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LaplaceMulti: 8 Gaussian blurs (9-tap separable, vertical then horizontal, clamp borders) of the
+// octave base image and the 7 differences, fused.  Reference: LaplaceMulti_D, cuSIFT_D.cu:525-553.
+//
+// Each lane owns kBlurCols=4 adjacent columns; a wave owns 256 columns of which lanes 1..62 (248
+// columns) produce output and lanes 0/63 are the 4-column halo.  Per row: one float4 load per lane
+// (1 KiB per wave), a 9-row register window, the scale-independent pair sums S[y-k]+S[y+k], then per
+// level the vertical 9-tap (5 multiplies), the +-4 column exchange with the neighbouring lanes by
+// DPP, the horizontal 9-tap and the DoG against the previous level; 7 float4 stores per row.
+// Algorithmic HBM bytes: 4 read + 28 written per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restrict__ img, float *__restrict__ dog,
+                                                           int w, int h, int pitch, long img_stride, long dog_stride,
+                                                           int rows_per_wave, int vec_ok, LaplaceTaps T) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int y0 = (blockIdx.y * kWavesPerBlock + wv) * rows_per_wave;
+  if (y0 >= h) return;  // wave-uniform
+  const int y1 = min(y0 + rows_per_wave, h);
+  img += (long)blockIdx.z * img_stride;
+  dog += (long)blockIdx.z * dog_stride;
+
+  const int c0 = blockIdx.x * kBlurStrip - kBlurCols + lane * kBlurCols;  // first of this lane's 4 columns
+  const bool interior = vec_ok && c0 >= 0 && c0 + 3 < w;
+  const int cc0 = clampi(c0, 0, w - 1), cc1 = clampi(c0 + 1, 0, w - 1), cc2 = clampi(c0 + 2, 0, w - 1),
+            cc3 = clampi(c0 + 3, 0, w - 1);
+
+  float win[9][4];
+  auto load_row = [&](int y, float (&o)[4]) {
+    const float *r = img + (long)clampi(y, 0, h - 1) * pitch;
+    if (interior) {
+      const float4 v = *reinterpret_cast<const float4 *>(r + c0);
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+      o[0] = r[cc0]; o[1] = r[cc1]; o[2] = r[cc2]; o[3] = r[cc3];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) load_row(y0 - 4 + i, win[i]);
+
+  const bool writer = lane >= 1 && lane <= 62 && c0 < w;
+  const bool vec_store = vec_ok && (c0 + 3 < w);
+  const long plane = (long)h * pitch;
+
+  for (int y = y0; y < y1; ++y) {
+    load_row(y + 4, win[8]);
+    float ctr[4], p1[4], p2[4], p3[4], p4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ctr[j] = win[4][j];
+      p1[j] = win[3][j] + win[5][j];
+      p2[j] = win[2][j] + win[6][j];
+      p3[j] = win[1][j] + win[7][j];
+      p4[j] = win[0][j] + win[8][j];
+    }
+    float prevL[4];
+    float *out = dog + (long)y * pitch + c0;
+#pragma unroll
+    for (int s = 0; s < kNumLevels; ++s) {
+      const float k0 = T.k[s][0], k1 = T.k[s][1], k2 = T.k[s][2], k3 = T.k[s][3], k4 = T.k[s][4];
+      float e[12];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = k4 * ctr[j];
+        v = fmaf(k3, p1[j], v);
+        v = fmaf(k2, p2[j], v);
+        v = fmaf(k1, p3[j], v);
+        v = fmaf(k0, p4[j], v);
+        e[4 + j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        e[j] = from_prev_lane(e[4 + j]);
+        e[8 + j] = from_next_lane(e[4 + j]);
+      }
+      float L[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = 4 + j;
+        float v = k4 * e[m];
+        v = fmaf(k3, e[m - 1] + e[m + 1], v);
+        v = fmaf(k2, e[m - 2] + e[m + 2], v);
+        v = fmaf(k1, e[m - 3] + e[m + 3], v);
+        v = fmaf(k0, e[m - 4] + e[m + 4], v);
+        L[j] = v;
+      }
+      if (s > 0 && writer) {
+        float *o = out + (long)(s - 1) * plane;
+        if (vec_store) {
+          *reinterpret_cast<float4 *>(o) =
+              make_float4(prevL[0] - L[0], prevL[1] - L[1], prevL[2] - L[2], prevL[3] - L[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + j < w) o[j] = prevL[j] - L[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prevL[j] = L[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[i][j] = win[i + 1][j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FindPointsMulti: 26-neighbour DoG extrema for the 5 searchable scales, edge test, 3-D quadratic
+// refinement and append.  Reference: FindPointsMulti_D, cuSIFT_D.cu:402-523.
+//
+// Each lane owns kFindCols=2 columns (float2 loads, 512 B per wave instruction) of all 7 planes with a
+// 3-row register window; column minima/maxima are exchanged with the neighbouring lanes by DPP.
+// Candidates (rare) are refined by the detecting lane from L2-resident data and appended with one
+// atomic per candidate (the compiler aggregates them per wave).  Algorithmic HBM bytes: 28 per pixel.
+// Not reproduced from the reference: the per-tile candidate list that wraps at 32,
+// and the overflow path that overwrites slot maxPts-1 -- overflow is dropped here.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void refine_and_append(const float *__restrict__ dog, long plane, int pitch, int x, int y,
+                                                   int s, const FindParams &P, cusift_point *__restrict__ pts,
+                                                   int max_pts, unsigned int *counter) {
+  // cuSIFT_D.cu:478-521, evaluated operation by operation exactly as oracle_find_points_multi
+  const float *d1 = dog + (long)(s + 1) * plane + (long)y * pitch + x;
+  const float val = d1[0];
+  const float dxx = 2.0f * val - d1[-1] - d1[1];
+  const float dyy = 2.0f * val - d1[-pitch] - d1[pitch];
+  const float dxy = 0.25f * (d1[pitch + 1] + d1[-pitch - 1] - d1[-pitch + 1] - d1[pitch - 1]);
+  const float tra = dxx + dyy;
+  const float det = dxx * dyy - dxy * dxy;
+  if (!(tra * tra < P.edge_limit * det)) return;
+  const float edge = (tra * tra) / det;
+  const float dx = 0.5f * (d1[1] - d1[-1]);
+  const float dy = 0.5f * (d1[pitch] - d1[-pitch]);
+  const float *d0 = d1 - plane;
+  const float *d2 = d1 + plane;
+  const float ds = 0.5f * (d0[0] - d2[0]);
+  const float dss = 2.0f * val - d2[0] - d0[0];
+  const float dxs = 0.25f * (d2[1] + d0[-1] - d0[1] - d2[-1]);
+  const float dys = 0.25f * (d2[pitch] + d0[-pitch] - d2[-pitch] - d0[pitch]);
+  const float idxx = dyy * dss - dys * dys;
+  const float idxy = dys * dxs - dxy * dss;
+  const float idxs = dxy * dys - dyy * dxs;
+  const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
+  const float idyy = dxx * dss - dxs * dxs;
+  const float idys = dxy * dxs - dxx * dys;
+  const float idss = dxx * dyy - dxy * dxy;
+  float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
+  float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
+  float pds = idet * (idxs * dx + idys * dy + idss * ds);
+  if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
+    pdx = dx / dxx;
+    pdy = dy / dyy;
+    pds = ds / dss;
+  }
+  const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+  const unsigned int idx = atomicAdd(counter, 1u);
+  if (idx >= (unsigned int)max_pts) return;
+  cusift_point *pt = pts + idx;
+  pt->coords2D[0] = (float)x + pdx;
+  pt->coords2D[1] = (float)y + pdy;
+  pt->scale = P.scales[s] * exp2f(pds * P.factor);
+  pt->sharpness = val + dval;
+  pt->edgeness = edge;
+  pt->subsampling = P.subsampling;
+}
+
+__global__ void __launch_bounds__(256) find_points_kernel(const float *__restrict__ dog, int w, int h, int pitch,
+                                                         long dog_stride, cusift_point *__restrict__ points,
+                                                         int max_pts, unsigned int *__restrict__ counters,
+                                                         int rows_per_wave, int vec_ok, FindParams P) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int y0 = (blockIdx.y * kWavesPerBlock + wv) * rows_per_wave;
+  if (y0 >= h) return;
+  const int y1 = min(y0 + rows_per_wave, h);
+  dog += (long)blockIdx.z * dog_stride;
+  points += (long)blockIdx.z * max_pts;
+  unsigned int *counter = counters + blockIdx.z;
+
+  const int c0 = blockIdx.x * kFindStrip - kFindCols + lane * kFindCols;
+  const bool interior = vec_ok && c0 >= 0 && c0 + 1 < w;
+  const int cc0 = clampi(c0, 0, w - 1), cc1 = clampi(c0 + 1, 0, w - 1);
+  const long plane = (long)h * pitch;
+
+  float d[kNumDog][3][2];  // [plane][row y-1, y, y+1][column]
+  auto load_rows = [&](int y, int slot) {
+    const float *r = dog + (long)clampi(y, 0, h - 1) * pitch;
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p) {
+      if (interior) {
+        const float2 v = *reinterpret_cast<const float2 *>(r + (long)p * plane + c0);
+        d[p][slot][0] = v.x;
+        d[p][slot][1] = v.y;
+      } else {
+        d[p][slot][0] = r[(long)p * plane + cc0];
+        d[p][slot][1] = r[(long)p * plane + cc1];
+      }
+    }
+  };
+  // slots are rotated by copying (the compiler renames registers in the unrolled body)
+  load_rows(y0 - 1, 0);
+  load_rows(y0, 1);
+  const bool lane_valid = lane >= 1 && lane <= 62;
+
+  for (int y = y0; y < y1; ++y) {
+    load_rows(y + 1, 2);
+    float cmin[kNumDog][2], cmax[kNumDog][2], nmin[kNumDog][2][2], nmax[kNumDog][2][2];  // n*[p][j][0=left,1=right]
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        cmin[p][j] = fminf(fminf(d[p][0][j], d[p][1][j]), d[p][2][j]);
+        cmax[p][j] = fmaxf(fmaxf(d[p][0][j], d[p][1][j]), d[p][2][j]);
+      }
+      nmin[p][0][0] = from_prev_lane(cmin[p][1]);
+      nmin[p][0][1] = cmin[p][1];
+      nmin[p][1][0] = cmin[p][0];
+      nmin[p][1][1] = from_next_lane(cmin[p][0]);
+      nmax[p][0][0] = from_prev_lane(cmax[p][1]);
+      nmax[p][0][1] = cmax[p][1];
+      nmax[p][1][0] = cmax[p][0];
+      nmax[p][1][1] = from_next_lane(cmax[p][0]);
+    }
+    unsigned int cand = 0;  // bit (2*s + j)
+#pragma unroll
+    for (int s = 0; s < kNumScales; ++s) {
+      const int c = s + 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v = d[c][1][j];
+        // plane below / above: full 3x3; centre plane: 3x3 without the centre
+        float mn = fminf(fminf(nmin[c - 1][j][0], cmin[c - 1][j]), nmin[c - 1][j][1]);
+        mn = fminf(mn, fminf(fminf(nmin[c + 1][j][0], cmin[c + 1][j]), nmin[c + 1][j][1]));
+        mn = fminf(mn, fminf(fminf(nmin[c][j][0], nmin[c][j][1]), fminf(d[c][0][j], d[c][2][j])));
+        float mx = fmaxf(fmaxf(nmax[c - 1][j][0], cmax[c - 1][j]), nmax[c - 1][j][1]);
+        mx = fmaxf(mx, fmaxf(fmaxf(nmax[c + 1][j][0], cmax[c + 1][j]), nmax[c + 1][j][1]));
+        mx = fmaxf(mx, fmaxf(fmaxf(nmax[c][j][0], nmax[c][j][1]), fmaxf(d[c][0][j], d[c][2][j])));
+        const bool hit = (v < P.thr_neg && v < mn) || (v > P.thr_pos && v > mx);
+        cand |= (hit ? 1u : 0u) << (2 * s + j);
+      }
+    }
+    if (!lane_valid) cand = 0;
+    if (cand) {
+      // strict extrema cannot sit on the image border (a clamped neighbour equals the centre);
+      // the explicit range test keeps the refinement's reads in bounds for any input (NaN/Inf).
+      for (int b = 0; b < 2 * kNumScales; ++b) {
+        if (cand & (1u << b)) {
+          const int x = c0 + (b & 1), s = b >> 1;
+          if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2)
+            refine_and_append(dog, plane, pitch, x, y, s, P, points, max_pts, counter);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        d[p][0][j] = d[p][1][j];
+        d[p][1][j] = d[p][2][j];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software model of the CUDA texture fetch the reference relies on (gfx950 has no image unit):
+// tex2D<float>(x, y), cudaFilterModeLinear, clamp, unnormalised coordinates (cuSIFT.cu:227-233).
+// xB = x - 0.5, i = floor(xB), alpha = frac(xB) rounded to `frac_bits` bits.  Same operation order
+// as oracle_tex2d.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int h, int pitch, float x, float y,
+                                       float q, float inv_q) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (q > 0.0f) {
+    a = floorf(a * q + 0.5f) * inv_q;  // q is a power of two: * inv_q == / q exactly
+    b = floorf(b * q + 0.5f) * inv_q;
+  }
+  fx = fminf(fmaxf(fx, -1.0f), (float)w);
+  fy = fminf(fmaxf(fy, -1.0f), (float)h);
+  const int i = (int)fx, j = (int)fy;
+  const int i0 = clampi(i, 0, w - 1), i1 = clampi(i + 1, 0, w - 1);
+  const int j0 = clampi(j, 0, h - 1), j1 = clampi(j + 1, 0, h - 1);
+  const float s00 = img[(long)j0 * pitch + i0], s10 = img[(long)j0 * pitch + i1];
+  const float s01 = img[(long)j1 * pitch + i0], s11 = img[(long)j1 * pitch + i1];
+  const float ia = 1.0f - a, ib = 1.0f - b;
+  float t = (ia * ib) * s00;
+  t = t + (a * ib) * s10;
+  t = t + (ia * b) * s01;
+  t = t + (a * b) * s11;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ComputeOrientations: reference ComputeOrientations_D, cuSIFT_D.cu:319-396.
+// One wave per keypoint (persistent grid over [first, min(count,max_pts)) read from device memory).
+// 121 samples (11x11) -> 32-bin histogram in LDS.  The histogram is accumulated by lanes 0..31, each
+// walking the samples in index order, so the sums are deterministic and in the oracle's order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) orientations_kernel(const float *__restrict__ img, int w, int h, int pitch,
+                                                         long img_stride, cusift_point *__restrict__ points,
+                                                         int max_pts, const unsigned int *__restrict__ first,
+                                                         const unsigned int *__restrict__ counters, float q,
+                                                         float inv_q) {
+  __shared__ float hist[64];
+  __shared__ float gauss[11];
+  __shared__ float s_val[128];
+  __shared__ int s_bin[128];
+  const int tx = threadIdx.x;
+  img += (long)blockIdx.y * img_stride;
+  points += (long)blockIdx.y * max_pts;
+  const unsigned int fst = first ? first[blockIdx.y] : 0u;
+  const unsigned int cnt = counters[blockIdx.y];
+  const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
+
+  for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
+    cusift_point *pt = points + bx;
+    const float scale = pt->scale;
+    const float i2sigma2 = -1.0f / (4.5f * scale * scale);
+    if (tx < 11) gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
+    const float xp = pt->coords2D[0] - 5.0f;
+    const float yp = pt->coords2D[1] - 5.0f;
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int t = tx + 64 * rep;
+      if (t < 121) {
+        const int yd = t / 11;
+        const int xd = t - yd * 11;
+        const float xf = xp + xd;
+        const float yf = yp + yd;
+        const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q, inv_q) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q, inv_q);
+        const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q, inv_q) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q, inv_q);
+        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+        if (bin > 31 || bin < 0) bin = 0;  // < 0 only for non-finite input
+        const float grad = sqrtf(dx * dx + dy * dy);
+        s_bin[t] = bin;
+        s_val[t] = grad * gauss[xd] * gauss[yd];
+      }
+    }
+    __syncthreads();
+    if (tx < 32) {
+      float acc = 0.0f;
+      for (int t = 0; t < 121; ++t)
+        if (s_bin[t] == tx) acc += s_val[t];
+      hist[tx] = acc;
+    }
+    __syncthreads();
+    const int x1m = (tx >= 1 ? tx - 1 : tx + 31);
+    const int x1p = (tx <= 30 ? tx + 1 : tx - 31);
+    if (tx < 32) {
+      const int x2m = (tx >= 2 ? tx - 2 : tx + 30);
+      const int x2p = (tx <= 29 ? tx + 2 : tx - 30);
+      hist[tx + 32] = 6.0f * hist[tx] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
+    }
+    __syncthreads();
+    float pk = 0.0f;
+    if (tx < 32) {
+      const float v = hist[32 + tx];
+      pk = (v > hist[32 + x1m] && v >= hist[32 + x1p]) ? v : 0.0f;
+    }
+    __syncthreads();
+    if (tx < 32) hist[tx] = pk;
+    __syncthreads();
+    if (tx == 0) {
+      float maxval1 = 0.0f;
+      int i1 = -1;
+      for (int i = 0; i < 32; ++i) {
+        const float v = hist[i];
+        if (v > maxval1) {
+          maxval1 = v;
+          i1 = i;
+        }
+      }
+      const float val1 = hist[32 + ((i1 + 1) & 31)];
+      const float val2 = hist[32 + ((i1 + 31) & 31)];
+      const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+      pt->orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ExtractSiftDescriptors: reference ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.
+// One wave per keypoint; the 16x16 rotated sample grid is visited in 4 steps of 64 samples
+// (sample row y = 4*step + lane/16, column tx = lane%16); each sample makes up to 8 trilinear LDS
+// float-atomic adds into the 4x4x8 histogram.  All adds come from one wave in program order, so the
+// result is reproducible run to run.  Then L2-normalise, clamp at 0.2, L2-normalise (same reduction
+// tree as the reference) and scale the keypoint by `subsampling`.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_add(float *buffer, int idx, float v) {
+  if ((unsigned int)idx < 176u) atomicAdd(buffer + idx, v);  // always true for finite inputs
+}
+
+__global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict__ img, int w, int h, int pitch,
+                                                        long img_stride, cusift_point *__restrict__ points,
+                                                        int max_pts, const unsigned int *__restrict__ first,
+                                                        const unsigned int *__restrict__ counters, float subsampling,
+                                                        float q, float inv_q) {
+  __shared__ float buffer[128 + 48];  // indices 128..175 absorb the reference's out-of-range adds (dropped)
+  __shared__ float sums[64];
+  const int lane = threadIdx.x;
+  const int tx = lane & 15;
+  img += (long)blockIdx.y * img_stride;
+  points += (long)blockIdx.y * max_pts;
+  const unsigned int fst = first ? first[blockIdx.y] : 0u;
+  const unsigned int cnt = counters[blockIdx.y];
+  const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
+  const float gx = expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
+
+  for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
+    cusift_point *pt = points + bx;
+    buffer[lane] = 0.0f;
+    buffer[lane + 64] = 0.0f;
+    if (lane < 48) buffer[128 + lane] = 0.0f;
+    const float theta = 2.0f * 3.1415f / 360.0f * pt->orientation;
+    const float sina = sinf(theta);
+    const float cosa = cosf(theta);
+    const float scale = 12.0f / 16.0f * pt->scale;
+    const float ssina = scale * sina;
+    const float scosa = scale * cosa;
+    const float px = pt->coords2D[0], py = pt->coords2D[1];
+    __syncthreads();
+#pragma unroll 1
+    for (int step = 0; step < 4; ++step) {
+      const int y = 4 * step + (lane >> 4);
+      const float gy = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
+      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
+      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
+      const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q, inv_q) -
+                       tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q, inv_q);
+      const float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q, inv_q) -
+                       tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q, inv_q);
+      const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
+      float angf = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;
+
+      const int hori = (tx + 2) / 4 - 1;
+      const float horf = (tx - 1.5f) / 4.0f - hori;
+      const float ihorf = 1.0f - horf;
+      const int veri = (y + 2) / 4 - 1;
+      const float verf = (y - 1.5f) / 4.0f - veri;
+      const float iverf = 1.0f - verf;
+      const int angi = (int)angf;
+      const int angp = (angi < 7 ? angi + 1 : 0);
+      angf -= angi;
+      const float iangf = 1.0f - angf;
+
+      const int hist = 8 * (4 * veri + hori);
+      const int p1 = angi + hist;
+      const int p2 = angp + hist;
+      // every index the guards let through is in [0, 176); >= 128 is the dropped overflow region
+      if (tx >= 2) {
+        const float grad1 = ihorf * grad;
+        if (y >= 2) {
+          const float grad2 = iverf * grad1;
+          lds_add(buffer, p1, iangf * grad2);
+          lds_add(buffer, p2, angf * grad2);
+        }
+        if (y <= 13) {
+          const float grad2 = verf * grad1;
+          lds_add(buffer, p1 + 32, iangf * grad2);
+          lds_add(buffer, p2 + 32, angf * grad2);
+        }
+      }
+      if (tx <= 14) {  // sic (cuSIFT_D.cu:243)
+        const float grad1 = horf * grad;
+        if (y >= 2) {
+          const float grad2 = iverf * grad1;
+          lds_add(buffer, p1 + 8, iangf * grad2);
+          lds_add(buffer, p2 + 8, angf * grad2);
+        }
+        if (y <= 13) {
+          const float grad2 = verf * grad1;
+          lds_add(buffer, p1 + 40, iangf * grad2);
+          lds_add(buffer, p2 + 40, angf * grad2);
+        }
+      }
+      __syncthreads();
+    }
+    float b0 = buffer[lane], b1 = buffer[lane + 64];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      sums[lane] = b0 * b0 + b1 * b1;
+      __syncthreads();
+      if (lane < 32) sums[lane] = sums[lane] + sums[lane + 32];
+      __syncthreads();
+      if (lane < 16) sums[lane] = sums[lane] + sums[lane + 16];
+      __syncthreads();
+      if (lane < 8) sums[lane] = sums[lane] + sums[lane + 8];
+      __syncthreads();
+      if (lane < 4) sums[lane] = sums[lane] + sums[lane + 4];
+      __syncthreads();
+      const float tsum = sums[0] + sums[1] + sums[2] + sums[3];
+      const float r = 1.0f / sqrtf(tsum);
+      b0 = b0 * r;
+      b1 = b1 * r;
+      if (pass == 0) {
+        if (b0 > 0.2f) b0 = 0.2f;
+        if (b1 > 0.2f) b1 = 0.2f;
+      }
+      __syncthreads();
+    }
+    pt->data[lane] = b0;
+    pt->data[lane + 64] = b1;
+    if (lane == 0) {
+      pt->coords2D[0] = px * subsampling;
+      pt->coords2D[1] = py * subsampling;
+      pt->scale = pt->scale * subsampling;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvertSiftToRootSift: reference cuSIFT_D.cu:299-317 (sequential L1 sum, sqrt(max(0,v)/sum)).
+// One wave per point; the 128-term sum is kept sequential (lane 0) to match the reference order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) rootsift_kernel(cusift_point *__restrict__ points, int num_pts) {
+  __shared__ float v[128];
+  __shared__ float s_sum;
+  const int lane = threadIdx.x;
+  for (int p = blockIdx.x; p < num_pts; p += gridDim.x) {
+    cusift_point *pt = points + p;
+    v[lane] = pt->data[lane];
+    v[lane + 64] = pt->data[lane + 64];
+    __syncthreads();
+    if (lane == 0) {
+      float sum = 0.0f;
+      for (int i = 0; i < 128; ++i) sum += v[i];
+      s_sum = sum;
+    }
+    __syncthreads();
+    const float sum = s_sum;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float x = v[lane + 64 * r];
+      const double m = x > 0.0 ? (double)x : 0.0;
+      pt->data[lane + 64 * r] = sqrtf((float)(m / sum));
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace cusift

@@ -1,0 +1,105 @@
+"""Multi-GPU layer: one process per GPU, images sharded across ranks, all-gatherv of SiftData.
+
+The reference is single-GPU (no collective call sites); BASELINE configs[3] adds the
+sharded batch.  Images are independent, so the data path has NO collective; the only exchange is the
+final all-gatherv of the variable-length SiftPoint lists:
+
+  1. all_gather of the per-image counts                      (n_local int32 per rank, tiny)
+  2. exact-count exchange of the packed 588-byte records, rank to rank.  xGMI is point-to-point
+     (7 links per GPU): the default method posts one send/recv pair per peer in a single group
+     (RCCL grouped p2p), so every shard travels over its own link instead of hopping round a ring.
+     `method="padded"` is the fallback: pad to the largest shard and use one all_gather_into_tensor.
+
+Works on the `nccl` (= RCCL) backend with device tensors and on `gloo` with CPU tensors (tests).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .capi import SIFT_POINT_BYTES
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block sharding of a batch: images [lo, hi) live on `rank` (64 per GPU for 512 over 8)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_points(points, counts, max_pts):
+    """[n, max_pts, 588] uint8 + raw counters -> ([sum(valid), 588] packed records, valid counts [n])."""
+    valid = torch.clamp(counts.to(torch.int64), min=0, max=max_pts)
+    mask = torch.arange(max_pts, device=points.device)[None, :] < valid[:, None]
+    return points[mask], valid.to(torch.int32)
+
+
+def allgather_siftdata(points, counts, max_pts, group=None, method="p2p"):
+    """All-gatherv of SiftData.
+
+    points : uint8 [n_local, max_pts, 588] on this rank; counts : int32 [n_local] raw counters.
+    Returns (all_counts int32 [world, n_max], gathered uint8 [total, 588], offsets int64 [world + 1]) where
+    rank r's records occupy gathered[offsets[r]:offsets[r+1]] in image order, and all_counts[r, i] is the
+    number of points of its i-th image (rows are padded with 0 when ranks hold different image counts).
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    packed, valid = pack_points(points, counts, max_pts)
+    n_local = torch.tensor([valid.numel()], dtype=torch.int32, device=points.device)
+    n_all = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(n_all, n_local, group=group)
+    n_max = int(max(int(t.item()) for t in n_all))
+    padded_counts = torch.zeros(n_max, dtype=torch.int32, device=points.device)
+    padded_counts[: valid.numel()] = valid
+    all_counts = torch.zeros((world, n_max), dtype=torch.int32, device=points.device)
+    dist.all_gather_into_tensor(all_counts.view(-1), padded_counts, group=group)
+    per_rank = all_counts.sum(dim=1).to(torch.int64).cpu()  # the one host read-back of the exchange
+    offsets = torch.zeros(world + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(per_rank, 0)
+    total = int(offsets[-1])
+    gathered = torch.empty((total, SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+
+    if method == "padded":
+        biggest = int(per_rank.max()) if world else 0
+        send = torch.zeros((max(biggest, 1), SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+        send[: packed.shape[0]] = packed
+        recv = torch.empty((world, max(biggest, 1), SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+        for r in range(world):
+            gathered[int(offsets[r]): int(offsets[r + 1])] = recv[r, : int(per_rank[r])]
+    elif method == "p2p":
+        packed = packed.contiguous()
+        gathered[int(offsets[rank]): int(offsets[rank + 1])] = packed
+        ops = []
+        for step in range(1, world):
+            dst = (rank + step) % world
+            src = (rank - step) % world
+            if packed.shape[0] > 0:
+                ops.append(dist.P2POp(dist.isend, packed, _global_rank(dst, group), group))
+            if int(per_rank[src]) > 0:
+                ops.append(dist.P2POp(dist.irecv, gathered[int(offsets[src]): int(offsets[src + 1])],
+                                      _global_rank(src, group), group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+    else:
+        raise ValueError("unknown method %r" % method)
+    return all_counts, gathered, offsets
+
+
+def _global_rank(group_rank, group):
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
+def split_gathered(all_counts, gathered, offsets):
+    """Host view: list (over ranks) of lists (over images) of packed uint8 record arrays."""
+    out = []
+    ac = all_counts.cpu().numpy()
+    g = gathered.cpu().numpy()
+    for r in range(ac.shape[0]):
+        pos = int(offsets[r])
+        imgs = []
+        for c in ac[r]:
+            imgs.append(g[pos: pos + int(c)])
+            pos += int(c)
+        out.append(imgs)
+    return out

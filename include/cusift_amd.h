@@ -1,0 +1,170 @@
+/*
+ * cusift_amd.h -- C ABI of the MI355X-native SIFT extraction path (libcusift_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of danielsuo/cuSIFT: plain pointers and sizes,
+ * no C++/HIP/torch types.  The reference has no FFI of its own (it is a C++ static library), so each
+ * entry point below names the reference interface it stands in for (file:line relative to the
+ * reference root).  The C++ header include/cuSIFT.h re-creates the reference's classes
+ * (SiftPoint / SiftData / cuImage / ExtractSift ...) on top of exactly these functions; Python binds
+ * them with ctypes (cusift_amd/capi.py).  See INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns CUSIFT_OK (0) or a negative cusift_status; cusift_last_error() gives text.
+ *    (The reference prints and exit(-1)s, cutils.h:24-48; the C++ shim keeps that behaviour.)
+ *  - images are float32, row-pitched; `pitch` is in FLOATS (cuImage.h:11, cuImage.cu:11-13).
+ *  - "d_" pointers are device (HBM) addresses, "h_" pointers are host addresses.
+ *  - batch entry points take `n_images` images laid out `image_stride` floats apart and write
+ *    `max_pts` records per image into d_points[i*max_pts ...] and one counter per image.
+ *  - all work is enqueued on the context's HIP stream; only calls documented as blocking wait.
+ */
+#ifndef CUSIFT_AMD_H
+#define CUSIFT_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cusift_status {
+  CUSIFT_OK = 0,
+  CUSIFT_ERR_INVALID = -1,   /* bad argument (NULL buffer, non-positive size, misaligned pitch ...) */
+  CUSIFT_ERR_HIP = -2,       /* a HIP runtime call failed; see cusift_last_error() */
+  CUSIFT_ERR_NO_DEVICE = -3, /* no GPU visible */
+  CUSIFT_ERR_NOMEM = -4
+} cusift_status;
+
+/* SiftPoint, cuSIFT.h:10-30.  147 x 4 B = 588 B, no padding; callers index h_data[i] directly
+ * (test/detector.cpp:56) so the layout is ABI.  Extraction writes coords2D, scale, sharpness,
+ * edgeness, orientation, subsampling and data; the other fields are left as they were. */
+typedef struct cusift_point {
+  float coords2D[2];
+  float scale;
+  float sharpness;
+  float edgeness;
+  float orientation; /* degrees, [0,360) */
+  float score;
+  float ambiguity;
+  int match;
+  float match_xpos;
+  float match_ypos;
+  float match_error;
+  float subsampling;
+  float empty[3];
+  float data[128];
+  float coords3D[3];
+} cusift_point;
+
+/* The public parameter fields of SiftData (cuSIFT.h:44-51) plus Extract()'s `subsampling`
+ * argument (cuSIFT.cu:61) and the capacity given to the SiftData constructor (cuSIFT.cu:13-15).
+ * Use cusift_default_params() -- the reference leaves these uninitialised. */
+typedef struct cusift_params {
+  int num_octaves;     /* SiftData::numOctaves */
+  double init_blur;    /* SiftData::initBlur: blur already present in the input image */
+  float peak_thresh;   /* SiftData::peakThresh, absolute DoG units on the caller's 0..255 scale */
+  float edge_thresh;   /* SiftData::edgeThresh, used raw: keep iff tr^2 < edge_thresh*det (cuSIFT_D.cu:486) */
+  float lowest_scale;  /* SiftData::lowestScale: octave o is searched iff lowest_scale < 2*subsampling*2^o */
+  float subsampling;   /* Extract(..., float subsampling = 1.0f) */
+  int max_pts;         /* capacity per image (SiftData::maxPts) */
+  int tex_frac_bits;   /* bilinear fraction bits of the texture-unit model: 8 = as the reference ran, 0 = fp32 */
+} cusift_params;
+
+typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */
+
+/* ---- process / device ------------------------------------------------------------------ */
+const char *cusift_last_error(void);
+const char *cusift_version(void);
+int cusift_device_count(int *count);
+/* InitCuda(devNum), cutils.h:71-92: clamps dev into [0, n-1] and selects it. */
+int cusift_init(int device);
+void cusift_default_params(cusift_params *p);
+
+/* ---- context --------------------------------------------------------------------------- */
+/* `hip_stream` may be NULL (the context creates and owns a non-blocking stream) or an existing
+ * hipStream_t (borrowed; e.g. torch.cuda.current_stream().cuda_stream). The reference has one
+ * implicit global context: default stream + file-scope device symbols (cuSIFT_D.cu:13-20). */
+int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream);
+int cusift_ctx_destroy(cusift_ctx *ctx);
+int cusift_ctx_synchronize(cusift_ctx *ctx); /* blocking */
+void *cusift_ctx_stream(cusift_ctx *ctx);
+/* Pre-size the scratch arena for batches of n_images w x h images (otherwise grown on demand). */
+int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p);
+/* Bytes of HBM currently held by the arena. */
+size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
+/* Per-stage GPU timing with HIP events on the context's stream (TimerGPU, cutils.h:94-114, used at
+ * cuSIFT.cu:64,177,208,238,249).  Stages: 0 ScaleDown, 1 LaplaceMulti, 2 FindPointsMulti,
+ * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call.  Accumulates
+ * milliseconds and launch counts until reset.  cusift_ctx_timing_read blocks. */
+enum { CUSIFT_STAGE_SCALEDOWN = 0, CUSIFT_STAGE_LAPLACE = 1, CUSIFT_STAGE_FINDPOINTS = 2,
+       CUSIFT_STAGE_ORIENT = 3, CUSIFT_STAGE_DESCR = 4, CUSIFT_STAGE_TOTAL = 5, CUSIFT_NUM_STAGES = 6 };
+int cusift_ctx_timing_enable(cusift_ctx *ctx, int on);
+int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGES], int launches[CUSIFT_NUM_STAGES]);
+int cusift_ctx_timing_reset(cusift_ctx *ctx);
+
+/* ---- device memory helpers (so a host program needs no HIP headers) ----------------------- */
+/* cuImage::Allocate / SiftData ctor: cudaMallocPitch / cudaMalloc (cuImage.cu:30, cuSIFT.cu:29) */
+int cusift_malloc(void **d_ptr, size_t bytes);
+int cusift_free(void *d_ptr);
+int cusift_memset(cusift_ctx *ctx, void *d_ptr, int value, size_t bytes);
+/* SiftData::Synchronize (cuSIFT.cu:52-59) and raw copies; blocking. */
+int cusift_memcpy_h2d(cusift_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int cusift_memcpy_d2h(cusift_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* cuImage::HostToDevice / DeviceToHost (cuImage.cu:83-117): dense host rows (w floats) <-> pitched device rows. */
+int cusift_image_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const float *h_src, int w, int h);
+int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_src, int src_pitch, int w, int h);
+/* Pinned host memory for overlap of uploads (new; the reference uses pageable malloc). */
+int cusift_malloc_host(void **h_ptr, size_t bytes);
+int cusift_free_host(void *h_ptr);
+
+/* ---- stage entry points (the reference's launch wrappers) --------------------------------- */
+/* ScaleDown(res, src, variance=0.5), cuSIFT.cu:313-353 + ScaleDown_D cuSIFT_D.cu:37-182.
+ * dst is (w/2) x (h/2); writes are bounds-checked (the reference's are not). */
+int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w,
+                      int h, int src_pitch, size_t src_stride, int n_images);
+/* SiftData::LaplaceMulti, cuSIFT.cu:399-422 + LaplaceMulti_D cuSIFT_D.cu:525-553: 8 blurs + 7 DoG
+ * planes, planar [7][h][pitch] per image (`dog_stride` floats between images, >= 7*h*pitch). */
+int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                         float init_blur, float *d_dog, size_t dog_stride, int n_images);
+/* The 8 x 9 tap table LaplaceMulti uploads (cuSIFT.cu:400-413), row stride 16 floats; host-only. */
+int cusift_laplace_taps(float init_blur, float taps[8 * 16]);
+/* SiftData::FindPointsMulti, cuSIFT.cu:424-455 + FindPointsMulti_D cuSIFT_D.cu:402-523.
+ * Appends at d_points[i*max_pts + atomicAdd(d_counters[i])]; overflow is dropped, counters keep counting. */
+int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int w, int h, int pitch, size_t dog_stride,
+                             float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points,
+                             int max_pts, unsigned int *d_counters, int n_images);
+/* SiftData::ComputeOrientations, cuSIFT.cu:355-365 + ComputeOrientations_D cuSIFT_D.cu:319-396.
+ * Processes points [d_first[i], min(d_counters[i], max_pts)) of every image; d_first may be NULL (= 0). */
+int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                                cusift_point *d_points, int max_pts, const unsigned int *d_first,
+                                const unsigned int *d_counters, int tex_frac_bits, int n_images);
+/* SiftData::ExtractSiftDescriptors, cuSIFT.cu:367-377 + ExtractSiftDescriptors_D cuSIFT_D.cu:184-297
+ * (also scales coords2D and scale by `subsampling`, cuSIFT_D.cu:292-296). */
+int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                               cusift_point *d_points, int max_pts, const unsigned int *d_first,
+                               const unsigned int *d_counters, float subsampling, int tex_frac_bits, int n_images);
+/* SiftData::ConvertSiftToRootSift, cuSIFT.cu:383-395 + cuSIFT_D.cu:299-317. */
+int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts);
+
+/* ---- drivers ------------------------------------------------------------------------------ */
+/* Batch form of ExtractSiftLoop/ExtractSiftOctave (cuSIFT.cu:175-270) on device-resident images.
+ * Asynchronous on the context's stream: no host read-back, no allocation once the arena is sized.
+ * d_points: n_images*max_pts records; d_counters: n_images counters (zeroed by this call); on
+ * completion image i holds min(d_counters[i], max_pts) points, octave blocks coarsest first. */
+int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_images, int w, int h, int pitch,
+                         size_t image_stride, const cusift_params *p, cusift_point *d_points,
+                         unsigned int *d_counters);
+/* The legacy ExtractSift(siftData, cuImage&, numOctaves, initBlur, thresh, lowestScale, subsampling)
+ * (main.cpp:99-103,324-328; cuSIFT.cu:123-134): image already on the device.  Blocking; writes
+ * *num_pts = min(count, max_pts) (cuSIFT.cu:107-110) and, if h_points != NULL, copies that many
+ * records to the host (SiftData::Synchronize, cuSIFT.cu:52-59). */
+int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, const cusift_params *p,
+                   cusift_point *d_points, cusift_point *h_points, int *num_pts);
+/* SiftData::Extract(float *im, w, h, subsampling), cuSIFT.cu:61-120: dense host image in, uploads
+ * (cuImage ctor, cuImage.cu:53-60), extracts, synchronises.  Blocking. */
+int cusift_extract_host(cusift_ctx *ctx, const float *h_img, int w, int h, const cusift_params *p,
+                        cusift_point *d_points, cusift_point *h_points, int *num_pts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSIFT_AMD_H */

@@ -320,7 +320,7 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
       float dy = oracle_tex2d(img, w, h, pitch, xf, yf + 1.0f, frac_bits) -
                  oracle_tex2d(img, w, h, pitch, xf, yf - 1.0f, frac_bits);
       int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
-      if (bin > 31) bin = 0;
+      if (bin > 31 || bin < 0) bin = 0; /* < 0 only for non-finite input (memory safety) */
       float grad = sqrtf(dx * dx + dy * dy);
       /* device: LDS float atomicAdd in arbitrary order; oracle: increasing tx */
       hist[bin] += grad * gauss[xd] * gauss[yd];

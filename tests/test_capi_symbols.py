@@ -1,0 +1,73 @@
+"""The C-ABI library loads on a CPU-only machine and exports every symbol include/cusift_amd.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cusift_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cusift_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cusift_amd import capi
+
+    names = declared_symbols()
+    assert len(names) >= 30
+    handle = ctypes.CDLL(capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, missing
+    # and the binding covers exactly the declared surface
+    assert sorted(capi.SIGNATURES) == names
+
+
+def test_binding_loads_and_reports_version():
+    from cusift_amd import capi
+
+    lib = capi.lib()
+    assert b"cusift_amd" in lib.cusift_version()
+    p = capi.default_params()
+    assert p.num_octaves == 5 and p.edge_thresh == 10.0 and p.tex_frac_bits == 8 and p.max_pts == 1024
+
+
+def test_point_record_is_588_bytes():
+    from cusift_amd import capi
+
+    assert capi.SIFT_POINT_DTYPE.itemsize == 588
+    assert capi.SIFT_POINT_DTYPE.fields["data"][1] == 64
+
+
+def test_laplace_taps_host_table_matches_oracle(oracle):
+    """Host-only entry point: the tap table the product uploads equals the oracle's, bit for bit."""
+    from cusift_amd import capi
+
+    for blur in (0.0, 0.5, 0.7, 1.0, 0.55901699):
+        np.testing.assert_array_equal(capi.laplace_taps(blur), oracle.laplace_taps(blur))
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    from cusift_amd import capi
+
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.CusiftError):
+        capi.Context(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped package must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "cusift_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "libsift_oracle" not in text and "oracle_binding" not in text, os.path.join(dirpath, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        text = open(os.path.join(ROOT, "include", f), errors="ignore").read()
+        assert "sift_oracle" not in text, f
