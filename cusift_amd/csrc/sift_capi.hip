@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -18,6 +19,9 @@ namespace cusift {
 // kernels (sift_kernels.hip)
 __global__ void scale_down_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
 __global__ void laplace_multi_kernel(const float *, float *, int, int, int, long, long, int, int, LaplaceTaps);
+__global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
+__global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
+                                        FindParams);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
                                    FindParams);
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
@@ -516,9 +520,23 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
   const int strips = idiv_up(w, kBlurStrip);
   const int rows = pick_rows(h, strips, n_images, 8, 32);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
+  // fast path: aligned float4 rows, whole lanes inside/outside the image, 32-bit buffer offsets
+  const bool fast = vec_ok && (w % 4 == 0) && w >= 4 && ((size_t)h * pitch * sizeof(float) < (1ull << 31)) &&
+                    !getenv("CUSIFT_FORCE_GENERIC");
   StageTimer t(ctx, CUSIFT_STAGE_LAPLACE);
-  hipLaunchKernelGGL(laplace_multi_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
-                     (long)img_stride, (long)dog_stride, rows, vec_ok, T);
+  if (fast) {
+    LaplaceTapsPk TP;
+    for (int q = 0; q < kNumLevels / 2; ++q)
+      for (int j = 0; j < 5; ++j) {
+        TP.k[q][j].x = taps[16 * (2 * q) + j];
+        TP.k[q][j].y = taps[16 * (2 * q + 1) + j];
+      }
+    hipLaunchKernelGGL(laplace_multi_fast_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
+                       (long)img_stride, (long)dog_stride, rows, TP);
+  } else {
+    hipLaunchKernelGGL(laplace_multi_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
+                       (long)img_stride, (long)dog_stride, rows, vec_ok, T);
+  }
   return check_launch("laplace_multi");
 }
 
@@ -537,8 +555,16 @@ extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int
   const int strips = idiv_up(w, kFindStrip);
   const int rows = pick_rows(h, strips, n_images, 8, 32);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
+  const bool fast = vec_ok && (w % 2 == 0) && w >= 2 &&
+                    ((size_t)kNumDog * h * pitch * sizeof(float) < (1ull << 31)) && !getenv("CUSIFT_FORCE_GENERIC");
   StageTimer t(ctx, CUSIFT_STAGE_FINDPOINTS);
-  hipLaunchKernelGGL(find_points_kernel, grid, dim3(256), 0, ctx->stream, d_dog, w, h, pitch, (long)dog_stride,
+  if (fast) {
+    dim3 fgrid(idiv_up(strips, kWavesPerBlock), idiv_up(h, rows), n_images);  // 4 waves = 4 adjacent strips
+    hipLaunchKernelGGL(find_points_fast_kernel, fgrid, dim3(256), 0, ctx->stream, d_dog, w, h, pitch,
+                       (long)dog_stride, d_points, max_pts, d_counters, rows, P);
+  }
+  else
+    hipLaunchKernelGGL(find_points_kernel, grid, dim3(256), 0, ctx->stream, d_dog, w, h, pitch, (long)dog_stride,
                      d_points, max_pts, d_counters, rows, vec_ok, P);
   return check_launch("find_points_multi");
 }

@@ -30,6 +30,22 @@ __device__ __forceinline__ float from_next_lane(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
+// XCD-aware work mapping.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each
+// with its own L2), so spatially adjacent tiles would land on different L2s and fetch their shared
+// halo lines twice.  Remapping id -> (id % 8) * (total / 8) + id / 8 gives every XCD a contiguous
+// run of tiles, dispatched in order, so neighbours meet in one L2.  Placement only affects speed.
+__device__ __forceinline__ void xcd_remap(int &bx, int &by, int &bz) {
+  const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+  const int total = nx * ny * nz;
+  if ((total & 7) != 0) return;
+  int id = (bz * ny + by) * nx + bx;
+  id = (id & 7) * (total >> 3) + (id >> 3);
+  bx = id % nx;
+  const int t = id / nx;
+  by = t % ny;
+  bz = t / ny;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ScaleDown: 5x5 separable low-pass + 2x decimation.  Reference: ScaleDown_D, cuSIFT_D.cu:37-182.
 // One lane per output column, marching down output rows; the five horizontally filtered source rows
@@ -42,7 +58,7 @@ __global__ void __launch_bounds__(256) scale_down_kernel(float *__restrict__ dst
                                                         const float *__restrict__ src, int w, int h, int src_pitch,
                                                         long src_stride, int rows_per_wave, ScaleDownTaps T) {
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   const int ow = w >> 1, oh = h >> 1;
   const int c = blockIdx.x * 64 + lane;
   const int r0 = (blockIdx.y * kWavesPerBlock + wv) * rows_per_wave;
@@ -77,8 +93,8 @@ __global__ void __launch_bounds__(256) scale_down_kernel(float *__restrict__ dst
 // LaplaceMulti: 8 Gaussian blurs (9-tap separable, vertical then horizontal, clamp borders) of the
 // octave base image and the 7 differences, fused.  Reference: LaplaceMulti_D, cuSIFT_D.cu:525-553.
 //
-// Each lane owns kBlurCols=4 adjacent columns; a wave owns 256 columns of which lanes 1..62 (248
-// columns) produce output and lanes 0/63 are the 4-column halo.  Per row: one float4 load per lane
+// Each lane owns kBlurCols=4 adjacent columns; a wave owns 256 columns of which lanes 4..59 (224
+// columns, 128-byte aligned) produce output and the outer lanes are halo (sift_types.h).  Per row: one float4 load per lane
 // (1 KiB per wave), a 9-row register window, the scale-independent pair sums S[y-k]+S[y+k], then per
 // level the vertical 9-tap (5 multiplies), the +-4 column exchange with the neighbouring lanes by
 // DPP, the horizontal 9-tap and the DoG against the previous level; 7 float4 stores per row.
@@ -88,14 +104,14 @@ __global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restr
                                                            int w, int h, int pitch, long img_stride, long dog_stride,
                                                            int rows_per_wave, int vec_ok, LaplaceTaps T) {
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   const int y0 = (blockIdx.y * kWavesPerBlock + wv) * rows_per_wave;
   if (y0 >= h) return;  // wave-uniform
   const int y1 = min(y0 + rows_per_wave, h);
   img += (long)blockIdx.z * img_stride;
   dog += (long)blockIdx.z * dog_stride;
 
-  const int c0 = blockIdx.x * kBlurStrip - kBlurCols + lane * kBlurCols;  // first of this lane's 4 columns
+  const int c0 = blockIdx.x * kBlurStrip - kBlurHaloLanes * kBlurCols + lane * kBlurCols;  // first of this lane's 4 columns
   const bool interior = vec_ok && c0 >= 0 && c0 + 3 < w;
   const int cc0 = clampi(c0, 0, w - 1), cc1 = clampi(c0 + 1, 0, w - 1), cc2 = clampi(c0 + 2, 0, w - 1),
             cc3 = clampi(c0 + 3, 0, w - 1);
@@ -113,7 +129,7 @@ __global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) load_row(y0 - 4 + i, win[i]);
 
-  const bool writer = lane >= 1 && lane <= 62 && c0 < w;
+  const bool writer = lane >= kBlurHaloLanes && lane < 64 - kBlurHaloLanes && c0 < w;
   const bool vec_store = vec_ok && (c0 + 3 < w);
   const long plane = (long)h * pitch;
 
@@ -181,6 +197,128 @@ __global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// LaplaceMulti, fast path (16-byte aligned buffers, w % 4 == 0, image and DoG block < 4 GiB).
+// Same strip geometry and the same arithmetic as laplace_multi_kernel above, restructured for the
+// CDNA4 VALU and memory pipes:
+//  * packed fp32 (v_pk_fma_f32 / v_pk_add_f32) across SCALE PAIRS: a register pair holds levels
+//    (2q, 2q+1) of one column, the tap pair (k_2q, k_2q+1) is an SGPR pair and the scale-independent
+//    operand is splat by op_sel -- no repacking moves (pairs across columns would be misaligned in the
+//    horizontal pass).  ~330 VALU instructions per 4x8 outputs instead of ~600.
+//  * buffer_load/store_dwordx4 with a wave-uniform row base (SGPR) and a 32-bit lane offset: no 64-bit
+//    per-lane address arithmetic, and the halo lanes / columns >= w are dropped by the hardware range
+//    check of a per-row buffer descriptor (num_records = w*4) -- no divergent branches in the loop.
+//  * the next source row is requested one full iteration before it is needed.
+// ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned int kBufFlags = 0x00020000u;  // raw buffer, 32-bit data format (gfx9/CDNA dword 3)
+constexpr int kOobOffset = 0x7fffffff;           // lane offset beyond any num_records: store dropped
+
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 dpp_prev2(f2 v) { return f2{from_prev_lane(v.x), from_prev_lane(v.y)}; }
+__device__ __forceinline__ f2 dpp_next2(f2 v) { return f2{from_next_lane(v.x), from_next_lane(v.y)}; }
+
+__global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__restrict__ img,
+                                                                float *__restrict__ dog, int w, int h, int pitch,
+                                                                long img_stride, long dog_stride, int rows_per_wave,
+                                                                LaplaceTapsPk T) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  xcd_remap(bx, by, bz);
+  const int y0 = (by * kWavesPerBlock + wv) * rows_per_wave;
+  if (y0 >= h) return;  // wave-uniform
+  const int y1 = min(y0 + rows_per_wave, h);
+  img += (long)bz * img_stride;
+  dog += (long)bz * dog_stride;
+
+  const int c0 = bx * kBlurStrip - kBlurHaloLanes * kBlurCols + lane * kBlurCols;
+  const bool left = c0 < 0, right = c0 >= w;  // w % 4 == 0: a lane is entirely inside or entirely outside
+  const int voff_in = clampi(c0, 0, w - 4) * 4;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((unsigned int)h * (unsigned int)pitch * 4u), kBufFlags);
+  const int voff_out = (lane >= kBlurHaloLanes && lane < 64 - kBlurHaloLanes) ? c0 * 4 : kOobOffset;  // c0 >= w is dropped by num_records
+  const long plane = (long)h * pitch;
+
+  auto load_row = [&](int y) -> f4 {
+    const int yc = clampi(y, 0, h - 1);
+    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, yc * pitch * 4, 0);
+    f4 v = __builtin_bit_cast(f4, raw);
+    if (left) v = f4{v.x, v.x, v.x, v.x};
+    if (right) v = f4{v.w, v.w, v.w, v.w};
+    return v;
+  };
+
+  f4 win[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) win[i] = load_row(y0 - 4 + i);
+
+  for (int y = y0; y < y1; ++y) {
+    const f4 nxt = load_row(y + 5);  // consumed at the end of this iteration
+    const f4 ctr = win[4];
+    const f4 p1 = win[3] + win[5];
+    const f4 p2 = win[2] + win[6];
+    const f4 p3 = win[1] + win[7];
+    const f4 p4 = win[0] + win[8];
+    float *row = dog + (long)y * pitch;
+    float prev_hi[4];
+#pragma unroll
+    for (int q = 0; q < kNumLevels / 2; ++q) {
+      const f2 k0 = T.k[q][0], k1 = T.k[q][1], k2 = T.k[q][2], k3 = T.k[q][3], k4 = T.k[q][4];
+      f2 e[12];  // columns c0-4 .. c0+7, each a (level 2q, level 2q+1) pair
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f2 v = k4 * splat(ctr[j]);
+        v = pk_fma(k3, splat(p1[j]), v);
+        v = pk_fma(k2, splat(p2[j]), v);
+        v = pk_fma(k1, splat(p3[j]), v);
+        v = pk_fma(k0, splat(p4[j]), v);
+        e[4 + j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        e[j] = dpp_prev2(e[4 + j]);
+        e[8 + j] = dpp_next2(e[4 + j]);
+      }
+      f2 L[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = 4 + j;
+        f2 v = k4 * e[m];
+        v = pk_fma(k3, e[m - 1] + e[m + 1], v);
+        v = pk_fma(k2, e[m - 2] + e[m + 2], v);
+        v = pk_fma(k1, e[m - 3] + e[m + 3], v);
+        v = pk_fma(k0, e[m - 4] + e[m + 4], v);
+        L[j] = v;
+      }
+      if (q > 0) {  // DoG plane 2q-1 = level 2q-1 (previous pair, high half) - level 2q
+        const f4 d = f4{prev_hi[0] - L[0].x, prev_hi[1] - L[1].x, prev_hi[2] - L[2].x, prev_hi[3] - L[3].x};
+        const __amdgpu_buffer_rsrc_t ro =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(row + (long)(2 * q - 1) * plane), 0, w * 4, kBufFlags);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), ro, voff_out, 0, 0);
+      }
+      {  // DoG plane 2q = level 2q - level 2q+1 (both halves of this pair)
+        const f4 d = f4{L[0].x - L[0].y, L[1].x - L[1].y, L[2].x - L[2].y, L[3].x - L[3].y};
+        if (2 * q < kNumDog) {
+          const __amdgpu_buffer_rsrc_t ro =
+              __builtin_amdgcn_make_buffer_rsrc((void *)(row + (long)(2 * q) * plane), 0, w * 4, kBufFlags);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), ro, voff_out, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prev_hi[j] = L[j].y;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
+    win[8] = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FindPointsMulti: 26-neighbour DoG extrema for the 5 searchable scales, edge test, 3-D quadratic
 // refinement and append.  Reference: FindPointsMulti_D, cuSIFT_D.cu:402-523.
 //
@@ -244,7 +382,7 @@ __global__ void __launch_bounds__(256) find_points_kernel(const float *__restric
                                                          int max_pts, unsigned int *__restrict__ counters,
                                                          int rows_per_wave, int vec_ok, FindParams P) {
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   const int y0 = (blockIdx.y * kWavesPerBlock + wv) * rows_per_wave;
   if (y0 >= h) return;
   const int y1 = min(y0 + rows_per_wave, h);
@@ -333,6 +471,119 @@ __global__ void __launch_bounds__(256) find_points_kernel(const float *__restric
         d[p][0][j] = d[p][1][j];
         d[p][1][j] = d[p][2][j];
       }
+  }
+}
+
+// 3-input min/max: these map to one v_min3_f32 / v_max3_f32 each.  (A 2-input IEEE minnum on loaded
+// values costs two extra sNaN-quieting v_max_f32 x,x, so the extremum test below only uses 3-input trees.)
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// ------------------------------------------------------------------------------------------------
+// FindPointsMulti, fast path (8-byte aligned DoG block < 4 GiB, w % 2 == 0): the same test and the
+// same refinement as find_points_kernel, with buffer_load_dwordx2 on a wave-uniform row base, the next
+// row of all 7 planes requested one iteration ahead, and v_min3/v_max3 trees.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__restrict__ dog, int w, int h, int pitch,
+                                                              long dog_stride, cusift_point *__restrict__ points,
+                                                              int max_pts, unsigned int *__restrict__ counters,
+                                                              int rows_per_wave, FindParams P) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  xcd_remap(bx, by, bz);
+  // the 4 waves of a block take 4 horizontally adjacent strips of the same rows: the 128-byte lines that
+  // straddle their strip borders are fetched once (L1/L2 hit) instead of once per strip
+  const int strip = bx * kWavesPerBlock + wv;
+  const int y0 = by * rows_per_wave;
+  if (strip * kFindStrip >= w || y0 >= h) return;  // wave-uniform
+  const int y1 = min(y0 + rows_per_wave, h);
+  dog += (long)bz * dog_stride;
+  points += (long)bz * max_pts;
+  unsigned int *counter = counters + bz;
+
+  const int c0 = strip * kFindStrip - kFindCols + lane * kFindCols;
+  const bool left = c0 < 0, right = c0 >= w;
+  const int voff = clampi(c0, 0, w - 2) * 4;
+  const long plane = (long)h * pitch;
+  const int plane_bytes = (int)((unsigned int)h * (unsigned int)pitch * 4u);
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc((void *)dog, 0, (int)((unsigned int)plane_bytes * (unsigned int)kNumDog), kBufFlags);
+
+  auto load_row = [&](int y, f2 (&o)[kNumDog]) {
+    const int row_off = clampi(y, 0, h - 1) * pitch * 4;
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p) {
+      const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(rin, voff, p * plane_bytes + row_off, 0);
+      f2 v = __builtin_bit_cast(f2, raw);
+      if (left) v = f2{v.x, v.x};
+      if (right) v = f2{v.y, v.y};
+      o[p] = v;
+    }
+  };
+
+  f2 r0[kNumDog], r1[kNumDog], r2[kNumDog], nxt[kNumDog];
+  load_row(y0 - 1, r0);
+  load_row(y0, r1);
+  load_row(y0 + 1, r2);
+  const bool lane_valid = lane >= 1 && lane <= 62;
+
+  for (int y = y0; y < y1; ++y) {
+    load_row(y + 2, nxt);
+    // per plane: 3-row column min/max for this lane's two columns and for the columns left/right of them
+    float cmn[kNumDog][2], cmx[kNumDog][2], hmn[kNumDog][2], hmx[kNumDog][2], lmn[kNumDog], rmn[kNumDog],
+        lmx[kNumDog], rmx[kNumDog];
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        cmn[p][j] = min3f(r0[p][j], r1[p][j], r2[p][j]);
+        cmx[p][j] = max3f(r0[p][j], r1[p][j], r2[p][j]);
+      }
+      lmn[p] = from_prev_lane(cmn[p][1]);  // column c0-1
+      rmn[p] = from_next_lane(cmn[p][0]);  // column c0+2
+      lmx[p] = from_prev_lane(cmx[p][1]);
+      rmx[p] = from_next_lane(cmx[p][0]);
+      hmn[p][0] = min3f(lmn[p], cmn[p][0], cmn[p][1]);
+      hmn[p][1] = min3f(cmn[p][0], cmn[p][1], rmn[p]);
+      hmx[p][0] = max3f(lmx[p], cmx[p][0], cmx[p][1]);
+      hmx[p][1] = max3f(cmx[p][0], cmx[p][1], rmx[p]);
+    }
+    unsigned int cand = 0;  // bit (2*s + j)
+#pragma unroll
+    for (int s = 0; s < kNumScales; ++s) {
+      const int c = s + 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v = r1[c][j];
+        const float nl_mn = j == 0 ? lmn[c] : cmn[c][0], nr_mn = j == 0 ? cmn[c][1] : rmn[c];
+        const float nl_mx = j == 0 ? lmx[c] : cmx[c][0], nr_mx = j == 0 ? cmx[c][1] : rmx[c];
+        // 26 neighbours as two 3-input trees per direction; "v < min(a, b)" is evaluated as v < a && v < b
+        // (a 2-input IEEE min would cost two extra quieting instructions)
+        const float mn_a = min3f(nl_mn, nr_mn, r0[c][j]);
+        const float mn_b = min3f(r2[c][j], hmn[c - 1][j], hmn[c + 1][j]);
+        const float mx_a = max3f(nl_mx, nr_mx, r0[c][j]);
+        const float mx_b = max3f(r2[c][j], hmx[c - 1][j], hmx[c + 1][j]);
+        const bool hit = (v < P.thr_neg && v < mn_a && v < mn_b) || (v > P.thr_pos && v > mx_a && v > mx_b);
+        cand |= (hit ? 1u : 0u) << (2 * s + j);
+      }
+    }
+    if (!lane_valid) cand = 0;
+    if (cand) {
+      for (int b = 0; b < 2 * kNumScales; ++b) {
+        if (cand & (1u << b)) {
+          const int x = c0 + (b & 1), s = b >> 1;
+          if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2)
+            refine_and_append(dog, plane, pitch, x, y, s, P, points, max_pts, counter);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p) {
+      r0[p] = r1[p];
+      r1[p] = r2[p];
+      r2[p] = nxt[p];
+    }
   }
 }
 
@@ -458,8 +709,10 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
 
 // ------------------------------------------------------------------------------------------------
 // ExtractSiftDescriptors: reference ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.
-// One wave per keypoint; the 16x16 rotated sample grid is visited in 4 steps of 64 samples
-// (sample row y = 4*step + lane/16, column tx = lane%16); each sample makes up to 8 trilinear LDS
+// One wave per keypoint; the 16x16 rotated sample grid is visited in 4 steps of 64 samples.  In step
+// (sy, sx) lane l takes sample row y = 2*(l/8) + sy, column tx = 2*(l%8) + sx: the 64 samples of a step
+// are spread over all 16 histogram cells (4 per cell), which keeps same-address collisions of the LDS
+// float atomics 4x lower than a row-major assignment.  Each sample makes up to 8 trilinear LDS
 // float-atomic adds into the 4x4x8 histogram.  All adds come from one wave in program order, so the
 // result is reproducible run to run.  Then L2-normalise, clamp at 0.2, L2-normalise (same reduction
 // tree as the reference) and scale the keypoint by `subsampling`.
@@ -476,13 +729,11 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
   __shared__ float buffer[128 + 48];  // indices 128..175 absorb the reference's out-of-range adds (dropped)
   __shared__ float sums[64];
   const int lane = threadIdx.x;
-  const int tx = lane & 15;
   img += (long)blockIdx.y * img_stride;
   points += (long)blockIdx.y * max_pts;
   const unsigned int fst = first ? first[blockIdx.y] : 0u;
   const unsigned int cnt = counters[blockIdx.y];
   const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
-  const float gx = expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
 
   for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
     cusift_point *pt = points + bx;
@@ -499,8 +750,10 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
     __syncthreads();
 #pragma unroll 1
     for (int step = 0; step < 4; ++step) {
-      const int y = 4 * step + (lane >> 4);
+      const int y = 2 * (lane >> 3) + (step >> 1);
+      const int tx = 2 * (lane & 7) + (step & 1);
       const float gy = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
+      const float gx = expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
       const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
       const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
       const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q, inv_q) -

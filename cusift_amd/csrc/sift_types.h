@@ -19,9 +19,13 @@ constexpr int kBlurRadius = 4;                // cuSIFT_D.h:26  LAPLACE_R
 constexpr int kMaxOctaves = 16;
 
 // Column-strip geometry of the wave-autonomous stencil kernels:
-// a 64-lane wave owns 64*kBlurCols consecutive columns, of which the outer lane on each side is halo.
-constexpr int kBlurCols = 4;                              // columns per lane in the blur kernel (float4)
-constexpr int kBlurStrip = 64 * kBlurCols - 2 * kBlurCols;  // 248 valid output columns per wave
+// a 64-lane wave owns 64*kBlurCols consecutive columns.  The blur needs +-4 columns of halo (one lane per
+// side), but the wave keeps FOUR halo lanes per side so that the 224 columns it writes start and end on
+// 128-byte lines: measured on MI355X (tools/microbench/stream_mix.hip), 7-plane stores in 992-byte
+// unaligned row segments sustain 3.4 TB/s, in 896-byte line-aligned segments 4.3 TB/s.
+constexpr int kBlurCols = 4;        // columns per lane in the blur kernel (float4)
+constexpr int kBlurHaloLanes = 4;   // halo lanes on each side of a wave
+constexpr int kBlurStrip = (64 - 2 * kBlurHaloLanes) * kBlurCols;  // 224 valid output columns per wave
 constexpr int kFindCols = 2;                              // columns per lane in the extrema kernel (float2)
 constexpr int kFindStrip = 64 * kFindCols - 2 * kFindCols;  // 124 valid output columns per wave
 constexpr int kWavesPerBlock = 4;
@@ -30,6 +34,12 @@ struct LaplaceTaps {
   // k[s][0..4] = reference kernel[16*s + 0..4]; k[s][4] is the centre tap, k[s][4-j] the tap at +-j
   // (cuSIFT.cu:400-412; only the lower half of each 9-tap row is read by the kernel, cuSIFT_D.cu:536-548)
   float k[kNumLevels][5];
+};
+
+struct LaplaceTapsPk {
+  // the same taps arranged for packed fp32: k[q][t] = (k[2q][t], k[2q+1][t]) -- one SGPR pair per
+  // (scale pair, tap), consumed by v_pk_fma_f32 in laplace_multi_fast_kernel
+  float __attribute__((ext_vector_type(2))) k[kNumLevels / 2][5];
 };
 
 struct ScaleDownTaps {

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_gpu.sh run (gpurun_out/<tag>/) into a small text summary for profiles/.
+
+    python tools/summarize_profile.py gpurun_out/r01a profiles/r01a_summary.txt
+
+Per kernel: calls, avg/min/max duration (kernel trace), and PMC counters averaged per launch.
+For the stencil kernels the largest launches (octave 0 of the batch) are also listed on their own,
+with HBM traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes; FETCH_SIZE reads half of a wide
+coalesced stream on gfx950, MI355X_MICROARCH.md "HBM").
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.split("(")[0]
+    return n.replace("cusift::", "").replace("void ", "")[:60]
+
+
+def read_csv(path):
+    with open(path, newline="") as f:
+        return list(csv.DictReader(f))
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    lines = []
+    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0) ==")
+        lines.append("%-62s %6s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+        for r in read_csv(stats[0]):
+            lines.append("%-62s %6s %12.2f %12.2f %12.2f %7s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                                                               r["Percentage"][:6]))
+    # PMC passes
+    per_kernel = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [values per dispatch]
+    per_dispatch = defaultdict(dict)  # (pass, dispatch) -> info
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in read_csv(f):
+                k = short(r["Kernel_Name"])
+                per_kernel[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                key = (os.path.basename(d), r["Dispatch_Id"])
+                per_dispatch[key]["kernel"] = k
+                per_dispatch[key]["grid"] = int(r["Grid_Size"])
+                per_dispatch[key]["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                per_dispatch[key][r["Counter_Name"]] = float(r["Counter_Value"])
+                per_dispatch[key]["vgpr"] = r.get("VGPR_Count")
+                per_dispatch[key]["sgpr"] = r.get("SGPR_Count")
+    ours = [k for k in per_kernel if k.endswith("_kernel") and "at::" not in k]
+    lines.append("")
+    lines.append("== PMC counters, mean per launch (separate --pmc passes) ==")
+    for k in sorted(ours):
+        lines.append(k)
+        for c in sorted(per_kernel[k]):
+            v = per_kernel[k][c]
+            lines.append("    %-26s n=%-4d mean=%.4g  max=%.4g" % (c, len(v), sum(v) / len(v), max(v)))
+    out_json = {}
+    for kern in ("laplace_multi_kernel", "find_points_kernel", "scale_down_kernel", "descriptors_kernel",
+                 "orientations_kernel"):
+        biggest = {}
+        for (pas, disp), info in per_dispatch.items():
+            if info.get("kernel") != kern:
+                continue
+            biggest[pas] = max(biggest.get(pas, 0), info["grid"])
+        rows = defaultdict(list)
+        for (pas, disp), info in per_dispatch.items():
+            if info.get("kernel") == kern and info["grid"] == biggest.get(pas):
+                for c, v in info.items():
+                    if isinstance(v, float) and c != "dur_us":
+                        rows[c].append(v)
+                rows["dur_us(profiled)"].append(info["dur_us"])
+                rows["_vgpr"].append(float(info["vgpr"] or 0))
+                rows["_sgpr"].append(float(info["sgpr"] or 0))
+        if not rows:
+            continue
+        lines.append("")
+        lines.append("== %s: largest-grid launches only (octave 0 of the 64-image batch) ==" % kern)
+        mean = {c: sum(v) / len(v) for c, v in rows.items()}
+        for c in sorted(mean):
+            lines.append("    %-26s %.6g" % (c, mean[c]))
+        if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+            fetch_b = mean["FETCH_SIZE"] * 1024
+            write_b = mean["WRITE_SIZE"] * 1024
+            lines.append("    HBM traffic per launch: read 2*FETCH_SIZE = %.1f MB, written WRITE_SIZE = %.1f MB, total %.1f MB"
+                         % (2 * fetch_b / 1e6, write_b / 1e6, (2 * fetch_b + write_b) / 1e6))
+            out_json[kern] = {"fetch_size_kib": mean["FETCH_SIZE"], "write_size_kib": mean["WRITE_SIZE"],
+                              "hbm_bytes_octave0_launch": 2 * fetch_b + write_b}
+    tot = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for (pas, disp), info in per_dispatch.items():
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if c in info:
+                tot[info["kernel"]][c] += info[c]
+                cnt[info["kernel"]][c] += 1
+    lines.append("")
+    for kern in ("laplace_multi_kernel", "find_points_kernel"):
+        if cnt[kern]["FETCH_SIZE"] and cnt[kern]["WRITE_SIZE"]:
+            n = cnt[kern]["FETCH_SIZE"]
+            per_launch = (2 * tot[kern]["FETCH_SIZE"] / n + tot[kern]["WRITE_SIZE"] / cnt[kern]["WRITE_SIZE"]) * 1024
+            out_json.setdefault(kern, {})["hbm_bytes_per_launch"] = per_launch
+            out_json[kern]["launches_profiled"] = n
+            lines.append("%s: mean HBM traffic per launch over all %d profiled launches (all octaves) = %.1f MB"
+                         % (kern, n, per_launch / 1e6))
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    with open(dst, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.splitext(dst)[0] + ".json", "w") as f:
+        json.dump(out_json, f, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
