@@ -618,6 +618,51 @@ __device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-staged image patches for the keypoint kernels.  A patch holds S[clamp(y0+r)][clamp(x0+c)] for the
+// UNCLAMPED coordinates (x0+c, y0+r), so a bilinear fetch whose 2x2 footprint lies inside the patch reads
+// exactly the pixels the clamping texture model would (a footprint clamped at the border interpolates
+// between equal values in both cases).  tex2d_patch() is tex2d() operation for operation, reading LDS.
+// ------------------------------------------------------------------------------------------------
+struct PatchGeom {
+  int x0, y0;  // image coordinate of patch element (0,0)
+  int stride;  // floats per patch row
+};
+
+__device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, float *lds,
+                                            const PatchGeom &g, int pw, int ph, int lane) {
+  // rows of up to 32 columns are loaded two at a time, wider rows one at a time (wave-uniform choice)
+  const int cols = pw <= 32 ? 32 : 64;
+  const int rows_per_iter = 64 / cols;
+  const int c = lane & (cols - 1), rsub = lane / cols;
+  const int col = clampi(g.x0 + c, 0, w - 1);
+  for (int r = rsub; r < ph; r += rows_per_iter) {
+    const int row = clampi(g.y0 + r, 0, h - 1);
+    if (c < pw) lds[r * g.stride + c] = img[(long)row * pitch + col];
+  }
+}
+
+__device__ __forceinline__ float tex2d_patch(const float *lds, const PatchGeom &g, float x, float y, float q,
+                                             float inv_q) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (q > 0.0f) {
+    a = floorf(a * q + 0.5f) * inv_q;
+    b = floorf(b * q + 0.5f) * inv_q;
+  }
+  const int i = (int)fx - g.x0, j = (int)fy - g.y0;
+  const float *p0 = lds + j * g.stride + i;
+  const float *p1 = p0 + g.stride;
+  const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
+  const float ia = 1.0f - a, ib = 1.0f - b;
+  float t = (ia * ib) * s00;
+  t = t + (a * ib) * s10;
+  t = t + (ia * b) * s01;
+  t = t + (a * b) * s11;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ComputeOrientations: reference ComputeOrientations_D, cuSIFT_D.cu:319-396.
 // One wave per keypoint (persistent grid over [first, min(count,max_pts)) read from device memory).
 // 121 samples (11x11) -> 32-bin histogram in LDS.  The histogram is accumulated by lanes 0..31, each
@@ -630,8 +675,8 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
                                                          float inv_q) {
   __shared__ float hist[64];
   __shared__ float gauss[11];
-  __shared__ float s_val[128];
-  __shared__ int s_bin[128];
+  __shared__ float2 s_sample[128];  // (bin as float bits, weight)
+  __shared__ float patch[16 * 16];
   const int tx = threadIdx.x;
   img += (long)blockIdx.y * img_stride;
   points += (long)blockIdx.y * max_pts;
@@ -642,10 +687,26 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
   for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
     cusift_point *pt = points + bx;
     const float scale = pt->scale;
+    const float kx = pt->coords2D[0], ky = pt->coords2D[1];
     const float i2sigma2 = -1.0f / (4.5f * scale * scale);
     if (tx < 11) gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
-    const float xp = pt->coords2D[0] - 5.0f;
-    const float yp = pt->coords2D[1] - 5.0f;
+    const float xp = kx - 5.0f;
+    const float yp = ky - 5.0f;
+    // every tap lies in [k-6, k+6]: its 2x2 footprint starts at floor(k-6.5) .. floor(k+5.5) -> a 16x16 patch
+    // (one spare column/row on each side).  Non-finite or absurd coordinates take the global path.
+    const bool use_patch = (fabsf(kx) < 1e6f) && (fabsf(ky) < 1e6f);
+    PatchGeom g;
+    g.x0 = (int)floorf(kx - 6.5f) - 1;
+    g.y0 = (int)floorf(ky - 6.5f) - 1;
+    g.stride = 16;
+    if (use_patch) {
+      const int col = clampi(g.x0 + (tx & 15), 0, w - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = (tx >> 4) + 4 * r;
+        patch[rr * 16 + (tx & 15)] = img[(long)clampi(g.y0 + rr, 0, h - 1) * pitch + col];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
@@ -655,20 +716,29 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
         const int xd = t - yd * 11;
         const float xf = xp + xd;
         const float yf = yp + yd;
-        const float dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q, inv_q) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q, inv_q);
-        const float dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q, inv_q) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q, inv_q);
+        float dx, dy;
+        if (use_patch) {
+          dx = tex2d_patch(patch, g, xf + 1.0f, yf, q, inv_q) - tex2d_patch(patch, g, xf - 1.0f, yf, q, inv_q);
+          dy = tex2d_patch(patch, g, xf, yf + 1.0f, q, inv_q) - tex2d_patch(patch, g, xf, yf - 1.0f, q, inv_q);
+        } else {
+          dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q, inv_q) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q, inv_q);
+          dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q, inv_q) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q, inv_q);
+        }
         int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
         if (bin > 31 || bin < 0) bin = 0;  // < 0 only for non-finite input
         const float grad = sqrtf(dx * dx + dy * dy);
-        s_bin[t] = bin;
-        s_val[t] = grad * gauss[xd] * gauss[yd];
+        s_sample[t] = make_float2(__int_as_float(bin), grad * gauss[xd] * gauss[yd]);
       }
     }
     __syncthreads();
     if (tx < 32) {
+      // bins are lanes; samples are walked in index order so the sums are the oracle's, bit for bit
       float acc = 0.0f;
-      for (int t = 0; t < 121; ++t)
-        if (s_bin[t] == tx) acc += s_val[t];
+#pragma unroll 11
+      for (int t = 0; t < 121; ++t) {
+        const float2 sv = s_sample[t];
+        if (__float_as_int(sv.x) == tx) acc += sv.y;
+      }
       hist[tx] = acc;
     }
     __syncthreads();
@@ -709,16 +779,37 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
 
 // ------------------------------------------------------------------------------------------------
 // ExtractSiftDescriptors: reference ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.
-// One wave per keypoint; the 16x16 rotated sample grid is visited in 4 steps of 64 samples.  In step
-// (sy, sx) lane l takes sample row y = 2*(l/8) + sy, column tx = 2*(l%8) + sx: the 64 samples of a step
-// are spread over all 16 histogram cells (4 per cell), which keeps same-address collisions of the LDS
-// float atomics 4x lower than a row-major assignment.  Each sample makes up to 8 trilinear LDS
-// float-atomic adds into the 4x4x8 histogram.  All adds come from one wave in program order, so the
-// result is reproducible run to run.  Then L2-normalise, clamp at 0.2, L2-normalise (same reduction
-// tree as the reference) and scale the keypoint by `subsampling`.
+// One wave per keypoint, no LDS float atomics (ds_add_f32 retires one lane at a time on gfx950:
+// ~150 cycles per wave instruction, measured -- it was half of this kernel's time).
+//   phase 0  the pixels the 1024 bilinear taps can touch are staged in LDS with coalesced row loads
+//            (kDescPatch^2 floats; larger keypoints sample global memory directly).
+//   phase 1  the 16x16 rotated sample grid, 4 samples per lane: gradient magnitude (with the Gaussian
+//            window), angle bin and angle fraction go to LDS.
+//   phase 2  gather: lane l = (cell l/4, row pair l%4) walks its 2x8 share of the 8x8 samples that reach
+//            its histogram cell, forms the same products as the reference (horizontal, vertical, then
+//            angle weight) and accumulates them into a private 8-bin LDS histogram (plain read-add-write,
+//            lane-private rows, stride 9 -> conflict free).  The reference's column-14 spill into the
+//            next row's first cell (guard `tx<=14`, cuSIFT_D.cu:243) is gathered the same way; its
+//            angle-index-8 spill (atan2f == +pi) is rare and goes through one LDS atomic.
+//   phase 3  the 4 partial histograms of each cell are summed in a fixed order; L2-normalise, clamp at
+//            0.2, L2-normalise with the reference's reduction tree; scale the keypoint by `subsampling`.
+// The order of the sums is fixed, so results are reproducible run to run.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_add(float *buffer, int idx, float v) {
-  if ((unsigned int)idx < 176u) atomicAdd(buffer + idx, v);  // always true for finite inputs
+constexpr int kDescPatch = 48;  // LDS patch edge: covers descriptor windows up to scale ~2.5
+
+__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float *__restrict__ fin, int next_cell_base,
+                                              float grad, float angf, int angi, float wx, float wy) {
+  const float grad1 = wx * grad;
+  const float grad2 = wy * grad1;
+  const float v1 = (1.0f - angf) * grad2;
+  const float v2 = angf * grad2;
+  if (angi < 8) {
+    myhist[angi] += v1;
+  } else if (next_cell_base < 128) {
+    atomicAdd(fin + next_cell_base, v1);  // index angi+hist+off = 8 + ...: bin 0 of the next linear cell
+  }
+  const int angp = (angi < 7 ? angi + 1 : 0);
+  myhist[angp] += v2;
 }
 
 __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict__ img, int w, int h, int pitch,
@@ -726,8 +817,13 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
                                                         int max_pts, const unsigned int *__restrict__ first,
                                                         const unsigned int *__restrict__ counters, float subsampling,
                                                         float q, float inv_q) {
-  __shared__ float buffer[128 + 48];  // indices 128..175 absorb the reference's out-of-range adds (dropped)
+  __shared__ float s_grad[256];
+  __shared__ float s_angf[256];
+  __shared__ int s_angi[256];
+  __shared__ float s_hist[64 * 9];
+  __shared__ float fin[128];
   __shared__ float sums[64];
+  __shared__ float patch[kDescPatch * kDescPatch];
   const int lane = threadIdx.x;
   img += (long)blockIdx.y * img_stride;
   points += (long)blockIdx.y * max_pts;
@@ -735,11 +831,13 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
   const unsigned int cnt = counters[blockIdx.y];
   const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
 
+  // phase-2 geometry of this lane (independent of the keypoint)
+  const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
+  float *myhist = s_hist + lane * 9;
+  const int next_cell_base = 8 * (cell + 1);
+
   for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
     cusift_point *pt = points + bx;
-    buffer[lane] = 0.0f;
-    buffer[lane + 64] = 0.0f;
-    if (lane < 48) buffer[128 + lane] = 0.0f;
     const float theta = 2.0f * 3.1415f / 360.0f * pt->orientation;
     const float sina = sinf(theta);
     const float cosa = cosf(theta);
@@ -747,66 +845,104 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
     const float ssina = scale * sina;
     const float scosa = scale * cosa;
     const float px = pt->coords2D[0], py = pt->coords2D[1];
+    fin[lane] = 0.0f;
+    fin[lane + 64] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) myhist[b] = 0.0f;
+
+    // ---- phase 0: stage the sampled neighbourhood in LDS when it fits (it does for scale <~ 2.5) ----
+    // every tap is within `reach` of the keypoint: 7.5*spacing*(|cos|+|sin|) for the grid + 1 for the tap
+    const float reach = 7.5f * scale * (fabsf(cosa) + fabsf(sina)) + 1.0f + 0.01f;
+    PatchGeom g;
+    g.stride = kDescPatch;
+    g.x0 = (int)floorf(px - reach - 0.5f) - 1;
+    g.y0 = (int)floorf(py - reach - 0.5f) - 1;
+    const int pw = (int)floorf(px + reach - 0.5f) + 2 - g.x0 + 1;
+    const int ph = (int)floorf(py + reach - 0.5f) + 2 - g.y0 + 1;
+    const bool use_patch = (reach < 0.5f * kDescPatch) && (fabsf(px) < 1e6f) && (fabsf(py) < 1e6f) &&
+                           pw <= kDescPatch && ph <= kDescPatch;  // wave-uniform
+    if (use_patch) stage_patch(img, w, h, pitch, patch, g, pw, ph, lane);
     __syncthreads();
+
+    // ---- phase 1: samples ----
 #pragma unroll 1
     for (int step = 0; step < 4; ++step) {
-      const int y = 2 * (lane >> 3) + (step >> 1);
-      const int tx = 2 * (lane & 7) + (step & 1);
+      const int idx = lane + 64 * step;
+      const int y = idx >> 4, tx = idx & 15;
       const float gy = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
       const float gx = expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
       const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
       const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
-      const float dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q, inv_q) -
-                       tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q, inv_q);
-      const float dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q, inv_q) -
-                       tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q, inv_q);
+      float dx, dy;
+      if (use_patch) {
+        dx = tex2d_patch(patch, g, xpos + cosa, ypos + sina, q, inv_q) -
+             tex2d_patch(patch, g, xpos - cosa, ypos - sina, q, inv_q);
+        dy = tex2d_patch(patch, g, xpos - sina, ypos + cosa, q, inv_q) -
+             tex2d_patch(patch, g, xpos + sina, ypos - cosa, q, inv_q);
+      } else {
+        dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q, inv_q) -
+             tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q, inv_q);
+        dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q, inv_q) -
+             tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q, inv_q);
+      }
       const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
       float angf = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;
-
-      const int hori = (tx + 2) / 4 - 1;
-      const float horf = (tx - 1.5f) / 4.0f - hori;
-      const float ihorf = 1.0f - horf;
-      const int veri = (y + 2) / 4 - 1;
-      const float verf = (y - 1.5f) / 4.0f - veri;
-      const float iverf = 1.0f - verf;
-      const int angi = (int)angf;
-      const int angp = (angi < 7 ? angi + 1 : 0);
+      int angi = (int)angf;
       angf -= angi;
-      const float iangf = 1.0f - angf;
-
-      const int hist = 8 * (4 * veri + hori);
-      const int p1 = angi + hist;
-      const int p2 = angp + hist;
-      // every index the guards let through is in [0, 176); >= 128 is the dropped overflow region
-      if (tx >= 2) {
-        const float grad1 = ihorf * grad;
-        if (y >= 2) {
-          const float grad2 = iverf * grad1;
-          lds_add(buffer, p1, iangf * grad2);
-          lds_add(buffer, p2, angf * grad2);
-        }
-        if (y <= 13) {
-          const float grad2 = verf * grad1;
-          lds_add(buffer, p1 + 32, iangf * grad2);
-          lds_add(buffer, p2 + 32, angf * grad2);
-        }
-      }
-      if (tx <= 14) {  // sic (cuSIFT_D.cu:243)
-        const float grad1 = horf * grad;
-        if (y >= 2) {
-          const float grad2 = iverf * grad1;
-          lds_add(buffer, p1 + 8, iangf * grad2);
-          lds_add(buffer, p2 + 8, angf * grad2);
-        }
-        if (y <= 13) {
-          const float grad2 = verf * grad1;
-          lds_add(buffer, p1 + 40, iangf * grad2);
-          lds_add(buffer, p2 + 40, angf * grad2);
-        }
-      }
-      __syncthreads();
+      if (angi < 0 || angi > 8) angi = 0;  // only for non-finite input
+      s_grad[idx] = grad;
+      s_angf[idx] = angf;
+      s_angi[idx] = angi;
     }
-    float b0 = buffer[lane], b1 = buffer[lane + 64];
+    __syncthreads();
+
+    // ---- phase 2: gather into the lane-private histogram ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = 4 * vi - 2 + 2 * kq + r;
+      if (y >= 0 && y <= 15) {
+        const int veri = (y + 2) / 4 - 1;
+        const float verf = (y - 1.5f) / 4.0f - veri;
+        const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
+#pragma unroll
+        for (int cx = 0; cx < 8; ++cx) {
+          const int tx = 4 * hi - 2 + cx;
+          if (tx >= 0 && tx <= 15) {
+            const int hori = (tx + 2) / 4 - 1;
+            const float horf = (tx - 1.5f) / 4.0f - hori;
+            const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
+            const int idx = y * 16 + tx;
+            gather_sample(myhist, fin, next_cell_base, s_grad[idx], s_angf[idx], s_angi[idx], wx, wy);
+          }
+        }
+      }
+    }
+    if (hi == 0 && vi >= 1) {
+      // the reference's right-hand adds of column 14 (hori+1 == 4) land in cell (row+1, 0)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int y = 4 * (vi - 1) - 2 + 2 * kq + r;
+        if (y >= 0 && y <= 15) {
+          const int veri = (y + 2) / 4 - 1;
+          const float verf = (y - 1.5f) / 4.0f - veri;
+          const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
+          const float horf = (14 - 1.5f) / 4.0f - 3;
+          const int idx = y * 16 + 14;
+          gather_sample(myhist, fin, next_cell_base, s_grad[idx], s_angf[idx], s_angi[idx], horf, wy);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: cell sums (fixed order) and normalisation ----
+    float bsum[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int b = lane + 64 * r;
+      const float *hc = s_hist + (b >> 3) * 4 * 9 + (b & 7);
+      bsum[r] = ((hc[0] + hc[9]) + hc[18]) + hc[27];
+    }
+    float b0 = fin[lane] + bsum[0], b1 = fin[lane + 64] + bsum[1];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       sums[lane] = b0 * b0 + b1 * b1;

@@ -246,6 +246,39 @@ def test_descriptors_match_oracle(ctx, oracle, gray1, frac_bits):
     np.testing.assert_array_equal(pts["data"][n:], got["data"][n:])
 
 
+def test_descriptor_quirk_paths(ctx, oracle):
+    """Hand-placed keypoints that force the reference's index-overflow paths:
+    rows identical + orientation 0 -> dy == +0 exactly, dx < 0 on falling ramps -> atan2f == +pi ->
+    angle index 8 spills into the next cell's bin 0; large scales leave the LDS patch (global path);
+    keypoints at the image corners exercise the clamped footprints."""
+    w, h = 256, 192
+    x = np.arange(w, dtype=np.float32)
+    row = np.where((x // 16) % 2 == 0, 200 - 8 * (x % 16), 72 + 8 * (x % 16))  # saw-tooth ramps
+    img = np.tile(row, (h, 1)).astype(np.float32)
+    src = pitched(img)
+    pts = np.zeros(64, dtype=SIFT_POINT_DTYPE)
+    rng = np.random.default_rng(3)
+    n = 48
+    pts["coords2D"][:n, 0] = rng.uniform(-2, w + 2, n)
+    pts["coords2D"][:n, 1] = rng.uniform(-2, h + 2, n)
+    pts["scale"][:n] = np.concatenate([rng.uniform(0.8, 2.2, 32), rng.uniform(2.6, 9.0, 16)])
+    pts["orientation"][:n] = np.where(np.arange(n) % 3 == 0, 0.0, rng.uniform(0, 360, n))
+    pts["coords2D"][0] = (0.0, 0.0)
+    pts["coords2D"][1] = (w - 1.0, h - 1.0)
+    want = pts.copy()
+    oracle.extract_descriptors(src, w, h, want, 0, n, 1.0, 8)
+    d_img = DeviceBuffer.from_numpy(ctx, src)
+    d_pts = DeviceBuffer.from_numpy(ctx, pts)
+    d_cnt = DeviceBuffer.from_numpy(ctx, np.array([n], dtype=np.uint32))
+    ctx.extract_descriptors(d_img.ptr, w, h, src.shape[1], d_pts.ptr, len(pts), None, d_cnt.ptr, 1.0, 8)
+    got = d_pts.to_numpy(SIFT_POINT_DTYPE, (len(pts),))
+    fin = np.isfinite(want["data"][:n]).all(axis=1)
+    assert fin.sum() >= n - 4
+    np.testing.assert_array_equal(np.isfinite(got["data"][:n]).all(axis=1), fin)
+    l2 = np.linalg.norm(want["data"][:n][fin].astype(np.float64) - got["data"][:n][fin].astype(np.float64), axis=1)
+    assert l2.max() < 1e-4, np.sort(l2)[-5:]
+
+
 def test_first_offset_restricts_the_range(ctx, oracle, gray1):
     w, h = 640, 480
     src, pts, n = oracle_octave_points(oracle, gray1, w, h, 0.0, 1.0, 1.0)
