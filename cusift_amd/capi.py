@@ -86,7 +86,7 @@ SIGNATURES = {
     "cusift_image_d2h": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "cusift_malloc_host": (_i, [C.POINTER(_vp), _sz]),
     "cusift_free_host": (_i, [_vp]),
-    "cusift_scale_down": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i]),
+    "cusift_scale_down": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
     "cusift_laplace_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _vp, _sz, _i]),
     "cusift_laplace_taps": (_i, [_f, _vp]),
     "cusift_find_points_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _vp, _i, _vp, _i]),
@@ -220,11 +220,12 @@ class Context:
         check(lib().cusift_memcpy_d2h(self.handle, arr.ctypes.data, C.c_void_p(d_ptr), arr.nbytes))
 
     # ---- stage entry points (device pointers are plain ints) ----
-    def scale_down(self, d_dst, dst_pitch, d_src, w, h, src_pitch, n_images=1, dst_stride=None, src_stride=None):
+    def scale_down(self, d_dst, dst_pitch, d_src, w, h, src_pitch, n_images=1, dst_stride=None, src_stride=None,
+                   variance=0.5):
         dst_stride = (h // 2) * dst_pitch if dst_stride is None else dst_stride
         src_stride = h * src_pitch if src_stride is None else src_stride
         check(lib().cusift_scale_down(self.handle, d_dst, dst_pitch, dst_stride, d_src, w, h, src_pitch, src_stride,
-                                      n_images))
+                                      n_images, variance))
 
     def laplace_multi(self, d_img, w, h, pitch, init_blur, d_dog, n_images=1, img_stride=None, dog_stride=None):
         img_stride = h * pitch if img_stride is None else img_stride

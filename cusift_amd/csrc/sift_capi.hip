@@ -206,9 +206,8 @@ int pick_rows(int h, int strips, int n_images, int lo, int hi) {
   return (int)r;
 }
 
-void scale_down_taps(ScaleDownTaps &T) {
-  // cuSIFT.cu:320-341 with variance = 0.5 (cuSIFT.cu:185)
-  const float variance = 0.5f;
+void scale_down_taps(ScaleDownTaps &T, float variance) {
+  // cuSIFT.cu:320-341 (the pyramid passes variance = 0.5, cuSIFT.cu:185)
   float k[5], sum = 0.0f;
   for (int j = 0; j < 5; j++) {
     k[j] = (float)expf(-(double)(j - 2) * (j - 2) / 2.0 / variance);
@@ -480,14 +479,15 @@ extern "C" int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_sr
 // stage entry points
 // ------------------------------------------------------------------------------------------------
 extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
-                                 int w, int h, int src_pitch, size_t src_stride, int n_images) {
+                                 int w, int h, int src_pitch, size_t src_stride, int n_images, float variance) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
   if (!d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "ScaleDown: missing data");  // cuSIFT.cu:315-318
+  if (!(variance > 0.0f)) return fail(CUSIFT_ERR_INVALID, "ScaleDown: variance must be > 0");
   const int ow = w / 2, oh = h / 2;
   if (n_images < 1 || ow < 1 || oh < 1 || src_pitch < w || dst_pitch < ow)
     return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
   ScaleDownTaps T;
-  scale_down_taps(T);
+  scale_down_taps(T, variance);
   const int strips = idiv_up(ow, 64);
   const int rows = pick_rows(oh, strips, n_images, 4, 16);
   dim3 grid(strips, idiv_up(idiv_up(oh, rows), kWavesPerBlock), n_images);
@@ -645,7 +645,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     float *dst = (float *)(ctx->arena + pl.base_off[o]);
     stride[o] = (size_t)pl.h[o] * pl.p[o];
     TRY(cusift_scale_down(ctx, dst, pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1], pl.p[o - 1],
-                          stride[o - 1], n_images));
+                          stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
     base[o] = dst;
   }
   float *dog = (float *)(ctx->arena + pl.dog_off);

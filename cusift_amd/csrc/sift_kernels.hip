@@ -795,7 +795,7 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
 //            0.2, L2-normalise with the reference's reduction tree; scale the keypoint by `subsampling`.
 // The order of the sums is fixed, so results are reproducible run to run.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDescPatch = 48;  // LDS patch edge: covers descriptor windows up to scale ~2.5
+constexpr int kDescPatch = 40;  // LDS patch edge: covers descriptor windows up to scale ~2.1 at 45 degrees
 
 __device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float *__restrict__ fin, int next_cell_base,
                                               float grad, float angf, int angi, float wx, float wy) {
@@ -831,6 +831,15 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
   const unsigned int cnt = counters[blockIdx.y];
   const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
 
+  // phase-1 constants of this lane: sample idx = lane + 64*step -> column tx = lane%16, row y = lane/16 + 4*step
+  const int tx1 = lane & 15;
+  const float gx1 = expf(-(tx1 - 7.5f) * (tx1 - 7.5f) / 128.0f);
+  float gy1[4];
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int y = (lane >> 4) + 4 * step;
+    gy1[step] = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
+  }
   // phase-2 geometry of this lane (independent of the keypoint)
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
   float *myhist = s_hist + lane * 9;
@@ -865,12 +874,11 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
     __syncthreads();
 
     // ---- phase 1: samples ----
-#pragma unroll 1
+#pragma unroll
     for (int step = 0; step < 4; ++step) {
       const int idx = lane + 64 * step;
-      const int y = idx >> 4, tx = idx & 15;
-      const float gy = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
-      const float gx = expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
+      const int y = idx >> 4, tx = tx1;
+      const float gy = gy1[step], gx = gx1;
       const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
       const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
       float dx, dy;

@@ -1,0 +1,346 @@
+// cuSIFT.h -- drop-in C++ surface of danielsuo/cuSIFT's extraction path for MI355X.
+//
+// A program written against the reference's cuSIFT.h / cuImage.h / cutils.h (the live `SiftData` class API of
+// test/detector.cpp:41-49, or the legacy InitSiftData / ExtractSift / FreeSiftData trio of main.cpp:99-103,
+// 324-349) compiles against this one header and links libcusift_amd.so.  Everything here is a thin
+// inline shim over the C ABI in cusift_amd.h: no HIP headers, no CUDA types.
+//
+// Differences from the reference, on purpose:
+//   * the methods that took a cudaTextureObject_t (cuSIFT.h:68-71) are internal helpers of the reference
+//     and are not exported; LaplaceMulti/FindPointsMulti/... are reachable through the C ABI instead;
+//   * errors: the reference prints and exit(-1)s (cutils.h:24-48); so does safeCall() below, with the
+//     library's message.  Define CUSIFT_NO_EXIT to get a std::runtime_error instead;
+//   * SiftData's parameter fields are initialised (the reference leaves them indeterminate, cuSIFT.cu:13-32);
+//   * copying a SiftData/cuImage is disabled (the reference double-frees).
+#ifndef CUSIFT_AMD_DROPIN_H
+#define CUSIFT_AMD_DROPIN_H
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+#include "cusift_amd.h"
+
+// ---- cutils.h:15-18 -------------------------------------------------------------------------------
+inline int iDivUp(int a, int b) { return (a % b != 0) ? (a / b + 1) : (a / b); }
+inline int iDivDown(int a, int b) { return a / b; }
+inline int iAlignUp(int a, int b) { return (a % b != 0) ? (a - a % b + b) : a; }
+inline int iAlignDown(int a, int b) { return a - a % b; }
+
+// ---- cutils.h:20-48: failure = message + exit(-1) ---------------------------------------------------
+inline void cusift_check_(int rc, const char *what, const char *file, int line) {
+  if (rc == CUSIFT_OK) return;
+#ifdef CUSIFT_NO_EXIT
+  (void)file;
+  (void)line;
+  throw std::runtime_error(std::string(what) + ": " + cusift_last_error());
+#else
+  std::fprintf(stderr, "safeCall() runtime error in file <%s>, line %i : %s (%s).\n", file, line, cusift_last_error(),
+               what);
+  std::exit(-1);
+#endif
+}
+#define safeCall(expr) cusift_check_((expr), #expr, __FILE__, __LINE__)
+
+namespace cusift_dropin {
+// The reference keeps one implicit global context (default stream + file-scope device symbols,
+// cuSIFT_D.cu:13-20).  Here it is one lazily created cusift_ctx on the device chosen by InitCuda().
+inline int &device_slot() {
+  static int dev = 0;
+  return dev;
+}
+inline cusift_ctx *&ctx_slot() {
+  static cusift_ctx *c = nullptr;
+  return c;
+}
+inline cusift_ctx *ctx() {
+  cusift_ctx *&c = ctx_slot();
+  if (!c) safeCall(cusift_ctx_create(&c, device_slot(), nullptr));
+  return c;
+}
+inline void shutdown() {
+  cusift_ctx *&c = ctx_slot();
+  if (c) cusift_ctx_destroy(c);
+  c = nullptr;
+}
+}  // namespace cusift_dropin
+
+// ---- cutils.h:71-92 -------------------------------------------------------------------------------
+inline void InitCuda(int devNum) {
+  int n = 0;
+  cusift_device_count(&n);
+  if (!n) {
+    std::cerr << "No GPU devices available" << std::endl;
+    return;
+  }
+  if (devNum > n - 1) devNum = n - 1;
+  if (devNum < 0) devNum = 0;
+  if (cusift_dropin::ctx_slot() && cusift_dropin::device_slot() != devNum) cusift_dropin::shutdown();
+  cusift_dropin::device_slot() = devNum;
+  safeCall(cusift_init(devNum));
+}
+
+// ---- cutils.h:94-140 ------------------------------------------------------------------------------
+// The reference brackets work with cudaEvents on the default stream; every entry point of this shim
+// blocks until its GPU work is done, so wall-clock between construction and read() measures the same span.
+class TimerGPU {
+ public:
+  explicit TimerGPU(void * /*stream*/ = nullptr) : t0(std::chrono::steady_clock::now()) {}
+  float read() {
+    cusift_ctx_synchronize(cusift_dropin::ctx());
+    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+
+ private:
+  std::chrono::steady_clock::time_point t0;
+};
+
+class TimerCPU {
+ public:
+  explicit TimerCPU(float /*freq_MHz*/) : t0(std::chrono::steady_clock::now()) {}
+  float read() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+ private:
+  std::chrono::steady_clock::time_point t0;
+};
+
+// ---- cuImage.h:8-26, cuImage.cu ---------------------------------------------------------------------
+class cuImage {
+ public:
+  int width, height;
+  int pitch;      // in floats
+  float *h_data;  // dense rows (width floats), borrowed unless h_internalAlloc
+  float *d_data;  // pitched rows, owned iff d_internalAlloc
+  float *t_data;  // kept for layout compatibility; never used (the reference's texture array)
+  bool d_internalAlloc;
+  bool h_internalAlloc;
+
+  cuImage() : width(0), height(0), pitch(0), h_data(nullptr), d_data(nullptr), t_data(nullptr),
+              d_internalAlloc(false), h_internalAlloc(false) {}
+  // cuImage.cu:53-60
+  cuImage(int w, int h, float *host, bool download = true)
+      : width(0), height(0), pitch(0), h_data(nullptr), d_data(nullptr), t_data(nullptr), d_internalAlloc(false),
+        h_internalAlloc(false) {
+    AllocateWithHostMemory(w, h, host);
+    if (download) HostToDevice();
+  }
+  ~cuImage() { release(); }
+  cuImage(const cuImage &) = delete;
+  cuImage &operator=(const cuImage &) = delete;
+
+  // cuImage.cu:11-13
+  void AllocateWithHostMemory(int w, int h, float *host) { Allocate(w, h, iAlignUp(w, 128), false, nullptr, host); }
+
+  // cuImage.cu:16-46.  Wraps caller memory when given, allocates otherwise (pitch is honoured as passed).
+  void Allocate(int w, int h, int p, bool withHost, float *dev = nullptr, float *host = nullptr) {
+    release();
+    width = w;
+    height = h;
+    pitch = p;
+    d_data = dev;
+    h_data = host;
+    t_data = nullptr;
+    if (d_data == nullptr) {
+      void *ptr = nullptr;
+      safeCall(cusift_malloc(&ptr, sizeof(float) * (size_t)pitch * (size_t)height));
+      d_data = static_cast<float *>(ptr);
+      d_internalAlloc = true;
+    }
+    if (withHost && h_data == nullptr) {
+      h_data = static_cast<float *>(std::malloc(sizeof(float) * (size_t)pitch * (size_t)height));
+      h_internalAlloc = true;
+    }
+  }
+
+  // cuImage.cu:83-117: return milliseconds
+  double HostToDevice() {
+    TimerGPU timer;
+    if (d_data != nullptr && h_data != nullptr)
+      safeCall(cusift_image_h2d(cusift_dropin::ctx(), d_data, pitch, h_data, width, height));
+    return timer.read();
+  }
+  double DeviceToHost() {
+    TimerGPU timer;
+    if (d_data != nullptr && h_data != nullptr)
+      safeCall(cusift_image_d2h(cusift_dropin::ctx(), h_data, d_data, pitch, width, height));
+    return timer.read();
+  }
+
+ private:
+  void release() {
+    if (d_internalAlloc && d_data != nullptr) cusift_free(d_data);
+    if (h_internalAlloc && h_data != nullptr) std::free(h_data);
+    d_data = h_data = t_data = nullptr;
+    d_internalAlloc = h_internalAlloc = false;
+  }
+};
+
+// ---- cuSIFT.h:10-30 -------------------------------------------------------------------------------
+class SiftPoint {
+ public:
+  float coords2D[2];
+  float scale;
+  float sharpness;
+  float edgeness;
+  float orientation;
+  float score;
+  float ambiguity;
+  int match;
+  float match_xpos;
+  float match_ypos;
+  float match_error;
+  float subsampling;
+  float empty[3];
+  float data[128];
+  float coords3D[3];
+};
+static_assert(sizeof(SiftPoint) == sizeof(cusift_point) && sizeof(SiftPoint) == 588, "SiftPoint is a 588-byte record");
+
+// ---- cuSIFT.h:32-74, cuSIFT.cu:13-120 ---------------------------------------------------------------
+class SiftData {
+ public:
+  int numPts;  // number of available SIFT points
+  int maxPts;  // number of allocated SIFT points
+  SiftPoint *h_data;
+  SiftPoint *d_data;
+
+  // parameters (cuSIFT.h:44-51); defaults are the values of test/detector.cpp:42-48
+  int numOctaves;
+  int numScales;  // never read on the live path of the reference either (NUM_SCALES is compile-time 5)
+  double initBlur;
+  float initSubsampling;
+  float peakThresh;
+  float edgeThresh;
+  float lowestScale;
+
+  // cuSIFT.cu:13-32
+  explicit SiftData(int maxPts_ = 1024, bool host = false, bool dev = false)
+      : numPts(0), maxPts(0), h_data(nullptr), d_data(nullptr), numOctaves(5), numScales(5), initBlur(0.0),
+        initSubsampling(1.0f), peakThresh(0.1f), edgeThresh(10.0f), lowestScale(0.0f) {
+    allocate(maxPts_, host, dev);
+  }
+  ~SiftData() { release(); }
+  SiftData(const SiftData &) = delete;
+  SiftData &operator=(const SiftData &) = delete;
+
+  // cuSIFT.cu:52-59
+  void Synchronize() {
+    if (h_data && d_data && numPts > 0)
+      safeCall(cusift_memcpy_d2h(cusift_dropin::ctx(), h_data, d_data, sizeof(SiftPoint) * (size_t)numPts));
+  }
+
+  // cuSIFT.cu:61-120: dense host image -> numPts, d_data, h_data
+  void Extract(float *im, int width, int height, float subsampling = 1.0f) {
+    TimerGPU timer;
+    require_device("Extract");
+    cusift_params p = params(subsampling);
+    safeCall(cusift_extract_host(cusift_dropin::ctx(), im, width, height, &p, as_c(d_data), as_c(h_data), &numPts));
+    report(timer.read());
+  }
+
+  // legacy ExtractSift on a device-resident cuImage (main.cpp:102-103,327-328)
+  void Extract(cuImage &img, float subsampling = 1.0f) {
+    TimerGPU timer;
+    require_device("ExtractSift");
+    if (img.d_data == nullptr) {
+      std::printf("ExtractSift: missing data\n");
+      return;
+    }
+    cusift_params p = params(subsampling);
+    safeCall(cusift_extract(cusift_dropin::ctx(), img.d_data, img.width, img.height, img.pitch, &p, as_c(d_data),
+                            as_c(h_data), &numPts));
+    report(timer.read());
+  }
+
+  // cuSIFT.cu:383-395 (always returns 0.0 like every launch wrapper of the reference)
+  double ConvertSiftToRootSift() {
+    if (d_data && numPts > 0) {
+      safeCall(cusift_rootsift(cusift_dropin::ctx(), as_c(d_data), numPts));
+      safeCall(cusift_ctx_synchronize(cusift_dropin::ctx()));
+    }
+    return 0.0;
+  }
+
+  // used by InitSiftData / FreeSiftData
+  void allocate(int maxPts_, bool host, bool dev) {
+    release();
+    numPts = 0;
+    maxPts = maxPts_;
+    const size_t bytes = sizeof(SiftPoint) * (size_t)(maxPts_ > 0 ? maxPts_ : 0);
+    if (host && bytes) h_data = static_cast<SiftPoint *>(std::malloc(bytes));
+    if (dev && bytes) {
+      void *ptr = nullptr;
+      safeCall(cusift_malloc(&ptr, bytes));
+      d_data = static_cast<SiftPoint *>(ptr);
+    }
+  }
+  void release() {
+    if (d_data != nullptr) cusift_free(d_data);
+    d_data = nullptr;
+    if (h_data != nullptr) std::free(h_data);
+    h_data = nullptr;
+    numPts = 0;
+    maxPts = 0;
+  }
+
+ private:
+  static cusift_point *as_c(SiftPoint *p) { return reinterpret_cast<cusift_point *>(p); }
+  cusift_params params(float subsampling) const {
+    cusift_params p;
+    cusift_default_params(&p);
+    p.num_octaves = numOctaves;
+    p.init_blur = initBlur;
+    p.peak_thresh = peakThresh;
+    p.edge_thresh = edgeThresh;
+    p.lowest_scale = lowestScale;
+    p.subsampling = subsampling;
+    p.max_pts = maxPts;
+    return p;
+  }
+  void require_device(const char *who) const {
+    if (d_data == nullptr || maxPts < 1) {
+      std::fprintf(stderr, "%s: SiftData has no device buffer (construct with dev = true)\n", who);
+      std::exit(-1);
+    }
+  }
+  static void report(double ms) {
+#ifndef CUSIFT_QUIET
+    // the reference prints this line on every call (inverted guard, cuSIFT.cu:117-119)
+    std::printf("Total time incl memory =      %.2f ms\n", ms);
+#else
+    (void)ms;
+#endif
+  }
+};
+
+// ---- free functions ----------------------------------------------------------------------------------
+// cuSIFT.cu:313-353
+inline double ScaleDown(cuImage &res, cuImage &src, float variance) {
+  if (res.d_data == nullptr || src.d_data == nullptr) {
+    std::printf("ScaleDown: missing data\n");
+    return 0.0;
+  }
+  safeCall(cusift_scale_down(cusift_dropin::ctx(), res.d_data, res.pitch, (size_t)res.pitch * res.height, src.d_data,
+                             src.width, src.height, src.pitch, (size_t)src.pitch * src.height, 1, variance));
+  safeCall(cusift_ctx_synchronize(cusift_dropin::ctx()));
+  return 0.0;
+}
+
+// Legacy API named by the north star (signatures from main.cpp:99-103,207-211,324-328,348-349 and the
+// commented bodies at cuSIFT.cu:123-134,272-303).  edgeThresh has no legacy argument: 10.0 as everywhere.
+inline void InitSiftData(SiftData &data, int num, bool host, bool dev) { data.allocate(num, host, dev); }
+inline void FreeSiftData(SiftData &data) { data.release(); }
+inline void ExtractSift(SiftData &siftData, cuImage &img, int numOctaves, double initBlur, float thresh,
+                        float lowestScale = 0.0f, float subsampling = 1.0f) {
+  siftData.numOctaves = numOctaves;
+  siftData.initBlur = initBlur;
+  siftData.peakThresh = thresh;
+  siftData.lowestScale = lowestScale;
+  siftData.edgeThresh = 10.0f;
+  siftData.Extract(img, subsampling);
+}
+
+#endif  // CUSIFT_AMD_DROPIN_H

@@ -117,10 +117,11 @@ int cusift_malloc_host(void **h_ptr, size_t bytes);
 int cusift_free_host(void *h_ptr);
 
 /* ---- stage entry points (the reference's launch wrappers) --------------------------------- */
-/* ScaleDown(res, src, variance=0.5), cuSIFT.cu:313-353 + ScaleDown_D cuSIFT_D.cu:37-182.
+/* ScaleDown(res, src, variance), cuSIFT.cu:313-353 + ScaleDown_D cuSIFT_D.cu:37-182.  `variance` sets the
+ * 5-tap Gaussian exp(-(j-2)^2/(2*variance)) (the pyramid uses 0.5, cuSIFT.cu:185).
  * dst is (w/2) x (h/2); writes are bounds-checked (the reference's are not). */
 int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w,
-                      int h, int src_pitch, size_t src_stride, int n_images);
+                      int h, int src_pitch, size_t src_stride, int n_images, float variance);
 /* SiftData::LaplaceMulti, cuSIFT.cu:399-422 + LaplaceMulti_D cuSIFT_D.cu:525-553: 8 blurs + 7 DoG
  * planes, planar [7][h][pitch] per image (`dog_stride` floats between images, >= 7*h*pitch). */
 int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
