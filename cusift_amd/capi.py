@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcusift_amd.so")
 
 CUSIFT_OK = 0
-NUM_STAGES = 6
+NUM_STAGES = 7
 STAGE_NAMES = ("scale_down", "laplace_multi", "find_points_multi", "compute_orientations",
-               "extract_descriptors", "total")
+               "extract_descriptors", "total", "detect_multi")
 
 # SiftPoint, cuSIFT.h:10-30 (588 B, no padding)
 SIFT_POINT_DTYPE = np.dtype(
@@ -52,6 +52,7 @@ class Params(C.Structure):
         ("subsampling", C.c_float),
         ("max_pts", C.c_int),
         ("tex_frac_bits", C.c_int),
+        ("fused_detect", C.c_int),
     ]
 
 
@@ -90,6 +91,7 @@ SIGNATURES = {
     "cusift_laplace_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _vp, _sz, _i]),
     "cusift_laplace_taps": (_i, [_f, _vp]),
     "cusift_find_points_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _vp, _i, _vp, _i]),
+    "cusift_detect_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _f, _vp, _i, _vp, _i]),
     "cusift_compute_orientations": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _i, _i]),
     "cusift_extract_descriptors": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _f, _i, _i]),
     "cusift_rootsift": (_i, [_vp, _vp, _i]),
@@ -238,6 +240,12 @@ class Context:
         dog_stride = 7 * h * pitch if dog_stride is None else dog_stride
         check(lib().cusift_find_points_multi(self.handle, d_dog, w, h, pitch, dog_stride, peak_thresh, edge_thresh,
                                              subsampling, d_points, max_pts, d_counters, n_images))
+
+    def detect_multi(self, d_img, w, h, pitch, init_blur, peak_thresh, edge_thresh, subsampling, d_points, max_pts,
+                     d_counters, n_images=1, img_stride=None):
+        img_stride = h * pitch if img_stride is None else img_stride
+        check(lib().cusift_detect_multi(self.handle, d_img, w, h, pitch, img_stride, init_blur, peak_thresh,
+                                        edge_thresh, subsampling, d_points, max_pts, d_counters, n_images))
 
     def compute_orientations(self, d_img, w, h, pitch, d_points, max_pts, d_first, d_counters, tex_frac_bits=8,
                              n_images=1, img_stride=None):

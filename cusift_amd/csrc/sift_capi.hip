@@ -22,6 +22,8 @@ __global__ void laplace_multi_kernel(const float *, float *, int, int, int, long
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                         FindParams);
+__global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
+                                    LaplaceTapsPk, FindParams);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
                                    FindParams);
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
@@ -80,6 +82,9 @@ struct cusift_ctx {
   // scratch arena (one allocation, grown on demand, never shrunk)
   char *arena = nullptr;
   size_t arena_bytes = 0;
+  // DoG planes of the two-stage path ([n][7][h0][p0] floats); allocated only when that path runs
+  float *dog = nullptr;
+  size_t dog_bytes = 0;
   // small persistent device scratch for the blocking single-image entry points
   unsigned int *d_counter1 = nullptr;
   // timing
@@ -141,7 +146,8 @@ struct Plan {
   float sub[kMaxOctaves];
   // arena offsets in bytes
   size_t base_off[kMaxOctaves];  // octave >= 1 base images (n * h*p floats each); [0] unused
-  size_t dog_off = 0, first_off = 0, total = 0;
+  size_t first_off = 0, total = 0;
+  size_t dog_bytes = 0;   // size of the separate DoG buffer if the two-stage path is taken
   size_t dog_stride = 0;  // floats per image
 };
 
@@ -175,12 +181,23 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
     pl.base_off[o] = off;
     off = align_up_sz(off + (size_t)n_images * pl.h[o] * pl.p[o] * sizeof(float), 256);
   }
-  pl.dog_off = off;
   pl.dog_stride = (size_t)kNumDog * pl.h[0] * pl.p[0];
-  off = align_up_sz(off + (size_t)n_images * pl.dog_stride * sizeof(float), 256);
+  pl.dog_bytes = (size_t)n_images * pl.dog_stride * sizeof(float);
   pl.first_off = off;
   off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
   pl.total = off;
+  return CUSIFT_OK;
+}
+
+int ensure_dog(cusift_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->dog_bytes) return CUSIFT_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->dog) HIP_TRY(hipFree(ctx->dog));
+  ctx->dog = nullptr;
+  ctx->dog_bytes = 0;
+  hipError_t e = hipMalloc((void **)&ctx->dog, bytes);
+  if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "DoG hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  ctx->dog_bytes = bytes;
   return CUSIFT_OK;
 }
 
@@ -314,6 +331,7 @@ extern "C" void cusift_default_params(cusift_params *p) {
   p->subsampling = 1.0f;
   p->max_pts = 1024;  // SiftData ctor default (cuSIFT.h:56)
   p->tex_frac_bits = 8;
+  p->fused_detect = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,6 +376,7 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->dog) (void)hipFree(ctx->dog);
   if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -380,7 +399,7 @@ extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, c
   return ensure_arena(ctx, pl.total + align_up_sz((size_t)h * ialign_up(w, 128) * sizeof(float), 256));
 }
 
-extern "C" size_t cusift_ctx_arena_bytes(cusift_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+extern "C" size_t cusift_ctx_arena_bytes(cusift_ctx *ctx) { return ctx ? ctx->arena_bytes + ctx->dog_bytes : 0; }
 
 extern "C" int cusift_ctx_timing_enable(cusift_ctx *ctx, int on) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
@@ -569,6 +588,39 @@ extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int
   return check_launch("find_points_multi");
 }
 
+static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t img_stride) {
+  return (pitch % 4 == 0) && (((uintptr_t)d_img % 16) == 0) && (img_stride % 4 == 0) && (w % 4 == 0) && w >= 4 &&
+         h >= 3 && ((size_t)h * pitch * sizeof(float) < (1ull << 31));
+}
+
+extern "C" int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                                   float init_blur, float peak_thresh, float edge_thresh, float subsampling,
+                                   cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
+  if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "DetectMulti: bad geometry");
+  if (!detect_fused_ok(d_img, w, h, pitch, img_stride))
+    return fail(CUSIFT_ERR_INVALID, "DetectMulti: needs 16-byte aligned rows, w %% 4 == 0, h >= 3, image < 2 GiB");
+  float taps[8 * 16];
+  laplace_taps_table(init_blur, taps);
+  LaplaceTapsPk TP;
+  for (int q = 0; q < kNumLevels / 2; ++q)
+    for (int j = 0; j < 5; ++j) {
+      TP.k[q][j].x = taps[16 * (2 * q) + j];
+      TP.k[q][j].y = taps[16 * (2 * q + 1) + j];
+    }
+  FindParams P;
+  find_params(P, peak_thresh, edge_thresh, subsampling);
+  const int strips = idiv_up(w, 240);  // kDetStrip
+  const int rows = pick_rows(h, strips, n_images, 8, 32);
+  dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_DETECT);
+  hipLaunchKernelGGL(detect_fused_kernel, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
+                     d_points, max_pts, d_counters, rows, TP, P);
+  return check_launch("detect_multi");
+}
+
 static int keypoint_grid_x(int max_pts, int n_images) {
   // persistent grid: enough waves to fill 256 CUs x 32 wave slots, never more than max_pts per image
   int per_image = std::max(1, (256 * 32 * 2) / std::max(1, n_images));
@@ -648,19 +700,27 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
                           stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
     base[o] = dst;
   }
-  float *dog = (float *)(ctx->arena + pl.dog_off);
   unsigned int *first = (unsigned int *)(ctx->arena + pl.first_off);
   // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
   for (int o = pl.n_oct - 1; o >= 0; --o) {
     if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
     // ExtractSiftOctave, cuSIFT.cu:204-270
     const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
-    TRY(cusift_laplace_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], dog, dstride,
-                             n_images));
     unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
     HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
-    TRY(cusift_find_points_multi(ctx, dog, pl.w[o], pl.h[o], pl.p[o], dstride, prm->peak_thresh, prm->edge_thresh,
-                                 pl.sub[o], d_points, prm->max_pts, d_counters, n_images));
+    if (prm->fused_detect && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o]) &&
+        !getenv("CUSIFT_FORCE_GENERIC")) {
+      TRY(cusift_detect_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o],
+                              prm->peak_thresh, prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters,
+                              n_images));
+    } else {
+      TRY(ensure_dog(ctx, pl.dog_bytes));
+      float *dog = ctx->dog;
+      TRY(cusift_laplace_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], dog, dstride,
+                               n_images));
+      TRY(cusift_find_points_multi(ctx, dog, pl.w[o], pl.h[o], pl.p[o], dstride, prm->peak_thresh, prm->edge_thresh,
+                                   pl.sub[o], d_points, prm->max_pts, d_counters, n_images));
+    }
     TRY(cusift_compute_orientations(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
                                     d_counters, prm->tex_frac_bits, n_images));
     TRY(cusift_extract_descriptors(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,

@@ -588,6 +588,257 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused detection: LaplaceMulti + FindPointsMulti in one pass, the DoG planes never leave the chip.
+// (Reference: LaplaceMulti_D cuSIFT_D.cu:525-553 followed by FindPointsMulti_D cuSIFT_D.cu:402-523; the
+// reference round-trips 7 DoG planes through memory between them: 28 B/px written + 28 B/px read.)
+//
+// Same column strips and the same arithmetic as laplace_multi_fast_kernel and find_points_fast_kernel --
+// the DoG values tested and refined here are bit for bit the ones those kernels store/load -- but each
+// wave keeps the DoG rows y-1, y, y+1 of all 7 planes in registers (float4 per lane) and runs the
+// 26-neighbour test on them as soon as row y+1 is blurred.  HBM traffic drops from 60 B/px to the 4 B/px
+// of the source image; the kernel is VALU-bound (~2.8 wave instructions per pixel).
+//   * lanes 0-1 / 62-63 are halo (blur needs +-4 columns = 1 lane, the extremum test 1 more column);
+//     60 lanes x 4 = 240 columns per wave produce keypoints.  Nothing is stored, so no alignment rule.
+//   * a wave owns rows [y0,y1) as extremum CENTRES: it blurs rows y0-1 .. y1 (2 extra rows per chunk).
+//     Image-border pixels are never extrema in the reference (a clamped neighbour equals the centre), so
+//     centres are restricted to 1..h-2 / 1..w-2 and no clamped DoG row is ever needed.
+//   * refinement (rare): the three planes x three rows a scale needs are dumped to a wave-private LDS
+//     cube, so the detecting lane can read its 3x3x3 neighbourhood (incl. neighbour lanes' columns) with
+//     the same code as the unfused kernel reads it from global memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDetHaloLanes = 2;
+constexpr int kDetStrip = (64 - 2 * kDetHaloLanes) * kBlurCols;  // 240 columns of extremum centres per wave
+constexpr int kCubeCols = 64 * kBlurCols;                        // 256 floats per cube row
+
+__device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTapsPk &T, f4 (&D)[kNumDog]) {
+  const f4 ctr = win[4];
+  const f4 p1 = win[3] + win[5];
+  const f4 p2 = win[2] + win[6];
+  const f4 p3 = win[1] + win[7];
+  const f4 p4 = win[0] + win[8];
+  float prev_hi[4];
+#pragma unroll
+  for (int q = 0; q < kNumLevels / 2; ++q) {
+    const f2 k0 = T.k[q][0], k1 = T.k[q][1], k2 = T.k[q][2], k3 = T.k[q][3], k4 = T.k[q][4];
+    f2 e[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f2 v = k4 * splat(ctr[j]);
+      v = pk_fma(k3, splat(p1[j]), v);
+      v = pk_fma(k2, splat(p2[j]), v);
+      v = pk_fma(k1, splat(p3[j]), v);
+      v = pk_fma(k0, splat(p4[j]), v);
+      e[4 + j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      e[j] = dpp_prev2(e[4 + j]);
+      e[8 + j] = dpp_next2(e[4 + j]);
+    }
+    f2 L[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = 4 + j;
+      f2 v = k4 * e[m];
+      v = pk_fma(k3, e[m - 1] + e[m + 1], v);
+      v = pk_fma(k2, e[m - 2] + e[m + 2], v);
+      v = pk_fma(k1, e[m - 3] + e[m + 3], v);
+      v = pk_fma(k0, e[m - 4] + e[m + 4], v);
+      L[j] = v;
+    }
+    if (q > 0) D[2 * q - 1] = f4{prev_hi[0] - L[0].x, prev_hi[1] - L[1].x, prev_hi[2] - L[2].x, prev_hi[3] - L[3].x};
+    if (2 * q < kNumDog) D[2 * q] = f4{L[0].x - L[0].y, L[1].x - L[1].y, L[2].x - L[2].y, L[3].x - L[3].y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) prev_hi[j] = L[j].y;
+  }
+}
+
+// refinement of one candidate from the LDS cube [plane c-1,c,c+1][row y-1,y,y+1][kCubeCols]; `col` is the
+// candidate's column inside the wave's strip.  Arithmetic: refine_and_append / oracle_find_points_multi.
+__device__ __forceinline__ void refine_from_cube(const float *cube, int col, int x, int y, int s, const FindParams &P,
+                                                 cusift_point *__restrict__ pts, int max_pts, unsigned int *counter) {
+  constexpr int RS = kCubeCols, PS = 3 * kCubeCols;
+  const float *d1 = cube + PS + RS + col;  // centre plane, centre row
+  const float val = d1[0];
+  const float dxx = 2.0f * val - d1[-1] - d1[1];
+  const float dyy = 2.0f * val - d1[-RS] - d1[RS];
+  const float dxy = 0.25f * (d1[RS + 1] + d1[-RS - 1] - d1[-RS + 1] - d1[RS - 1]);
+  const float tra = dxx + dyy;
+  const float det = dxx * dyy - dxy * dxy;
+  if (!(tra * tra < P.edge_limit * det)) return;
+  const float edge = (tra * tra) / det;
+  const float dx = 0.5f * (d1[1] - d1[-1]);
+  const float dy = 0.5f * (d1[RS] - d1[-RS]);
+  const float *d0 = d1 - PS;
+  const float *d2 = d1 + PS;
+  const float ds = 0.5f * (d0[0] - d2[0]);
+  const float dss = 2.0f * val - d2[0] - d0[0];
+  const float dxs = 0.25f * (d2[1] + d0[-1] - d0[1] - d2[-1]);
+  const float dys = 0.25f * (d2[RS] + d0[-RS] - d2[-RS] - d0[RS]);
+  const float idxx = dyy * dss - dys * dys;
+  const float idxy = dys * dxs - dxy * dss;
+  const float idxs = dxy * dys - dyy * dxs;
+  const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
+  const float idyy = dxx * dss - dxs * dxs;
+  const float idys = dxy * dxs - dxx * dys;
+  const float idss = dxx * dyy - dxy * dxy;
+  float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
+  float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
+  float pds = idet * (idxs * dx + idys * dy + idss * ds);
+  if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
+    pdx = dx / dxx;
+    pdy = dy / dyy;
+    pds = ds / dss;
+  }
+  const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+  const unsigned int idx = atomicAdd(counter, 1u);
+  if (idx >= (unsigned int)max_pts) return;
+  cusift_point *pt = pts + idx;
+  pt->coords2D[0] = (float)x + pdx;
+  pt->coords2D[1] = (float)y + pdy;
+  pt->scale = P.scales[s] * exp2f(pds * P.factor);
+  pt->sharpness = val + dval;
+  pt->edgeness = edge;
+  pt->subsampling = P.subsampling;
+}
+
+__global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
+                                                          long img_stride, cusift_point *__restrict__ points,
+                                                          int max_pts, unsigned int *__restrict__ counters,
+                                                          int rows_per_wave, LaplaceTapsPk T, FindParams P) {
+  __shared__ float s_cube[kWavesPerBlock][9 * kCubeCols];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  xcd_remap(bx, by, bz);
+  const int y0 = (by * kWavesPerBlock + wv) * rows_per_wave;
+  const int ya = max(y0, 1), yb = min(y0 + rows_per_wave, h - 1);  // centres [ya, yb)
+  if (ya >= yb) return;                                            // wave-uniform
+  img += (long)bz * img_stride;
+  points += (long)bz * max_pts;
+  unsigned int *counter = counters + bz;
+  float *cube = s_cube[wv];
+
+  const int c0 = bx * kDetStrip - kDetHaloLanes * kBlurCols + lane * kBlurCols;
+  const bool left = c0 < 0, right = c0 >= w;
+  const int voff_in = clampi(c0, 0, w - 4) * 4;
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((unsigned int)h * (unsigned int)pitch * 4u), kBufFlags);
+  const bool lane_valid = lane >= kDetHaloLanes && lane < 64 - kDetHaloLanes;
+
+  auto load_row = [&](int y) -> f4 {
+    const int yc = clampi(y, 0, h - 1);
+    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, yc * pitch * 4, 0);
+    f4 v = __builtin_bit_cast(f4, raw);
+    if (left) v = f4{v.x, v.x, v.x, v.x};
+    if (right) v = f4{v.w, v.w, v.w, v.w};
+    return v;
+  };
+
+  f4 win[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) win[i] = load_row(ya - 1 - 4 + i);
+
+  f4 D0[kNumDog], D1[kNumDog], D2[kNumDog];  // DoG rows yy-2, yy-1, yy
+#pragma unroll
+  for (int p = 0; p < kNumDog; ++p) D0[p] = D1[p] = f4{0.f, 0.f, 0.f, 0.f};
+
+  for (int yy = ya - 1; yy <= yb; ++yy) {
+    const f4 nxt = load_row(yy + 5);
+    blur_dog_row(win, T, D2);
+
+    if (yy >= ya + 1) {
+      const int y = yy - 1;  // centre row: D0 = y-1, D1 = y, D2 = y+1
+      // per plane: 3-row column min/max, then the 3x3 min/max (h*) and the left/right neighbours' columns
+      f4 hmn[kNumDog], hmx[kNumDog];
+      f4 lmn[kNumScales], rmn[kNumScales], lmx[kNumScales], rmx[kNumScales];  // for the 5 centre planes 1..5
+#pragma unroll
+      for (int p = 0; p < kNumDog; ++p) {
+        f4 cmn, cmx, l_mn, r_mn, l_mx, r_mx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cmn[j] = min3f(D0[p][j], D1[p][j], D2[p][j]);
+          cmx[j] = max3f(D0[p][j], D1[p][j], D2[p][j]);
+        }
+        l_mn = f4{from_prev_lane(cmn[3]), cmn[0], cmn[1], cmn[2]};
+        r_mn = f4{cmn[1], cmn[2], cmn[3], from_next_lane(cmn[0])};
+        l_mx = f4{from_prev_lane(cmx[3]), cmx[0], cmx[1], cmx[2]};
+        r_mx = f4{cmx[1], cmx[2], cmx[3], from_next_lane(cmx[0])};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hmn[p][j] = min3f(l_mn[j], cmn[j], r_mn[j]);
+          hmx[p][j] = max3f(l_mx[j], cmx[j], r_mx[j]);
+        }
+        if (p >= 1 && p <= kNumScales) {
+          lmn[p - 1] = l_mn;
+          rmn[p - 1] = r_mn;
+          lmx[p - 1] = l_mx;
+          rmx[p - 1] = r_mx;
+        }
+      }
+      unsigned int cand = 0;  // bit (4*s + j)
+#pragma unroll
+      for (int s = 0; s < kNumScales; ++s) {
+        const int c = s + 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = D1[c][j];
+          const float mn_a = min3f(lmn[s][j], rmn[s][j], D0[c][j]);
+          const float mn_b = min3f(D2[c][j], hmn[c - 1][j], hmn[c + 1][j]);
+          const float mx_a = max3f(lmx[s][j], rmx[s][j], D0[c][j]);
+          const float mx_b = max3f(D2[c][j], hmx[c - 1][j], hmx[c + 1][j]);
+          const bool hit = (v < P.thr_neg && v < mn_a && v < mn_b) || (v > P.thr_pos && v > mx_a && v > mx_b);
+          cand |= (hit ? 1u : 0u) << (4 * s + j);
+        }
+      }
+      if (!lane_valid) cand = 0;
+      // border pixels are never extrema in the reference (clamped neighbour == centre)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < 1 || c0 + j > w - 2) cand &= ~(0x11111u << j);
+      if (__builtin_amdgcn_ballot_w64(cand != 0) != 0) {  // wave-uniform, rare
+#pragma unroll 1
+        for (int s = 0; s < kNumScales; ++s) {
+          const unsigned int m = (cand >> (4 * s)) & 0xfu;
+          if (__builtin_amdgcn_ballot_w64(m != 0) == 0) continue;  // wave-uniform
+          // dump planes s, s+1, s+2 x rows y-1, y, y+1 of the whole strip into the wave's LDS cube
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) {
+            f4 r0, r1, r2;
+            // static plane selection (s is a loop variable): select among the 5 possible triples
+            switch (s) {
+              case 0: r0 = D0[0 + pp]; r1 = D1[0 + pp]; r2 = D2[0 + pp]; break;
+              case 1: r0 = D0[1 + pp]; r1 = D1[1 + pp]; r2 = D2[1 + pp]; break;
+              case 2: r0 = D0[2 + pp]; r1 = D1[2 + pp]; r2 = D2[2 + pp]; break;
+              case 3: r0 = D0[3 + pp]; r1 = D1[3 + pp]; r2 = D2[3 + pp]; break;
+              default: r0 = D0[4 + pp]; r1 = D1[4 + pp]; r2 = D2[4 + pp]; break;
+            }
+            float *dst = cube + (pp * 3) * kCubeCols + lane * 4;
+            *reinterpret_cast<f4 *>(dst) = r0;
+            *reinterpret_cast<f4 *>(dst + kCubeCols) = r1;
+            *reinterpret_cast<f4 *>(dst + 2 * kCubeCols) = r2;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (int j = 0; j < 4; ++j)
+            if (m & (1u << j)) refine_from_cube(cube, lane * 4 + j, c0 + j, y, s, P, points, max_pts, counter);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kNumDog; ++p) {
+      D0[p] = D1[p];
+      D1[p] = D2[p];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
+    win[8] = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Software model of the CUDA texture fetch the reference relies on (gfx950 has no image unit):
 // tex2D<float>(x, y), cudaFilterModeLinear, clamp, unnormalised coordinates (cuSIFT.cu:227-233).
 // xB = x - 0.5, i = floor(xB), alpha = frac(xB) rounded to `frac_bits` bits.  Same operation order

@@ -67,6 +67,8 @@ typedef struct cusift_params {
   float subsampling;   /* Extract(..., float subsampling = 1.0f) */
   int max_pts;         /* capacity per image (SiftData::maxPts) */
   int tex_frac_bits;   /* bilinear fraction bits of the texture-unit model: 8 = as the reference ran, 0 = fp32 */
+  int fused_detect;    /* 1 (default): the drivers run LaplaceMulti+FindPointsMulti as one kernel that keeps the
+                          DoG planes on chip (identical results); 0: the two reference stages, DoG in HBM */
 } cusift_params;
 
 typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */
@@ -93,10 +95,11 @@ int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift
 size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
 /* Per-stage GPU timing with HIP events on the context's stream (TimerGPU, cutils.h:94-114, used at
  * cuSIFT.cu:64,177,208,238,249).  Stages: 0 ScaleDown, 1 LaplaceMulti, 2 FindPointsMulti,
- * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call.  Accumulates
+ * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call, 6 fused detection.  Accumulates
  * milliseconds and launch counts until reset.  cusift_ctx_timing_read blocks. */
 enum { CUSIFT_STAGE_SCALEDOWN = 0, CUSIFT_STAGE_LAPLACE = 1, CUSIFT_STAGE_FINDPOINTS = 2,
-       CUSIFT_STAGE_ORIENT = 3, CUSIFT_STAGE_DESCR = 4, CUSIFT_STAGE_TOTAL = 5, CUSIFT_NUM_STAGES = 6 };
+       CUSIFT_STAGE_ORIENT = 3, CUSIFT_STAGE_DESCR = 4, CUSIFT_STAGE_TOTAL = 5, CUSIFT_STAGE_DETECT = 6,
+       CUSIFT_NUM_STAGES = 7 };
 int cusift_ctx_timing_enable(cusift_ctx *ctx, int on);
 int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGES], int launches[CUSIFT_NUM_STAGES]);
 int cusift_ctx_timing_reset(cusift_ctx *ctx);
@@ -133,6 +136,13 @@ int cusift_laplace_taps(float init_blur, float taps[8 * 16]);
 int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int w, int h, int pitch, size_t dog_stride,
                              float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points,
                              int max_pts, unsigned int *d_counters, int n_images);
+/* LaplaceMulti + FindPointsMulti fused (cuSIFT.cu:239-247 calls them back to back): same results as the two
+ * stages above, but the 7 DoG planes stay in registers -- no DoG buffer, 4 B/px of HBM traffic instead of 60.
+ * Needs 16-byte aligned rows (pitch % 4 == 0), w % 4 == 0 and an image < 2 GiB; returns CUSIFT_ERR_INVALID
+ * otherwise (the drivers then fall back to the two-stage path). */
+int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                        float init_blur, float peak_thresh, float edge_thresh, float subsampling,
+                        cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images);
 /* SiftData::ComputeOrientations, cuSIFT.cu:355-365 + ComputeOrientations_D cuSIFT_D.cu:319-396.
  * Processes points [d_first[i], min(d_counters[i], max_pts)) of every image; d_first may be NULL (= 0). */
 int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,

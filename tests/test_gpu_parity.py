@@ -187,6 +187,59 @@ def test_find_points_overflow_is_dropped_not_written(ctx, oracle, gray1):
 
 
 # ------------------------------------------------------------------------------------------------
+# Fused detection (LaplaceMulti + FindPointsMulti in one kernel, DoG never stored)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,blur,thresh", [(640, 480, 0.0, 0.1), (320, 240, 0.559017, 0.1), (244, 37, 0.0, 0.5),
+                                             (1920, 1080, 1.0, 3.0), (8, 5, 0.0, 0.01), (4, 3, 0.0, 0.01),
+                                             (480, 9, 0.3, 0.2)])
+def test_detect_multi_same_set_as_oracle(ctx, oracle, gray1, w, h, blur, thresh):
+    if (w, h) == (640, 480):
+        img = gray1
+    elif (w, h) == (320, 240):
+        img = gray1[::2, ::2].copy()
+    elif (w, h) == (1920, 1080):
+        img = synth.tile(1003, preblur=1.0)
+    else:
+        img = rand_image(h, w, w + 5 * h)
+    src = pitched(img)
+    dog = oracle.laplace_multi(src, w, h, blur)
+    max_pts = 32768
+    want, n_want = oracle.find_points_multi(dog, w, h, thresh, 10.0, 4.0, max_pts)
+    d_img = DeviceBuffer.from_numpy(ctx, src)
+    d_pts = DeviceBuffer(ctx, max_pts * 588)
+    d_pts.zero()
+    d_cnt = DeviceBuffer(ctx, 4)
+    d_cnt.zero()
+    ctx.detect_multi(d_img.ptr, w, h, src.shape[1], blur, thresh, 10.0, 4.0, d_pts.ptr, max_pts, d_cnt.ptr)
+    n_got = int(d_cnt.to_numpy(np.uint32, (1,))[0])
+    got = d_pts.to_numpy(SIFT_POINT_DTYPE, (max_pts,))
+    assert n_got == n_want
+    a, b = canonical_order(want[:n_want]), canonical_order(got[:n_got])
+    np.testing.assert_array_equal(a["coords2D"], b["coords2D"])
+    np.testing.assert_array_equal(a["sharpness"], b["sharpness"])
+    np.testing.assert_array_equal(a["edgeness"], b["edgeness"])
+    np.testing.assert_allclose(a["scale"], b["scale"], rtol=1e-6, atol=0)
+
+
+def test_detect_multi_rejects_what_it_cannot_do(ctx):
+    d = DeviceBuffer(ctx, 1 << 16)
+    with pytest.raises(capi.CusiftError, match="aligned"):
+        ctx.detect_multi(d.ptr, 30, 20, 31, 0.0, 1.0, 10.0, 1.0, d.ptr, 16, d.ptr)  # odd pitch, w % 4 != 0
+
+
+def test_two_stage_and_fused_drivers_agree(ctx, gray1):
+    """cusift_params.fused_detect selects the pipeline; both must give the same SiftData (as sets)."""
+    res = []
+    for fused in (1, 0):
+        got = gpu_extract(ctx, gray1, fused_detect=fused, **REF_PARAMS)
+        res.append(canonical_order(got))
+    assert len(res[0]) == len(res[1]) == 9508
+    np.testing.assert_array_equal(res[0]["coords2D"], res[1]["coords2D"])
+    np.testing.assert_array_equal(res[0]["orientation"], res[1]["orientation"])
+    np.testing.assert_array_equal(res[0]["data"], res[1]["data"])
+
+
+# ------------------------------------------------------------------------------------------------
 # ComputeOrientations / ExtractSiftDescriptors on identical keypoints
 # ------------------------------------------------------------------------------------------------
 def oracle_octave_points(oracle, img, w, h, blur, thresh, sub, max_pts=16384):
@@ -471,16 +524,21 @@ def test_full_size_batch_properties(ctx):
 
 
 def test_stage_timers_report_every_stage(ctx, gray1):
-    prm = capi.default_params(num_octaves=3, peak_thresh=1.0, max_pts=4096)
-    d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    ctx.extract_host(gray1, prm, d_pts.ptr, None)
-    t = ctx.timing_read()
-    ctx.timing_enable(False)
-    assert t["scale_down"][1] == 2 and t["laplace_multi"][1] == 3 and t["find_points_multi"][1] == 3
-    assert t["total"][1] == 1 and t["total"][0] > 0
-    assert all(ms >= 0 for ms, _ in t.values())
+    d_pts = DeviceBuffer(ctx, 4096 * 588)
+    for fused in (1, 0):
+        prm = capi.default_params(num_octaves=3, peak_thresh=1.0, max_pts=4096, fused_detect=fused)
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        ctx.extract_host(gray1, prm, d_pts.ptr, None)
+        t = ctx.timing_read()
+        ctx.timing_enable(False)
+        assert t["scale_down"][1] == 2 and t["compute_orientations"][1] == 3 and t["extract_descriptors"][1] == 3
+        if fused:
+            assert t["detect_multi"][1] == 3 and t["laplace_multi"][1] == 0 and t["find_points_multi"][1] == 0
+        else:
+            assert t["detect_multi"][1] == 0 and t["laplace_multi"][1] == 3 and t["find_points_multi"][1] == 3
+        assert t["total"][1] == 1 and t["total"][0] > 0
+        assert all(ms >= 0 for ms, _ in t.values())
 
 
 def test_errors_are_reported_not_fatal(ctx):
