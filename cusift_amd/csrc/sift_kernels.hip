@@ -21,13 +21,14 @@ namespace cusift {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// lane i receives the value of lane i-1 (lane 0 receives 0): DPP wave_shr:1
+// lane i receives the value of lane i-1 (lane 0 receives 0): DPP wave_shr:1.  bound_ctrl makes the hardware
+// write 0 for the lane without a source, so no "old" value has to be materialised in front of every DPP move.
 __device__ __forceinline__ float from_prev_lane(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 // lane i receives the value of lane i+1 (lane 63 receives 0): DPP wave_shl:1
 __device__ __forceinline__ float from_next_lane(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // XCD-aware work mapping.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
         const float mn_b = min3f(r2[c][j], hmn[c - 1][j], hmn[c + 1][j]);
         const float mx_a = max3f(nl_mx, nr_mx, r0[c][j]);
         const float mx_b = max3f(r2[c][j], hmx[c - 1][j], hmx[c + 1][j]);
-        const bool hit = (v < P.thr_neg && v < mn_a && v < mn_b) || (v > P.thr_pos && v > mx_a && v > mx_b);
+        const bool hit = (v < min3f(mn_a, mn_b, P.thr_neg)) || (v > max3f(mx_a, mx_b, P.thr_pos));
         cand |= (hit ? 1u : 0u) << (2 * s + j);
       }
     }
@@ -739,11 +740,13 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
 #pragma unroll
   for (int i = 0; i < 9; ++i) win[i] = load_row(ya - 1 - 4 + i);
 
-  f4 D0[kNumDog], D1[kNumDog], D2[kNumDog];  // DoG rows yy-2, yy-1, yy
+  // DoG rows yy-2, yy-1, yy live in three register sets whose roles rotate; the row loop is unrolled by
+  // three so the rotation costs no moves.
+  f4 DA[kNumDog], DB[kNumDog], DC[kNumDog];
 #pragma unroll
-  for (int p = 0; p < kNumDog; ++p) D0[p] = D1[p] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < kNumDog; ++p) DA[p] = DB[p] = DC[p] = f4{0.f, 0.f, 0.f, 0.f};
 
-  for (int yy = ya - 1; yy <= yb; ++yy) {
+  auto row_step = [&](int yy, f4 (&D0)[kNumDog], f4 (&D1)[kNumDog], f4 (&D2)[kNumDog]) {
     const f4 nxt = load_row(yy + 5);
     blur_dog_row(win, T, D2);
 
@@ -783,11 +786,12 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float v = D1[c][j];
+          // v < thr_neg && v < every neighbour  <=>  v < min(thr_neg, neighbours): three 3-input trees, one compare
           const float mn_a = min3f(lmn[s][j], rmn[s][j], D0[c][j]);
           const float mn_b = min3f(D2[c][j], hmn[c - 1][j], hmn[c + 1][j]);
           const float mx_a = max3f(lmx[s][j], rmx[s][j], D0[c][j]);
           const float mx_b = max3f(D2[c][j], hmx[c - 1][j], hmx[c + 1][j]);
-          const bool hit = (v < P.thr_neg && v < mn_a && v < mn_b) || (v > P.thr_pos && v > mx_a && v > mx_b);
+          const bool hit = (v < min3f(mn_a, mn_b, P.thr_neg)) || (v > max3f(mx_a, mx_b, P.thr_pos));
           cand |= (hit ? 1u : 0u) << (4 * s + j);
         }
       }
@@ -828,13 +832,16 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
       }
     }
 #pragma unroll
-    for (int p = 0; p < kNumDog; ++p) {
-      D0[p] = D1[p];
-      D1[p] = D2[p];
-    }
-#pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
     win[8] = nxt;
+  };
+
+  for (int yy = ya - 1; yy <= yb; yy += 3) {
+    row_step(yy, DA, DB, DC);
+    if (yy + 1 > yb) break;
+    row_step(yy + 1, DB, DC, DA);
+    if (yy + 2 > yb) break;
+    row_step(yy + 2, DC, DA, DB);
   }
 }
 

@@ -63,7 +63,7 @@ def main():
             v = per_kernel[k][c]
             lines.append("    %-26s n=%-4d mean=%.4g  max=%.4g" % (c, len(v), sum(v) / len(v), max(v)))
     out_json = {}
-    for kern in ("laplace_multi_kernel", "find_points_kernel", "scale_down_kernel", "descriptors_kernel",
+    for kern in ("laplace_multi_fast_kernel", "find_points_fast_kernel", "detect_fused_kernel", "scale_down_kernel", "descriptors_kernel",
                  "orientations_kernel"):
         biggest = {}
         for (pas, disp), info in per_dispatch.items():
@@ -101,7 +101,7 @@ def main():
                 tot[info["kernel"]][c] += info[c]
                 cnt[info["kernel"]][c] += 1
     lines.append("")
-    for kern in ("laplace_multi_kernel", "find_points_kernel"):
+    for kern in ("laplace_multi_fast_kernel", "find_points_fast_kernel", "detect_fused_kernel"):
         if cnt[kern]["FETCH_SIZE"] and cnt[kern]["WRITE_SIZE"]:
             n = cnt[kern]["FETCH_SIZE"]
             per_launch = (2 * tot[kern]["FETCH_SIZE"] / n + tot[kern]["WRITE_SIZE"] / cnt[kern]["WRITE_SIZE"]) * 1024
