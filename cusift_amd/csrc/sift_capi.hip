@@ -18,6 +18,7 @@
 namespace cusift {
 // kernels (sift_kernels.hip)
 __global__ void scale_down_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
+__global__ void scale_down_fast_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
 __global__ void laplace_multi_kernel(const float *, float *, int, int, int, long, long, int, int, LaplaceTaps);
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
@@ -507,12 +508,24 @@ extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, s
     return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
   ScaleDownTaps T;
   scale_down_taps(T, variance);
-  const int strips = idiv_up(ow, 64);
-  const int rows = pick_rows(oh, strips, n_images, 4, 16);
-  dim3 grid(strips, idiv_up(idiv_up(oh, rows), kWavesPerBlock), n_images);
+  const bool fast = (w % 4 == 0) && w >= 4 && (src_pitch % 4 == 0) && (((uintptr_t)d_src % 16) == 0) &&
+                    (src_stride % 4 == 0) && (dst_pitch % 2 == 0) && (((uintptr_t)d_dst % 8) == 0) &&
+                    (dst_stride % 2 == 0) && ((size_t)h * src_pitch * sizeof(float) < (1ull << 31)) &&
+                    !getenv("CUSIFT_FORCE_GENERIC");
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
-  hipLaunchKernelGGL(scale_down_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride, d_src, w,
-                     h, src_pitch, (long)src_stride, rows, T);
+  if (fast) {
+    const int strips = idiv_up(ow, 124);  // kDownStrip
+    const int rows = pick_rows(oh, strips, n_images, 4, 32);
+    dim3 grid(idiv_up(strips, kWavesPerBlock), idiv_up(oh, rows), n_images);
+    hipLaunchKernelGGL(scale_down_fast_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride,
+                       d_src, w, h, src_pitch, (long)src_stride, rows, T);
+  } else {
+    const int strips = idiv_up(ow, 64);
+    const int rows = pick_rows(oh, strips, n_images, 4, 16);
+    dim3 grid(strips, idiv_up(idiv_up(oh, rows), kWavesPerBlock), n_images);
+    hipLaunchKernelGGL(scale_down_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride, d_src,
+                       w, h, src_pitch, (long)src_stride, rows, T);
+  }
   return check_launch("scale_down");
 }
 

@@ -320,6 +320,84 @@ __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
+// ScaleDown, fast path (16-byte aligned source rows, w % 4 == 0, 8-byte aligned destination rows).
+// Same arithmetic as scale_down_kernel.  A lane loads source columns 4l..4l+3 as one float4 (1 KiB per wave
+// row), takes columns 4l-2, 4l-1 and 4l+4 from its neighbours by DPP and produces two output columns
+// (one float2 store); the five horizontally filtered rows 2r-1..2r+3 slide through registers.
+// Lanes 0 and 63 are halo: 62 lanes x 2 = 124 output columns per wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDownStrip = 62 * 2;  // output columns per wave
+
+__global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict__ dst, int dst_pitch, long dst_stride,
+                                                             const float *__restrict__ src, int w, int h,
+                                                             int src_pitch, long src_stride, int rows_per_wave,
+                                                             ScaleDownTaps T) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  xcd_remap(bx, by, bz);
+  const int ow = w >> 1, oh = h >> 1;
+  // the 4 waves of a block take 4 horizontally adjacent strips (their shared 128-byte lines meet in L1/L2)
+  const int strip = bx * kWavesPerBlock + wv;
+  const int r0 = by * rows_per_wave;
+  if (strip * kDownStrip >= ow || r0 >= oh) return;  // wave-uniform
+  const int r1 = min(r0 + rows_per_wave, oh);
+  src += (long)bz * src_stride;
+  dst += (long)bz * dst_stride;
+
+  const int cs = strip * (2 * kDownStrip) - 4 + lane * 4;  // first source column of this lane's float4
+  const bool left = cs < 0, right = cs >= w;
+  const int voff_in = clampi(cs, 0, w - 4) * 4;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)src, 0, (int)((unsigned int)h * (unsigned int)src_pitch * 4u), kBufFlags);
+  const int o0 = cs >> 1;  // first output column (even)
+  const int voff_out = (lane >= 1 && lane <= 62 && cs >= 0) ? o0 * 4 : kOobOffset;  // o0 >= ow dropped by num_records
+  const float k0 = T.k[0], k1 = T.k[1], k2 = T.k[2];
+
+  auto load_row = [&](int y) -> f4 {
+    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, clampi(y, 0, h - 1) * src_pitch * 4, 0);
+    f4 v = __builtin_bit_cast(f4, raw);
+    if (left) v = f4{v.x, v.x, v.x, v.x};
+    if (right) v = f4{v.w, v.w, v.w, v.w};
+    return v;
+  };
+  // horizontal 5-tap of one source row for output columns o0 (centre 4l) and o0+1 (centre 4l+2)
+  auto hrow = [&](const f4 v) -> f2 {
+    const float m2 = from_prev_lane(v.z), m1 = from_prev_lane(v.w), p4 = from_next_lane(v.x);
+    float a = k0 * (m2 + v.z);
+    a = fmaf(k1, m1 + v.y, a);
+    a = fmaf(k2, v.x, a);
+    float b = k0 * (v.x + p4);
+    b = fmaf(k1, v.y + v.w, b);
+    b = fmaf(k2, v.z, b);
+    return f2{a, b};
+  };
+
+  f2 bm1 = hrow(load_row(2 * r0 - 1)), b0 = hrow(load_row(2 * r0)), bp1 = hrow(load_row(2 * r0 + 1));
+  f4 n2 = load_row(2 * r0 + 2), n3 = load_row(2 * r0 + 3);
+  for (int r = r0; r < r1; ++r) {
+    const f4 s2 = n2, s3 = n3;
+    n2 = load_row(2 * r + 4);  // next iteration's rows, requested now
+    n3 = load_row(2 * r + 5);
+    const f2 bp2 = hrow(s2), bp3 = hrow(s3);
+    f2 v;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float t = k2 * b0[j];
+      t = fmaf(k0, bp3[j] + bp2[j], t);
+      t = fmaf(k1, bm1[j] + bp1[j], t);
+      v[j] = t;
+    }
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(dst + (long)r * dst_pitch), 0, ow * 4, kBufFlags);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), ro, voff_out, 0, 0);
+    bm1 = bp1;
+    b0 = bp2;
+    bp1 = bp3;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FindPointsMulti: 26-neighbour DoG extrema for the 5 searchable scales, edge test, 3-D quadratic
 // refinement and append.  Reference: FindPointsMulti_D, cuSIFT_D.cu:402-523.
 //

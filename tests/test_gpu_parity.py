@@ -34,7 +34,8 @@ def rand_image(h, w, seed):
 # ------------------------------------------------------------------------------------------------
 # ScaleDown
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("w,h", [(640, 480), (101, 77), (130, 64), (2, 2), (7, 9), (1920, 1080), (256, 17)])
+@pytest.mark.parametrize("w,h", [(640, 480), (101, 77), (130, 64), (2, 2), (7, 9), (1920, 1080), (256, 17), (4, 4),
+                                 (248, 6), (252, 31), (500, 3), (960, 540), (120, 67)])
 def test_scale_down_bit_exact(ctx, oracle, gray1, w, h):
     img = gray1 if (w, h) == (640, 480) else rand_image(h, w, w * 131 + h)
     src = pitched(img)
