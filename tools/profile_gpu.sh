@@ -2,25 +2,20 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the benchmark.
 # Usage: tools/profile_gpu.sh <tag> [bench args...]
 # Results land under gpurun_out/<tag>/ ; tools/summarize_profile.py condenses them into profiles/.
+# PMC passes use --kernel-trace only (never combined with sys/hip/hsa tracing).
 set -u
 TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
+cd /tmp 2>/dev/null && cd - >/dev/null
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 5 --warmup 2 --cpu-seconds 0 $*"
-echo "== plain bench ==" 
-python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 2500 "$OUT/bench.json"
-echo "== kernel trace =="
+BENCH_ARGS="--steps 5 --warmup 2 --cpu-seconds 0 --no-two-stage $*"
+echo "bench args: $BENCH_ARGS" > "$OUT/command.txt"
+python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/trace.log" 2>&1
-echo "== pmc SQ =="
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq.log" 2>&1
-echo "== pmc SQ2 =="
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq2.log" 2>&1
-echo "== pmc FETCH =="
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1
-echo "== pmc WRITE =="
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_write.log" 2>&1
-echo "== pmc TCC =="
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_tcc.log" 2>&1
-find "$OUT" -name "*.csv" | head -40
 du -sh "$OUT"
