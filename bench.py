@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--two-stage", action="store_true",
                     help="time the reference's two-stage pipeline (DoG planes in HBM) instead of the fused detection")
     ap.add_argument("--no-two-stage", action="store_true", help="skip the roofline exhibit leg")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the all-gatherv of SiftData even with one rank (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -132,14 +134,17 @@ def main():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     w, h, B = args.width, args.height, args.batch
     prm_kw = dict(num_octaves=args.octaves, init_blur=args.init_blur, peak_thresh=args.thresh, edge_thresh=10.0,
                   lowest_scale=0.0, subsampling=1.0, max_pts=args.max_pts, tex_frac_bits=8)
-    ex = BatchExtractor(B, w, h, fused_detect=0 if args.two_stage else 1, **prm_kw)
+    ex = BatchExtractor(B, w, h, n_slots=2 if use_dist else 1, fused_detect=0 if args.two_stage else 1, **prm_kw)
 
     # ---- synthetic inputs, resident in HBM before anything is timed ----
     from concurrent.futures import ThreadPoolExecutor
@@ -150,14 +155,39 @@ def main():
     d_imgs = ex.images_from_numpy(np.stack(host))
     del host
 
+    # N > 1: the all-gatherv of step i runs on a side stream while step i+1 is extracted on the main stream
+    # (two output slots); its one host read-back (the counts) then waits only for the side stream.
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream() if use_dist else None
+    pending = []
+    state = {"i": 0, "gathered": None}
+
+    def finish_one():
+        pts, cnt, ev = pending.pop(0)
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(ev)
+            state["gathered"] = allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather)
+
     def step():
-        pts, cnt = ex.extract(d_imgs)
-        if world > 1:
-            return allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather)
-        return None
+        slot = state["i"] % len(ex.slots)
+        state["i"] += 1
+        pts, cnt = ex.extract(d_imgs, slot=slot)
+        if use_dist:
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
+            pending.append((pts, cnt, ev))
+            if len(pending) > 1:
+                finish_one()
+
+    def drain():
+        while pending:
+            finish_one()
+        if use_dist:
+            main_stream.wait_stream(side_stream)
 
     def fence():
-        if world > 1:
+        drain()
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,9 +199,10 @@ def main():
         ex.ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gathered = step()
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    gathered = state["gathered"]
     stage = ex.ctx.timing_read() if not args.no_stage_timers else None
     ex.ctx.timing_enable(False)
 
@@ -197,14 +228,14 @@ def main():
 
     # max over ranks
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
     counts = ex.valid_counts()
     local_kp = int(counts.sum().item())
     kp = torch.tensor([local_kp], dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
         total_gathered = int(gathered[2][-1])
         assert total_gathered == int(kp.item()), (total_gathered, int(kp.item()))
@@ -232,7 +263,7 @@ def main():
                             "%d octaves, initBlur=%.1f, thresh=%.1f, edge=10, maxPts=%d; full SIFT extraction "
                             "(pyramid+DoG, extrema, orientation, 128-D descriptor)%s"
                             % (B, w, h, world, args.octaves, args.init_blur, args.thresh, args.max_pts,
-                               "; + all-gatherv of SiftData (%s)" % args.gather if world > 1 else ""),
+                               "; + all-gatherv of SiftData (%s)" % args.gather if use_dist else ""),
                 "images_per_gpu": B,
                 "parallelism": "image-sharded x%d" % world,
             },
@@ -308,12 +339,13 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             cpu_kw = dict(prm_kw)
             out["cpu_baseline"] = cpu_baseline(w, h, cpu_kw, args.init_blur, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-
     ex.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ class BatchExtractor:
         counts  int32  [n]                 raw counters; valid points = min(count, max_pts)
     """
 
-    def __init__(self, n_images, w, h, params=None, device=None, pitch=None, **param_overrides):
+    def __init__(self, n_images, w, h, params=None, device=None, pitch=None, n_slots=1, **param_overrides):
         if not torch.cuda.is_available():
             raise capi.CusiftError("BatchExtractor needs a GPU (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -30,9 +30,12 @@ class BatchExtractor:
             self.stream = torch.cuda.current_stream()
             self.ctx = capi.Context(self.device.index, stream=self.stream.cuda_stream)
             self.ctx.reserve(self.n, self.w, self.h, self.params)
-            self.points = torch.zeros((self.n, self.max_pts, capi.SIFT_POINT_BYTES), dtype=torch.uint8,
-                                      device=self.device)
-            self.counts = torch.zeros((self.n,), dtype=torch.int32, device=self.device)
+            # n_slots > 1: output ring, so that a consumer (D2H copy, all-gatherv on another stream) can still
+            # read step i's SiftData while step i+1 is being extracted
+            self.slots = [(torch.zeros((self.n, self.max_pts, capi.SIFT_POINT_BYTES), dtype=torch.uint8,
+                                       device=self.device),
+                           torch.zeros((self.n,), dtype=torch.int32, device=self.device)) for _ in range(n_slots)]
+            self.points, self.counts = self.slots[0]
 
     def images_from_numpy(self, imgs):
         """(n, h, w) float32 host array -> pitched device tensor (n, h, pitch)."""
@@ -42,9 +45,10 @@ class BatchExtractor:
         dev[:, :, : self.w] = torch.from_numpy(imgs).to(self.device)
         return dev
 
-    def extract(self, d_imgs):
+    def extract(self, d_imgs, slot=0):
         assert d_imgs.is_cuda and d_imgs.dtype == torch.float32 and d_imgs.is_contiguous()
         assert tuple(d_imgs.shape) == (self.n, self.h, self.pitch), tuple(d_imgs.shape)
+        self.points, self.counts = self.slots[slot]
         self.ctx.extract_batch(d_imgs.data_ptr(), self.n, self.w, self.h, self.pitch, self.h * self.pitch,
                                self.params, self.points.data_ptr(), self.counts.data_ptr())
         return self.points, self.counts
