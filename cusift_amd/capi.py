@@ -70,6 +70,7 @@ SIGNATURES = {
     "cusift_init": (_i, [_i]),
     "cusift_default_params": (None, [_PP]),
     "cusift_ctx_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "cusift_ctx_create_borrowed": (_i, [C.POINTER(_vp), _i, _vp]),
     "cusift_ctx_destroy": (_i, [_vp]),
     "cusift_ctx_synchronize": (_i, [_vp]),
     "cusift_ctx_stream": (_vp, [_vp]),
@@ -95,6 +96,9 @@ SIGNATURES = {
     "cusift_compute_orientations": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _i, _i]),
     "cusift_extract_descriptors": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _f, _i, _i]),
     "cusift_rootsift": (_i, [_vp, _vp, _i]),
+    "cusift_scale_down_band": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f]),
+    "cusift_detect_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i, _vp]),
+    "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_extract": (_i, [_vp, _vp, _i, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
     "cusift_extract_host": (_i, [_vp, _vp, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
@@ -152,8 +156,13 @@ class Context:
     """cusift_ctx: one device + one HIP stream + the scratch arena."""
 
     def __init__(self, device=0, stream=None):
+        """stream=None: the context creates its own stream.  stream=<int handle>: borrow that hipStream_t;
+        0 is the device's null stream (torch.cuda.current_stream().cuda_stream is 0 for the default stream)."""
         self._h = C.c_void_p()
-        check(lib().cusift_ctx_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None))
+        if stream is None:
+            check(lib().cusift_ctx_create(C.byref(self._h), device, None))
+        else:
+            check(lib().cusift_ctx_create_borrowed(C.byref(self._h), device, C.c_void_p(int(stream))))
         self.device = device
 
     @property
@@ -258,6 +267,22 @@ class Context:
         img_stride = h * pitch if img_stride is None else img_stride
         check(lib().cusift_extract_descriptors(self.handle, d_img, w, h, pitch, img_stride, d_points, max_pts,
                                                d_first, d_counters, subsampling, tex_frac_bits, n_images))
+
+    # ---- band forms (strip tiling) ----
+    def scale_down_band(self, d_dst, dst_pitch, dst_row0, r_begin, r_end, d_src, w, h_src, src_pitch, src_row0,
+                        h_src_global, variance=0.5):
+        check(lib().cusift_scale_down_band(self.handle, d_dst, dst_pitch, dst_row0, r_begin, r_end, d_src, w, h_src,
+                                           src_pitch, src_row0, h_src_global, variance))
+
+    def detect_band(self, d_img, w, h, pitch, row0, h_global, cy_begin, cy_end, init_blur, peak_thresh, edge_thresh,
+                    subsampling, d_points, max_pts, d_counter):
+        check(lib().cusift_detect_band(self.handle, d_img, w, h, pitch, row0, h_global, cy_begin, cy_end, init_blur,
+                                       peak_thresh, edge_thresh, subsampling, d_points, max_pts, d_counter))
+
+    def describe_band(self, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first, d_counter, subsampling,
+                      tex_frac_bits=8):
+        check(lib().cusift_describe_band(self.handle, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first,
+                                         d_counter, subsampling, tex_frac_bits))
 
     def rootsift(self, d_points, num_pts):
         check(lib().cusift_rootsift(self.handle, d_points, num_pts))

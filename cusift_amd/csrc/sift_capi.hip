@@ -18,19 +18,20 @@
 namespace cusift {
 // kernels (sift_kernels.hip)
 __global__ void scale_down_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
-__global__ void scale_down_fast_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
+__global__ void scale_down_fast_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps,
+                                       RowWindow, int, int, int);
 __global__ void laplace_multi_kernel(const float *, float *, int, int, int, long, long, int, int, LaplaceTaps);
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                         FindParams);
 __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
-                                    LaplaceTapsPk, FindParams);
+                                    LaplaceTapsPk, FindParams, RowWindow, int, int);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
                                    FindParams);
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
-                                    const unsigned int *, float, float);
+                                    const unsigned int *, float, float, RowWindow);
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
-                                   const unsigned int *, float, float, float);
+                                   const unsigned int *, float, float, float, RowWindow);
 __global__ void rootsift_kernel(cusift_point *, int);
 }  // namespace cusift
 
@@ -338,7 +339,7 @@ extern "C" void cusift_default_params(cusift_params *p) {
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
-extern "C" int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream) {
+static int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool borrow) {
   if (!out) return fail(CUSIFT_ERR_INVALID, "out is NULL");
   *out = nullptr;
   int n = 0;
@@ -347,8 +348,8 @@ extern "C" int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream)
   HIP_TRY(hipSetDevice(device));
   cusift_ctx *ctx = new cusift_ctx();
   ctx->device = device;
-  if (hip_stream) {
-    ctx->stream = (hipStream_t)hip_stream;
+  if (borrow) {
+    ctx->stream = (hipStream_t)hip_stream;  // NULL = the null stream
   } else {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -365,6 +366,14 @@ extern "C" int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream)
   }
   *out = ctx;
   return CUSIFT_OK;
+}
+
+extern "C" int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream) {
+  return ctx_create_impl(out, device, hip_stream, hip_stream != nullptr);
+}
+
+extern "C" int cusift_ctx_create_borrowed(cusift_ctx **out, int device, void *hip_stream) {
+  return ctx_create_impl(out, device, hip_stream, true);
 }
 
 extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
@@ -498,12 +507,13 @@ extern "C" int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_sr
 // ------------------------------------------------------------------------------------------------
 // stage entry points
 // ------------------------------------------------------------------------------------------------
-extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
-                                 int w, int h, int src_pitch, size_t src_stride, int n_images, float variance) {
+static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w,
+                           int h, int src_pitch, size_t src_stride, int n_images, float variance, RowWindow src_rw,
+                           int dst_row0, int r_begin, int r_end, bool band) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
   if (!d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "ScaleDown: missing data");  // cuSIFT.cu:315-318
   if (!(variance > 0.0f)) return fail(CUSIFT_ERR_INVALID, "ScaleDown: variance must be > 0");
-  const int ow = w / 2, oh = h / 2;
+  const int ow = w / 2, oh = r_end - r_begin;
   if (n_images < 1 || ow < 1 || oh < 1 || src_pitch < w || dst_pitch < ow)
     return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
   ScaleDownTaps T;
@@ -511,14 +521,16 @@ extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, s
   const bool fast = (w % 4 == 0) && w >= 4 && (src_pitch % 4 == 0) && (((uintptr_t)d_src % 16) == 0) &&
                     (src_stride % 4 == 0) && (dst_pitch % 2 == 0) && (((uintptr_t)d_dst % 8) == 0) &&
                     (dst_stride % 2 == 0) && ((size_t)h * src_pitch * sizeof(float) < (1ull << 31)) &&
-                    !getenv("CUSIFT_FORCE_GENERIC");
+                    (band || !getenv("CUSIFT_FORCE_GENERIC"));
+  if (band && !fast)
+    return fail(CUSIFT_ERR_INVALID, "ScaleDown (band): needs w %% 4 == 0, 16-byte aligned source rows, band < 2 GiB");
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
   if (fast) {
     const int strips = idiv_up(ow, 124);  // kDownStrip
     const int rows = pick_rows(oh, strips, n_images, 4, 32);
     dim3 grid(idiv_up(strips, kWavesPerBlock), idiv_up(oh, rows), n_images);
     hipLaunchKernelGGL(scale_down_fast_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride,
-                       d_src, w, h, src_pitch, (long)src_stride, rows, T);
+                       d_src, w, h, src_pitch, (long)src_stride, rows, T, src_rw, dst_row0, r_begin, r_end);
   } else {
     const int strips = idiv_up(ow, 64);
     const int rows = pick_rows(oh, strips, n_images, 4, 16);
@@ -527,6 +539,23 @@ extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, s
                        w, h, src_pitch, (long)src_stride, rows, T);
   }
   return check_launch("scale_down");
+}
+
+extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
+                                 int w, int h, int src_pitch, size_t src_stride, int n_images, float variance) {
+  if (h / 2 < 1) return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
+  return scale_down_impl(ctx, d_dst, dst_pitch, dst_stride, d_src, w, h, src_pitch, src_stride, n_images, variance,
+                         RowWindow{0, h}, 0, 0, h / 2, false);
+}
+
+extern "C" int cusift_scale_down_band(cusift_ctx *ctx, float *d_dst, int dst_pitch, int dst_row0, int r_begin,
+                                      int r_end, const float *d_src, int w, int h_src, int src_pitch, int src_row0,
+                                      int h_src_global, float variance) {
+  if (h_src < 1 || h_src_global < 2 || src_row0 < 0 || src_row0 + h_src > h_src_global || r_begin < dst_row0 ||
+      r_end <= r_begin || r_end > h_src_global / 2)
+    return fail(CUSIFT_ERR_INVALID, "ScaleDown (band): bad row geometry");
+  return scale_down_impl(ctx, d_dst, dst_pitch, 0, d_src, w, h_src, src_pitch, 0, 1, variance,
+                         RowWindow{src_row0, h_src_global}, dst_row0, r_begin, r_end, true);
 }
 
 extern "C" int cusift_laplace_taps(float init_blur, float taps[8 * 16]) {
@@ -606,9 +635,9 @@ static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t 
          h >= 3 && ((size_t)h * pitch * sizeof(float) < (1ull << 31));
 }
 
-extern "C" int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
-                                   float init_blur, float peak_thresh, float edge_thresh, float subsampling,
-                                   cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images) {
+static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
+                       float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
+                       unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -625,13 +654,30 @@ extern "C" int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, i
     }
   FindParams P;
   find_params(P, peak_thresh, edge_thresh, subsampling);
+  const int rows_total = cy_end - cy_begin;
   const int strips = idiv_up(w, 240);  // kDetStrip
-  const int rows = pick_rows(h, strips, n_images, 8, 32);
-  dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
+  const int rows = pick_rows(rows_total, strips, n_images, 8, 32);
+  dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), kWavesPerBlock), n_images);
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
   hipLaunchKernelGGL(detect_fused_kernel, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
-                     d_points, max_pts, d_counters, rows, TP, P);
+                     d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   return check_launch("detect_multi");
+}
+
+extern "C" int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                                   float init_blur, float peak_thresh, float edge_thresh, float subsampling,
+                                   cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images) {
+  return detect_impl(ctx, d_img, w, h, pitch, img_stride, init_blur, peak_thresh, edge_thresh, subsampling, d_points,
+                     max_pts, d_counters, n_images, RowWindow{0, h}, 0, h);
+}
+
+extern "C" int cusift_detect_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0, int h_global,
+                                  int cy_begin, int cy_end, float init_blur, float peak_thresh, float edge_thresh,
+                                  float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counter) {
+  if (row0 < 0 || h < 1 || row0 + h > h_global || cy_begin < row0 || cy_end > row0 + h || cy_end <= cy_begin)
+    return fail(CUSIFT_ERR_INVALID, "Detect (band): bad row geometry");
+  return detect_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, init_blur, peak_thresh, edge_thresh, subsampling,
+                     d_points, max_pts, d_counter, 1, RowWindow{row0, h_global}, cy_begin, cy_end);
 }
 
 static int keypoint_grid_x(int max_pts, int n_images) {
@@ -640,10 +686,9 @@ static int keypoint_grid_x(int max_pts, int n_images) {
   return std::max(1, std::min(max_pts, std::min(per_image, 4096)));
 }
 
-extern "C" int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch,
-                                           size_t img_stride, cusift_point *d_points, int max_pts,
-                                           const unsigned int *d_first, const unsigned int *d_counters,
-                                           int tex_frac_bits, int n_images) {
+static int orientations_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                             cusift_point *d_points, int max_pts, const unsigned int *d_first,
+                             const unsigned int *d_counters, int tex_frac_bits, int n_images, RowWindow rw) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ComputeOrientations: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -653,14 +698,14 @@ extern "C" int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, 
   dim3 grid(keypoint_grid_x(max_pts, n_images), n_images);
   StageTimer t(ctx, CUSIFT_STAGE_ORIENT);
   hipLaunchKernelGGL(orientations_kernel, grid, dim3(64), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
-                     d_points, max_pts, d_first, d_counters, q, inv_q);
+                     d_points, max_pts, d_first, d_counters, q, inv_q, rw);
   return check_launch("compute_orientations");
 }
 
-extern "C" int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch,
-                                          size_t img_stride, cusift_point *d_points, int max_pts,
-                                          const unsigned int *d_first, const unsigned int *d_counters,
-                                          float subsampling, int tex_frac_bits, int n_images) {
+static int descriptors_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                            cusift_point *d_points, int max_pts, const unsigned int *d_first,
+                            const unsigned int *d_counters, float subsampling, int tex_frac_bits, int n_images,
+                            RowWindow rw) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -670,8 +715,35 @@ extern "C" int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, i
   dim3 grid(keypoint_grid_x(max_pts, n_images), n_images);
   StageTimer t(ctx, CUSIFT_STAGE_DESCR);
   hipLaunchKernelGGL(descriptors_kernel, grid, dim3(64), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
-                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q);
+                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q, rw);
   return check_launch("extract_descriptors");
+}
+
+extern "C" int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch,
+                                           size_t img_stride, cusift_point *d_points, int max_pts,
+                                           const unsigned int *d_first, const unsigned int *d_counters,
+                                           int tex_frac_bits, int n_images) {
+  return orientations_impl(ctx, d_img, w, h, pitch, img_stride, d_points, max_pts, d_first, d_counters, tex_frac_bits,
+                           n_images, RowWindow{0, h});
+}
+
+extern "C" int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch,
+                                          size_t img_stride, cusift_point *d_points, int max_pts,
+                                          const unsigned int *d_first, const unsigned int *d_counters,
+                                          float subsampling, int tex_frac_bits, int n_images) {
+  return descriptors_impl(ctx, d_img, w, h, pitch, img_stride, d_points, max_pts, d_first, d_counters, subsampling,
+                          tex_frac_bits, n_images, RowWindow{0, h});
+}
+
+extern "C" int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0,
+                                    int h_global, cusift_point *d_points, int max_pts, const unsigned int *d_first,
+                                    const unsigned int *d_counter, float subsampling, int tex_frac_bits) {
+  if (row0 < 0 || h < 1 || row0 + h > h_global) return fail(CUSIFT_ERR_INVALID, "Describe (band): bad row geometry");
+  const RowWindow rw{row0, h_global};
+  TRY(orientations_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
+                        tex_frac_bits, 1, rw));
+  return descriptors_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
+                          subsampling, tex_frac_bits, 1, rw);
 }
 
 extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts) {

@@ -20,6 +20,11 @@ namespace cusift {
 // helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// global row -> row of the local band: clamp to the global image (the reference's border rule), translate,
+// then clamp into the band (memory safety only: with enough halo the second clamp never acts)
+__device__ __forceinline__ int local_row(int y_global, int h_local, RowWindow rw) {
+  return clampi(clampi(y_global, 0, rw.hg - 1) - rw.row0, 0, h_local - 1);
+}
 
 // lane i receives the value of lane i-1 (lane 0 receives 0): DPP wave_shr:1.  bound_ctrl makes the hardware
 // write 0 for the lane without a source, so no "old" value has to be materialised in front of every DPP move.
@@ -331,17 +336,20 @@ constexpr int kDownStrip = 62 * 2;  // output columns per wave
 __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict__ dst, int dst_pitch, long dst_stride,
                                                              const float *__restrict__ src, int w, int h,
                                                              int src_pitch, long src_stride, int rows_per_wave,
-                                                             ScaleDownTaps T) {
+                                                             ScaleDownTaps T, RowWindow src_rw, int dst_row0,
+                                                             int r_begin, int r_end) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   xcd_remap(bx, by, bz);
-  const int ow = w >> 1, oh = h >> 1;
+  const int ow = w >> 1;
   // the 4 waves of a block take 4 horizontally adjacent strips (their shared 128-byte lines meet in L1/L2)
   const int strip = bx * kWavesPerBlock + wv;
-  const int r0 = by * rows_per_wave;
-  if (strip * kDownStrip >= ow || r0 >= oh) return;  // wave-uniform
-  const int r1 = min(r0 + rows_per_wave, oh);
+  // output rows are GLOBAL rows [r_begin, r_end) of the half-size image; the destination band starts at
+  // global row dst_row0, the source band is described by src_rw (whole images: {0, h}, 0, 0, h/2)
+  const int r0 = r_begin + by * rows_per_wave;
+  if (strip * kDownStrip >= ow || r0 >= r_end) return;  // wave-uniform
+  const int r1 = min(r0 + rows_per_wave, r_end);
   src += (long)bz * src_stride;
   dst += (long)bz * dst_stride;
 
@@ -355,7 +363,7 @@ __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict_
   const float k0 = T.k[0], k1 = T.k[1], k2 = T.k[2];
 
   auto load_row = [&](int y) -> f4 {
-    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, clampi(y, 0, h - 1) * src_pitch * 4, 0);
+    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, local_row(y, h, src_rw) * src_pitch * 4, 0);
     f4 v = __builtin_bit_cast(f4, raw);
     if (left) v = f4{v.x, v.x, v.x, v.x};
     if (right) v = f4{v.w, v.w, v.w, v.w};
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict_
       v[j] = t;
     }
     const __amdgpu_buffer_rsrc_t ro =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(dst + (long)r * dst_pitch), 0, ow * 4, kBufFlags);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(dst + (long)(r - dst_row0) * dst_pitch), 0, ow * 4, kBufFlags);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), ro, voff_out, 0, 0);
     bm1 = bp1;
     b0 = bp2;
@@ -784,15 +792,19 @@ __device__ __forceinline__ void refine_from_cube(const float *cube, int col, int
 __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
                                                           long img_stride, cusift_point *__restrict__ points,
                                                           int max_pts, unsigned int *__restrict__ counters,
-                                                          int rows_per_wave, LaplaceTapsPk T, FindParams P) {
+                                                          int rows_per_wave, LaplaceTapsPk T, FindParams P,
+                                                          RowWindow rw, int cy_begin, int cy_end) {
   __shared__ float s_cube[kWavesPerBlock][9 * kCubeCols];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   xcd_remap(bx, by, bz);
-  const int y0 = (by * kWavesPerBlock + wv) * rows_per_wave;
-  const int ya = max(y0, 1), yb = min(y0 + rows_per_wave, h - 1);  // centres [ya, yb)
-  if (ya >= yb) return;                                            // wave-uniform
+  // extremum centres are GLOBAL rows [cy_begin, cy_end) minus the global border rows; this wave takes a chunk
+  // of them and works in band-local row indices (global - rw.row0).  Whole image: rw = {0, h}, [0, h).
+  const int gy0 = cy_begin + (by * kWavesPerBlock + wv) * rows_per_wave;
+  const int ya = max(max(gy0, 1), cy_begin) - rw.row0;
+  const int yb = min(min(gy0 + rows_per_wave, rw.hg - 1), cy_end) - rw.row0;  // local centres [ya, yb)
+  if (ya >= yb) return;                                                         // wave-uniform
   img += (long)bz * img_stride;
   points += (long)bz * max_pts;
   unsigned int *counter = counters + bz;
@@ -903,7 +915,8 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           for (int j = 0; j < 4; ++j)
-            if (m & (1u << j)) refine_from_cube(cube, lane * 4 + j, c0 + j, y, s, P, points, max_pts, counter);
+            if (m & (1u << j))
+              refine_from_cube(cube, lane * 4 + j, c0 + j, y + rw.row0, s, P, points, max_pts, counter);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
@@ -929,8 +942,8 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
 // xB = x - 0.5, i = floor(xB), alpha = frac(xB) rounded to `frac_bits` bits.  Same operation order
 // as oracle_tex2d.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int h, int pitch, float x, float y,
-                                       float q, float inv_q) {
+__device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw, float x,
+                                       float y, float q, float inv_q) {
   const float xb = x - 0.5f, yb = y - 0.5f;
   float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
@@ -939,10 +952,10 @@ __device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int
     b = floorf(b * q + 0.5f) * inv_q;
   }
   fx = fminf(fmaxf(fx, -1.0f), (float)w);
-  fy = fminf(fmaxf(fy, -1.0f), (float)h);
+  fy = fminf(fmaxf(fy, -1.0f), (float)rw.hg);
   const int i = (int)fx, j = (int)fy;
   const int i0 = clampi(i, 0, w - 1), i1 = clampi(i + 1, 0, w - 1);
-  const int j0 = clampi(j, 0, h - 1), j1 = clampi(j + 1, 0, h - 1);
+  const int j0 = local_row(j, h, rw), j1 = local_row(j + 1, h, rw);
   const float s00 = img[(long)j0 * pitch + i0], s10 = img[(long)j0 * pitch + i1];
   const float s01 = img[(long)j1 * pitch + i0], s11 = img[(long)j1 * pitch + i1];
   const float ia = 1.0f - a, ib = 1.0f - b;
@@ -964,15 +977,15 @@ struct PatchGeom {
   int stride;  // floats per patch row
 };
 
-__device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, float *lds,
-                                            const PatchGeom &g, int pw, int ph, int lane) {
+__device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
+                                            float *lds, const PatchGeom &g, int pw, int ph, int lane) {
   // rows of up to 32 columns are loaded two at a time, wider rows one at a time (wave-uniform choice)
   const int cols = pw <= 32 ? 32 : 64;
   const int rows_per_iter = 64 / cols;
   const int c = lane & (cols - 1), rsub = lane / cols;
   const int col = clampi(g.x0 + c, 0, w - 1);
   for (int r = rsub; r < ph; r += rows_per_iter) {
-    const int row = clampi(g.y0 + r, 0, h - 1);
+    const int row = local_row(g.y0 + r, h, rw);
     if (c < pw) lds[r * g.stride + c] = img[(long)row * pitch + col];
   }
 }
@@ -1008,7 +1021,7 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
                                                          long img_stride, cusift_point *__restrict__ points,
                                                          int max_pts, const unsigned int *__restrict__ first,
                                                          const unsigned int *__restrict__ counters, float q,
-                                                         float inv_q) {
+                                                         float inv_q, RowWindow rw) {
   __shared__ float hist[64];
   __shared__ float gauss[11];
   __shared__ float2 s_sample[128];  // (bin as float bits, weight)
@@ -1040,7 +1053,7 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = (tx >> 4) + 4 * r;
-        patch[rr * 16 + (tx & 15)] = img[(long)clampi(g.y0 + rr, 0, h - 1) * pitch + col];
+        patch[rr * 16 + (tx & 15)] = img[(long)local_row(g.y0 + rr, h, rw) * pitch + col];
       }
     }
     __syncthreads();
@@ -1057,8 +1070,8 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
           dx = tex2d_patch(patch, g, xf + 1.0f, yf, q, inv_q) - tex2d_patch(patch, g, xf - 1.0f, yf, q, inv_q);
           dy = tex2d_patch(patch, g, xf, yf + 1.0f, q, inv_q) - tex2d_patch(patch, g, xf, yf - 1.0f, q, inv_q);
         } else {
-          dx = tex2d(img, w, h, pitch, xf + 1.0f, yf, q, inv_q) - tex2d(img, w, h, pitch, xf - 1.0f, yf, q, inv_q);
-          dy = tex2d(img, w, h, pitch, xf, yf + 1.0f, q, inv_q) - tex2d(img, w, h, pitch, xf, yf - 1.0f, q, inv_q);
+          dx = tex2d(img, w, h, pitch, rw, xf + 1.0f, yf, q, inv_q) - tex2d(img, w, h, pitch, rw, xf - 1.0f, yf, q, inv_q);
+          dy = tex2d(img, w, h, pitch, rw, xf, yf + 1.0f, q, inv_q) - tex2d(img, w, h, pitch, rw, xf, yf - 1.0f, q, inv_q);
         }
         int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
         if (bin > 31 || bin < 0) bin = 0;  // < 0 only for non-finite input
@@ -1152,7 +1165,7 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
                                                         long img_stride, cusift_point *__restrict__ points,
                                                         int max_pts, const unsigned int *__restrict__ first,
                                                         const unsigned int *__restrict__ counters, float subsampling,
-                                                        float q, float inv_q) {
+                                                        float q, float inv_q, RowWindow rw) {
   __shared__ float s_grad[256];
   __shared__ float s_angf[256];
   __shared__ int s_angi[256];
@@ -1206,7 +1219,7 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
     const int ph = (int)floorf(py + reach - 0.5f) + 2 - g.y0 + 1;
     const bool use_patch = (reach < 0.5f * kDescPatch) && (fabsf(px) < 1e6f) && (fabsf(py) < 1e6f) &&
                            pw <= kDescPatch && ph <= kDescPatch;  // wave-uniform
-    if (use_patch) stage_patch(img, w, h, pitch, patch, g, pw, ph, lane);
+    if (use_patch) stage_patch(img, w, h, pitch, rw, patch, g, pw, ph, lane);
     __syncthreads();
 
     // ---- phase 1: samples ----
@@ -1224,10 +1237,10 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
         dy = tex2d_patch(patch, g, xpos - sina, ypos + cosa, q, inv_q) -
              tex2d_patch(patch, g, xpos + sina, ypos - cosa, q, inv_q);
       } else {
-        dx = tex2d(img, w, h, pitch, xpos + cosa, ypos + sina, q, inv_q) -
-             tex2d(img, w, h, pitch, xpos - cosa, ypos - sina, q, inv_q);
-        dy = tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, q, inv_q) -
-             tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, q, inv_q);
+        dx = tex2d(img, w, h, pitch, rw, xpos + cosa, ypos + sina, q, inv_q) -
+             tex2d(img, w, h, pitch, rw, xpos - cosa, ypos - sina, q, inv_q);
+        dy = tex2d(img, w, h, pitch, rw, xpos - sina, ypos + cosa, q, inv_q) -
+             tex2d(img, w, h, pitch, rw, xpos + sina, ypos - cosa, q, inv_q);
       }
       const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
       float angf = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;

@@ -46,6 +46,15 @@ struct ScaleDownTaps {
   float k[3];  // k0, k1, k2 of cuSIFT.cu:330-341 (k[2] centre)
 };
 
+// A device image may be a horizontal band of a larger ("global") image: its local row 0 is global row
+// `row0` and the global image has `hg` rows.  Whole images use {0, h}.  Row addressing everywhere is
+// "clamp to the global image, then translate" so that a band with enough halo rows behaves exactly like
+// the whole image (used by the multi-GPU strip tiling).
+struct RowWindow {
+  int row0;
+  int hg;
+};
+
 struct FindParams {
   float thr_pos;            // d_Threshold[0] = +peakThresh   (cuSIFT.cu:432)
   float thr_neg;            // d_Threshold[1] = -peakThresh

@@ -86,6 +86,9 @@ void cusift_default_params(cusift_params *p);
  * hipStream_t (borrowed; e.g. torch.cuda.current_stream().cuda_stream). The reference has one
  * implicit global context: default stream + file-scope device symbols (cuSIFT_D.cu:13-20). */
 int cusift_ctx_create(cusift_ctx **out, int device, void *hip_stream);
+/* Same, but `hip_stream` is always borrowed, and NULL means the device's default (null) stream -- what
+ * torch.cuda.current_stream().cuda_stream is (0) unless the caller switched streams. */
+int cusift_ctx_create_borrowed(cusift_ctx **out, int device, void *hip_stream);
 int cusift_ctx_destroy(cusift_ctx *ctx);
 int cusift_ctx_synchronize(cusift_ctx *ctx); /* blocking */
 void *cusift_ctx_stream(cusift_ctx *ctx);
@@ -155,6 +158,27 @@ int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h
                                const unsigned int *d_counters, float subsampling, int tex_frac_bits, int n_images);
 /* SiftData::ConvertSiftToRootSift, cuSIFT.cu:383-395 + cuSIFT_D.cu:299-317. */
 int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts);
+
+/* ---- band ("tile") forms: one large image strip-tiled over several GPUs (BASELINE configs[4]) -- */
+/* A band is `h` rows of device memory whose local row 0 is row `row0` of a global image with `h_global` rows
+ * (same width).  Row addressing is "clamp to the global image, then translate", so a band that carries enough
+ * halo rows gives bit-identical results to the whole image for the rows it owns.  New functionality: the
+ * reference has no tiling (its scratch arena is sized for the whole image, cuSIFT.cu:81-98).
+ * cusift_scale_down_band: computes global rows [r_begin, r_end) of the half-size image into a destination band
+ *   that starts at global row dst_row0, from a source band {src_row0, h_src_global}; needs source rows
+ *   2r-1 .. 2r+3 (cuSIFT_D.cu:75,123-125) inside the source band.
+ * cusift_detect_band: fused LaplaceMulti+FindPointsMulti with extremum centres restricted to global rows
+ *   [cy_begin, cy_end); keypoint rows are written in global coordinates.  Needs >= 6 halo rows.
+ * cusift_describe_band: ComputeOrientations + ExtractSiftDescriptors for keypoints in global coordinates. */
+int cusift_scale_down_band(cusift_ctx *ctx, float *d_dst, int dst_pitch, int dst_row0, int r_begin, int r_end,
+                           const float *d_src, int w, int h_src, int src_pitch, int src_row0, int h_src_global,
+                           float variance);
+int cusift_detect_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0, int h_global,
+                       int cy_begin, int cy_end, float init_blur, float peak_thresh, float edge_thresh,
+                       float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counter);
+int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0, int h_global,
+                         cusift_point *d_points, int max_pts, const unsigned int *d_first,
+                         const unsigned int *d_counter, float subsampling, int tex_frac_bits);
 
 /* ---- drivers ------------------------------------------------------------------------------ */
 /* Batch form of ExtractSiftLoop/ExtractSiftOctave (cuSIFT.cu:175-270) on device-resident images.

@@ -17,15 +17,16 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(world, mode, tmp_path):
+def run_world(world, mode, tmp_path, script="dist_worker.py", extra=()):
     port = free_port()
     out = str(tmp_path / ("out_" + mode))
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, mode], env=env,
-                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        args = [sys.executable, os.path.join(HERE, script), out] + ([mode] if script == "dist_worker.py" else []) + \
+            [str(a) for a in extra]
+        procs.append(subprocess.Popen(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
@@ -89,3 +90,40 @@ def test_sharded_batch_equals_single_process(tmp_path, oracle):
     for r in range(2):
         np.testing.assert_array_equal(res[r]["merged_counts"], want_counts)
         np.testing.assert_array_equal(res[r]["merged_bytes"], want_bytes)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strip_tiling_halo_exchange_and_merge(world, tmp_path, oracle):
+    """BASELINE configs[4] host logic on CPU: per-octave halo exchange rebuilds every band exactly (== the slice of
+    the single-process pyramid), each keypoint is found by exactly one rank, and the all-gatherv merge equals the
+    whole-image detection (rows within 1e-3: band-local float rows are re-based)."""
+    from cusift_amd import synth
+    from cusift_amd.tiling import StripPlan, octave_blurs
+    from oracle_binding import SIFT_POINT_DTYPE, pitched
+    from parity_utils import canonical_order
+
+    W, H, n_oct, thresh = 256, 1536, 3, 2.0
+    res = run_world(world, "tiling", tmp_path, script="tiling_worker.py", extra=(W, H, n_oct, thresh))
+    plan = StripPlan(W, H, world, n_oct)
+    img = synth.tile(99, W, H)
+    pyr = [pitched(img)]
+    for o in range(1, n_oct):
+        pyr.append(oracle.scale_down(pyr[-1], plan.w[o - 1], plan.h[o - 1]))
+    for r in range(world):
+        for o in range(n_oct):
+            lo, hi = plan.band(r, o)
+            np.testing.assert_array_equal(res[r]["band%d" % o][:, : plan.w[o]], pyr[o][lo:hi, : plan.w[o]])
+    blur = octave_blurs(0.0, n_oct)
+    want = []
+    for o in reversed(range(n_oct)):
+        dog = oracle.laplace_multi(pyr[o], plan.w[o], plan.h[o], blur[o])
+        c, n = oracle.find_points_multi(dog, plan.w[o], plan.h[o], thresh, 10.0, float(2 ** o), 8192)
+        want.append(c[:n])
+    want = canonical_order(np.concatenate(want))
+    assert len(want) > 300
+    for r in range(world):
+        got = canonical_order(res[r]["merged"].view(SIFT_POINT_DTYPE).reshape(-1))
+        assert len(got) == len(want)
+        np.testing.assert_array_equal(got["coords2D"][:, 0], want["coords2D"][:, 0])
+        np.testing.assert_allclose(got["coords2D"][:, 1], want["coords2D"][:, 1], atol=1e-3, rtol=0)
+        np.testing.assert_array_equal(got["sharpness"], want["sharpness"])
