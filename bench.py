@@ -301,8 +301,9 @@ def main():
             }
 
         def stage_table(st):
-            return {k: round(st[k][0] / K, 4) for k in ("scale_down", "detect_multi", "laplace_multi", "find_points_multi",
-                                                         "compute_orientations", "extract_descriptors", "total")}
+            return {k: round(st[k][0] / K, 4) for k in ("scale_down", "detect_multi", "describe_all", "laplace_multi",
+                                                         "find_points_multi", "compute_orientations",
+                                                         "extract_descriptors", "total")}
 
         if stage is not None:
             out["stage_ms_per_step"] = stage_table(stage)

@@ -12,8 +12,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcusift_amd.so")
-SOURCES = ["sift_capi.hip", "sift_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "sift_types.h"), os.path.join(HERE, "..", "include", "cusift_amd.h")]
+SOURCES = ["sift_capi.hip", "sift_stencils.hip", "sift_keypoints.hip"]
+HEADERS = [os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"),
+           os.path.join(HERE, "..", "include", "cusift_amd.h")]
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).
 HIPCC_FLAGS = [

@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcusift_amd.so")
 
 CUSIFT_OK = 0
-NUM_STAGES = 7
+NUM_STAGES = 8
 STAGE_NAMES = ("scale_down", "laplace_multi", "find_points_multi", "compute_orientations",
-               "extract_descriptors", "total", "detect_multi")
+               "extract_descriptors", "total", "detect_multi", "describe_all")
 
 # SiftPoint, cuSIFT.h:10-30 (588 B, no padding)
 SIFT_POINT_DTYPE = np.dtype(

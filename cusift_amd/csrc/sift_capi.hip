@@ -16,7 +16,7 @@
 #include "sift_types.h"
 
 namespace cusift {
-// kernels (sift_kernels.hip)
+// kernels (sift_stencils.hip, sift_keypoints.hip)
 __global__ void scale_down_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps);
 __global__ void scale_down_fast_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps,
                                        RowWindow, int, int, int);
@@ -32,6 +32,7 @@ __global__ void orientations_kernel(const float *, int, int, int, long, cusift_p
                                     const unsigned int *, float, float, RowWindow);
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                    const unsigned int *, float, float, float, RowWindow);
+__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float);
 __global__ void rootsift_kernel(cusift_point *, int);
 }  // namespace cusift
 
@@ -89,6 +90,7 @@ struct cusift_ctx {
   size_t dog_bytes = 0;
   // small persistent device scratch for the blocking single-image entry points
   unsigned int *d_counter1 = nullptr;
+  int describe_grid = 0;  // resident blocks of describe_all_kernel on this device (occupancy query, cached)
   // timing
   bool timing = false;
   std::vector<TimedSpan> spans;       // recorded, not yet folded
@@ -786,10 +788,22 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     base[o] = dst;
   }
   unsigned int *first = (unsigned int *)(ctx->arena + pl.first_off);
+  // With fused_detect the keypoint stages run once, after the last octave's detection, over the flattened list
+  // of all keypoints of the batch (describe_all_kernel); otherwise per octave like the reference.
+  bool all_fused = prm->fused_detect && n_images <= kMaxFlatImages && !getenv("CUSIFT_FORCE_GENERIC");
+  for (int o = 0; o < pl.n_oct && all_fused; ++o)
+    if ((prm->lowest_scale < pl.sub[o] * 2.0f) && !detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o]))
+      all_fused = false;
   // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
   for (int o = pl.n_oct - 1; o >= 0; --o) {
     if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
     // ExtractSiftOctave, cuSIFT.cu:204-270
+    if (all_fused) {
+      TRY(cusift_detect_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o],
+                              prm->peak_thresh, prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters,
+                              n_images));
+      continue;
+    }
     const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
     unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
     HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
@@ -810,6 +824,35 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
                                     d_counters, prm->tex_frac_bits, n_images));
     TRY(cusift_extract_descriptors(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
                                    d_counters, pl.sub[o], prm->tex_frac_bits, n_images));
+  }
+  if (all_fused) {
+    OctaveTable T;
+    memset(&T, 0, sizeof(T));
+    T.n_oct = pl.n_oct;
+    for (int o = 0; o < pl.n_oct; ++o) {
+      T.base[o] = base[o];
+      T.stride[o] = (long)stride[o];
+      T.w[o] = pl.w[o];
+      T.h[o] = pl.h[o];
+      T.pitch[o] = pl.p[o];
+      T.sub[o] = pl.sub[o];
+    }
+    float q, inv_q;
+    frac_consts(prm->tex_frac_bits, q, inv_q);
+    // persistent grid = exactly the blocks that are resident at once (a larger static grid would run in
+    // rounds and leave the second round's items waiting); items are interleaved over the blocks
+    if (ctx->describe_grid == 0) {
+      int per_cu = 0, cus = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, describe_all_kernel, 64, 0));
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+      ctx->describe_grid = std::max(1, per_cu) * std::max(1, cus);
+    }
+    const long cap = (long)n_images * prm->max_pts;
+    dim3 grid((unsigned int)std::max(1L, std::min(cap, (long)ctx->describe_grid)));
+    StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
+    hipLaunchKernelGGL(describe_all_kernel, grid, dim3(64), 0, ctx->stream, T, d_points, prm->max_pts, d_counters,
+                       n_images, q, inv_q);
+    TRY(check_launch("describe_all"));
   }
   return CUSIFT_OK;
 }

@@ -1,0 +1,553 @@
+// sift_keypoints.hip -- gfx950 keypoint kernels: dominant orientation, 128-D descriptor, their fusion over all
+// octaves of a batch, RootSIFT.  One 64-lane wave per keypoint; the pixels a keypoint samples are staged in LDS
+// and the reference's texture fetches are modelled in software (gfx950 has no image unit).
+//
+// Arithmetic follows oracle/sift_oracle.c operation by operation (nothing fused: -ffp-contract=off).
+#include "sift_device.h"
+
+namespace cusift {
+
+// ------------------------------------------------------------------------------------------------
+// Software model of the CUDA texture fetch the reference relies on:
+// tex2D<float>(x, y), cudaFilterModeLinear, clamp, unnormalised coordinates (cuSIFT.cu:227-233).
+// xB = x - 0.5, i = floor(xB), alpha = frac(xB) rounded to `frac_bits` bits.  Same operation order
+// as oracle_tex2d.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw, float x,
+                                       float y, float q, float inv_q) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (q > 0.0f) {
+    a = floorf(a * q + 0.5f) * inv_q;  // q is a power of two: * inv_q == / q exactly
+    b = floorf(b * q + 0.5f) * inv_q;
+  }
+  fx = fminf(fmaxf(fx, -1.0f), (float)w);
+  fy = fminf(fmaxf(fy, -1.0f), (float)rw.hg);
+  const int i = (int)fx, j = (int)fy;
+  const int i0 = clampi(i, 0, w - 1), i1 = clampi(i + 1, 0, w - 1);
+  const int j0 = local_row(j, h, rw), j1 = local_row(j + 1, h, rw);
+  const float s00 = img[(long)j0 * pitch + i0], s10 = img[(long)j0 * pitch + i1];
+  const float s01 = img[(long)j1 * pitch + i0], s11 = img[(long)j1 * pitch + i1];
+  const float ia = 1.0f - a, ib = 1.0f - b;
+  float t = (ia * ib) * s00;
+  t = t + (a * ib) * s10;
+  t = t + (ia * b) * s01;
+  t = t + (a * b) * s11;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged image patches.  A patch holds S[clamp(y0+r)][clamp(x0+c)] for the UNCLAMPED coordinates
+// (x0+c, y0+r), so a bilinear fetch whose 2x2 footprint lies inside the patch reads exactly the pixels the
+// clamping texture model would (a footprint clamped at the border interpolates between equal values in both
+// cases).  tex2d_patch() is tex2d() operation for operation, reading LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDescPatch = 40;  // LDS patch edge: covers descriptor windows up to scale ~2.1 at 45 degrees
+
+struct PatchGeom {
+  int x0, y0;  // image coordinate of patch element (0,0)
+  int stride;  // floats per patch row
+};
+
+__device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
+                                            float *lds, const PatchGeom &g, int pw, int ph, int lane) {
+  // rows of up to 32 columns are loaded two at a time, wider rows one at a time (wave-uniform choice)
+  const int cols = pw <= 32 ? 32 : 64;
+  const int rows_per_iter = 64 / cols;
+  const int c = lane & (cols - 1), rsub = lane / cols;
+  const int col = clampi(g.x0 + c, 0, w - 1);
+  for (int r = rsub; r < ph; r += rows_per_iter) {
+    const int row = local_row(g.y0 + r, h, rw);
+    if (c < pw) lds[r * g.stride + c] = img[(long)row * pitch + col];
+  }
+}
+
+__device__ __forceinline__ float tex2d_patch(const float *lds, const PatchGeom &g, float x, float y, float q,
+                                             float inv_q) {
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fx = floorf(xb), fy = floorf(yb);
+  float a = xb - fx, b = yb - fy;
+  if (q > 0.0f) {
+    a = floorf(a * q + 0.5f) * inv_q;
+    b = floorf(b * q + 0.5f) * inv_q;
+  }
+  const int i = (int)fx - g.x0, j = (int)fy - g.y0;
+  const float *p0 = lds + j * g.stride + i;
+  const float *p1 = p0 + g.stride;
+  const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
+  const float ia = 1.0f - a, ib = 1.0f - b;
+  float t = (ia * ib) * s00;
+  t = t + (a * ib) * s10;
+  t = t + (ia * b) * s01;
+  t = t + (a * b) * s11;
+  return t;
+}
+
+// The keypoint kernels run ONE wave per workgroup, so "all threads of the block have written LDS" only needs
+// this wave's LDS operations to have completed (they execute in order): wait for lgkmcnt, not for outstanding
+// global loads/stores as __syncthreads() would (its vmcnt(0) drain cost ~1-2 us per keypoint).
+__device__ __forceinline__ void wave_sync() {
+  // compiler barrier for memory + "my LDS operations are done"; no s_barrier (one wave), no vmcnt wait
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// Where a keypoint's taps come from: an LDS patch (usual) or global memory (footprint larger than the patch).
+struct Sampler {
+  const float *img;
+  int w, h, pitch;
+  RowWindow rw;
+  const float *patch;
+  PatchGeom g;
+  bool use_patch;  // wave-uniform
+  float q, inv_q;
+  __device__ __forceinline__ float operator()(float x, float y) const {
+    return use_patch ? tex2d_patch(patch, g, x, y, q, inv_q) : tex2d(img, w, h, pitch, rw, x, y, q, inv_q);
+  }
+};
+
+// LDS of one keypoint wave (8.75 KB => 16 waves per CU together with the 1 KB prefix table of describe_all).
+// The descriptor's histogram buffers are only needed after its sampling phase, when the patch is dead, so they
+// live inside the patch storage.
+struct KpShared {
+  float hist[64];
+  float gauss[11];      // orientation window; gauss[0] also carries the finished orientation to all lanes
+  union {
+    float2 sample[128];  // orientation: (bin as float bits, weight)
+    float grad[256];     // descriptor samples (the two stages never overlap in time)
+  };
+  float angraw[256];    // descriptor samples: 4/pi*atan2 + 4 (integer part = bin, fraction = weight)
+  float patch[kDescPatch * kDescPatch];
+  __device__ __forceinline__ float *hist8() { return patch; }              // 64 lanes x 9 (stride 9)
+  __device__ __forceinline__ float *fin() { return patch + 64 * 9; }       // 128
+  __device__ __forceinline__ float *sums() { return patch + 64 * 9 + 128; }  // 64
+};
+static_assert(64 * 9 + 128 + 64 <= kDescPatch * kDescPatch, "histogram buffers must fit in the patch storage");
+
+// LDS of the orientation-only stage kernel
+struct OriShared {
+  float hist[64];
+  float gauss[11];
+  float2 sample[128];
+  float patch[16 * 16];
+};
+
+// ------------------------------------------------------------------------------------------------
+// Dominant orientation.  Reference: ComputeOrientations_D, cuSIFT_D.cu:319-396 (second peak compiled out, :380).
+// 121 samples (11x11) -> 32-bin histogram: bins are lanes, samples are walked in index order, so the sums are
+// deterministic and in the oracle's order.  Every lane returns the orientation (degrees).
+// ------------------------------------------------------------------------------------------------
+template <typename SH>
+__device__ __forceinline__ float kp_orientation(SH &S, const Sampler &tex, float kx, float ky, float scale, int tx) {
+  const float i2sigma2 = -1.0f / (4.5f * scale * scale);
+  if (tx < 11) S.gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
+  const float xp = kx - 5.0f;
+  const float yp = ky - 5.0f;
+  wave_sync();
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int t = tx + 64 * rep;
+    if (t < 121) {
+      const int yd = t / 11;
+      const int xd = t - yd * 11;
+      const float xf = xp + xd;
+      const float yf = yp + yd;
+      const float dx = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
+      const float dy = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
+      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      if (bin > 31 || bin < 0) bin = 0;  // < 0 only for non-finite input
+      const float grad = sqrtf(dx * dx + dy * dy);
+      S.sample[t] = make_float2(__int_as_float(bin), grad * S.gauss[xd] * S.gauss[yd]);
+    }
+  }
+  wave_sync();
+  if (tx < 32) {
+    float acc = 0.0f;
+#pragma unroll 11
+    for (int t = 0; t < 121; ++t) {
+      const float2 sv = S.sample[t];
+      if (__float_as_int(sv.x) == tx) acc += sv.y;
+    }
+    S.hist[tx] = acc;
+  }
+  wave_sync();
+  const int x1m = (tx >= 1 ? tx - 1 : tx + 31);
+  const int x1p = (tx <= 30 ? tx + 1 : tx - 31);
+  if (tx < 32) {
+    const int x2m = (tx >= 2 ? tx - 2 : tx + 30);
+    const int x2p = (tx <= 29 ? tx + 2 : tx - 30);
+    S.hist[tx + 32] = 6.0f * S.hist[tx] + 4.0f * (S.hist[x1m] + S.hist[x1p]) + (S.hist[x2m] + S.hist[x2p]);
+  }
+  wave_sync();
+  float pk = 0.0f;
+  if (tx < 32) {
+    const float v = S.hist[32 + tx];
+    pk = (v > S.hist[32 + x1m] && v >= S.hist[32 + x1p]) ? v : 0.0f;
+  }
+  wave_sync();
+  if (tx < 32) S.hist[tx] = pk;
+  wave_sync();
+  if (tx == 0) {
+    float maxval1 = 0.0f;
+    int i1 = -1;
+    for (int i = 0; i < 32; ++i) {
+      const float v = S.hist[i];
+      if (v > maxval1) {
+        maxval1 = v;
+        i1 = i;
+      }
+    }
+    const float val1 = S.hist[32 + ((i1 + 1) & 31)];
+    const float val2 = S.hist[32 + ((i1 + 31) & 31)];
+    const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
+    S.gauss[0] = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+  }
+  wave_sync();
+  const float ori = S.gauss[0];
+  wave_sync();
+  return ori;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 128-D descriptor.  Reference: ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.  No LDS float atomics
+// (ds_add_f32 retires one lane at a time on gfx950: ~150 cycles per wave instruction, measured):
+//   phase 1  the 16x16 rotated sample grid, 4 samples per lane: gradient magnitude (with the Gaussian
+//            window), angle bin and angle fraction go to LDS.
+//   phase 2  gather: lane l = (cell l/4, row pair l%4) walks its 2x8 share of the 8x8 samples that reach
+//            its histogram cell, forms the same products as the reference (horizontal, vertical, then
+//            angle weight) and accumulates them into a private 8-bin LDS histogram (plain read-add-write,
+//            lane-private rows, stride 9 -> conflict free).  The reference's column-14 spill into the
+//            next row's first cell (guard `tx<=14`, cuSIFT_D.cu:243) is gathered the same way; its
+//            angle-index-8 spill (atan2f == +pi) is rare and goes through one LDS atomic.
+//   phase 3  the 4 partial histograms of each cell are summed in a fixed order; L2-normalise, clamp at
+//            0.2, L2-normalise with the reference's reduction tree.
+// The order of the sums is fixed, so results are reproducible run to run.  Lane l returns elements l, l+64.
+// ------------------------------------------------------------------------------------------------
+struct DescLaneConsts {
+  int tx1;
+  float gx1;
+  float gy1[4];
+};
+
+__device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
+  // sample idx = lane + 64*step -> column tx = lane%16, row y = lane/16 + 4*step
+  DescLaneConsts c;
+  c.tx1 = lane & 15;
+  c.gx1 = expf(-(c.tx1 - 7.5f) * (c.tx1 - 7.5f) / 128.0f);
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int y = (lane >> 4) + 4 * step;
+    c.gy1[step] = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
+  }
+  return c;
+}
+
+__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float *__restrict__ fin, int next_cell_base,
+                                              float grad, float angraw, float wx, float wy) {
+  int angi = (int)angraw;
+  const float angf = angraw - angi;
+  if (angi < 0 || angi > 8) angi = 0;  // only for non-finite input
+  const float grad1 = wx * grad;
+  const float grad2 = wy * grad1;
+  const float v1 = (1.0f - angf) * grad2;
+  const float v2 = angf * grad2;
+  if (angi < 8) {
+    myhist[angi] += v1;
+  } else if (next_cell_base < 128) {
+    atomicAdd(fin + next_cell_base, v1);  // index angi+hist+off = 8 + ...: bin 0 of the next linear cell
+  }
+  const int angp = (angi < 7 ? angi + 1 : 0);
+  myhist[angp] += v2;
+}
+
+__device__ __forceinline__ void kp_descriptor(KpShared &S, const Sampler &tex, const DescLaneConsts &C, float px,
+                                              float py, float kp_scale, float orientation, int lane, float &out0,
+                                              float &out1) {
+  const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
+  float *myhist = S.hist8() + lane * 9;
+  float *fin = S.fin(), *sums = S.sums();
+  const int next_cell_base = 8 * (cell + 1);
+  const float theta = 2.0f * 3.1415f / 360.0f * orientation;
+  const float sina = sinf(theta);
+  const float cosa = cosf(theta);
+  const float scale = 12.0f / 16.0f * kp_scale;
+  const float ssina = scale * sina;
+  const float scosa = scale * cosa;
+
+  // ---- phase 1: samples ----
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int idx = lane + 64 * step;
+    const int y = idx >> 4, tx = C.tx1;
+    const float gy = C.gy1[step], gx = C.gx1;
+    const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
+    const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
+    const float dx = tex(xpos + cosa, ypos + sina) - tex(xpos - cosa, ypos - sina);
+    const float dy = tex(xpos - sina, ypos + cosa) - tex(xpos + sina, ypos - cosa);
+    const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
+    S.grad[idx] = grad;
+    S.angraw[idx] = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;
+  }
+  wave_sync();
+  // the patch is dead from here on: its storage becomes the histogram buffers
+  fin[lane] = 0.0f;
+  fin[lane + 64] = 0.0f;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) myhist[b] = 0.0f;
+  wave_sync();
+
+  // ---- phase 2: gather into the lane-private histogram ----
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int y = 4 * vi - 2 + 2 * kq + r;
+    if (y >= 0 && y <= 15) {
+      const int veri = (y + 2) / 4 - 1;
+      const float verf = (y - 1.5f) / 4.0f - veri;
+      const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
+#pragma unroll
+      for (int cx = 0; cx < 8; ++cx) {
+        const int tx = 4 * hi - 2 + cx;
+        if (tx >= 0 && tx <= 15) {
+          const int hori = (tx + 2) / 4 - 1;
+          const float horf = (tx - 1.5f) / 4.0f - hori;
+          const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
+          const int idx = y * 16 + tx;
+          gather_sample(myhist, fin, next_cell_base, S.grad[idx], S.angraw[idx], wx, wy);
+        }
+      }
+    }
+  }
+  if (hi == 0 && vi >= 1) {
+    // the reference's right-hand adds of column 14 (hori+1 == 4) land in cell (row+1, 0)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = 4 * (vi - 1) - 2 + 2 * kq + r;
+      if (y >= 0 && y <= 15) {
+        const int veri = (y + 2) / 4 - 1;
+        const float verf = (y - 1.5f) / 4.0f - veri;
+        const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
+        const float horf = (14 - 1.5f) / 4.0f - 3;
+        const int idx = y * 16 + 14;
+        gather_sample(myhist, fin, next_cell_base, S.grad[idx], S.angraw[idx], horf, wy);
+      }
+    }
+  }
+  wave_sync();
+
+  // ---- phase 3: cell sums (fixed order) and normalisation ----
+  float bsum[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int b = lane + 64 * r;
+    const float *hc = S.hist8() + (b >> 3) * 4 * 9 + (b & 7);
+    bsum[r] = ((hc[0] + hc[9]) + hc[18]) + hc[27];
+  }
+  float b0 = fin[lane] + bsum[0], b1 = fin[lane + 64] + bsum[1];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    sums[lane] = b0 * b0 + b1 * b1;
+    wave_sync();
+    if (lane < 32) sums[lane] = sums[lane] + sums[lane + 32];
+    wave_sync();
+    if (lane < 16) sums[lane] = sums[lane] + sums[lane + 16];
+    wave_sync();
+    if (lane < 8) sums[lane] = sums[lane] + sums[lane + 8];
+    wave_sync();
+    if (lane < 4) sums[lane] = sums[lane] + sums[lane + 4];
+    wave_sync();
+    const float tsum = sums[0] + sums[1] + sums[2] + sums[3];
+    const float r = 1.0f / sqrtf(tsum);
+    b0 = b0 * r;
+    b1 = b1 * r;
+    if (pass == 0) {
+      if (b0 > 0.2f) b0 = 0.2f;
+      if (b1 > 0.2f) b1 = 0.2f;
+    }
+    wave_sync();
+  }
+  out0 = b0;
+  out1 = b1;
+}
+
+// patch that covers every tap within `reach` of (px, py); false if it does not fit kDescPatch^2
+__device__ __forceinline__ bool patch_for_reach(float px, float py, float reach, PatchGeom &g, int &pw, int &ph) {
+  g.stride = kDescPatch;
+  g.x0 = (int)floorf(px - reach - 0.5f) - 1;
+  g.y0 = (int)floorf(py - reach - 0.5f) - 1;
+  pw = (int)floorf(px + reach - 0.5f) + 2 - g.x0 + 1;
+  ph = (int)floorf(py + reach - 0.5f) + 2 - g.y0 + 1;
+  return (reach < 0.5f * kDescPatch) && (fabsf(px) < 1e6f) && (fabsf(py) < 1e6f) && pw <= kDescPatch &&
+         ph <= kDescPatch;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ComputeOrientations (stage entry point; persistent grid over [first, min(count,max_pts)) of each image)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) orientations_kernel(const float *__restrict__ img, int w, int h, int pitch,
+                                                         long img_stride, cusift_point *__restrict__ points,
+                                                         int max_pts, const unsigned int *__restrict__ first,
+                                                         const unsigned int *__restrict__ counters, float q,
+                                                         float inv_q, RowWindow rw) {
+  __shared__ OriShared S;
+  const int tx = threadIdx.x;
+  img += (long)blockIdx.y * img_stride;
+  points += (long)blockIdx.y * max_pts;
+  const unsigned int fst = first ? first[blockIdx.y] : 0u;
+  const unsigned int cnt = counters[blockIdx.y];
+  const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
+
+  for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
+    cusift_point *pt = points + bx;
+    const float scale = pt->scale;
+    const float kx = pt->coords2D[0], ky = pt->coords2D[1];
+    // every tap lies in [k-6, k+6]; its 2x2 footprint starts at floor(k-6.5) .. floor(k+5.5): a 16x16 patch
+    Sampler tex{img, w, h, pitch, rw, S.patch, PatchGeom{0, 0, 16}, false, q, inv_q};
+    tex.use_patch = (fabsf(kx) < 1e6f) && (fabsf(ky) < 1e6f);
+    tex.g.x0 = (int)floorf(kx - 6.5f) - 1;
+    tex.g.y0 = (int)floorf(ky - 6.5f) - 1;
+    if (tex.use_patch) stage_patch(img, w, h, pitch, rw, S.patch, tex.g, 16, 16, tx);
+    const float ori = kp_orientation(S, tex, kx, ky, scale, tx);
+    if (tx == 0) pt->orientation = ori;
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ExtractSiftDescriptors (stage entry point)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict__ img, int w, int h, int pitch,
+                                                        long img_stride, cusift_point *__restrict__ points,
+                                                        int max_pts, const unsigned int *__restrict__ first,
+                                                        const unsigned int *__restrict__ counters, float subsampling,
+                                                        float q, float inv_q, RowWindow rw) {
+  __shared__ KpShared S;
+  const int lane = threadIdx.x;
+  img += (long)blockIdx.y * img_stride;
+  points += (long)blockIdx.y * max_pts;
+  const unsigned int fst = first ? first[blockIdx.y] : 0u;
+  const unsigned int cnt = counters[blockIdx.y];
+  const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
+  const DescLaneConsts C = desc_lane_consts(lane);
+
+  for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
+    cusift_point *pt = points + bx;
+    const float px = pt->coords2D[0], py = pt->coords2D[1], kscale = pt->scale, ori = pt->orientation;
+    // every tap is within `reach` of the keypoint: 7.5*spacing*(|cos|+|sin|) for the grid + 1 for the tap
+    const float theta = 2.0f * 3.1415f / 360.0f * ori;
+    const float reach = 7.5f * (12.0f / 16.0f * kscale) * (fabsf(cosf(theta)) + fabsf(sinf(theta))) + 1.0f + 0.01f;
+    Sampler tex{img, w, h, pitch, rw, S.patch, PatchGeom{0, 0, kDescPatch}, false, q, inv_q};
+    int pw, ph;
+    tex.use_patch = patch_for_reach(px, py, reach, tex.g, pw, ph);
+    if (tex.use_patch) stage_patch(img, w, h, pitch, rw, S.patch, tex.g, pw, ph, lane);
+    wave_sync();
+    float b0, b1;
+    kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
+    pt->data[lane] = b0;
+    pt->data[lane + 64] = b1;
+    if (lane == 0) {  // cuSIFT_D.cu:292-296
+      pt->coords2D[0] = px * subsampling;
+      pt->coords2D[1] = py * subsampling;
+      pt->scale = kscale * subsampling;
+    }
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orientation + descriptor of ALL keypoints of a batch in one launch (driver path).  The reference runs the
+// two kernels once per octave (cuSIFT.cu:253-258); here detection runs for every octave first and this kernel
+// then walks the flattened list of (image, keypoint) pairs -- the octave comes from the record's `subsampling`
+// -- so images with more keypoints do not leave the rest of the grid idle, one patch load serves both stages,
+// and 2 x octaves launches become one.  Same device functions as the two stage kernels => same results.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) describe_all_kernel(OctaveTable T, cusift_point *__restrict__ points, int max_pts,
+                                                         const unsigned int *__restrict__ counters, int n_images,
+                                                         float q, float inv_q) {
+  __shared__ KpShared S;
+  __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
+  const int lane = threadIdx.x;
+  // exclusive prefix sums of the per-image counts (every block computes them: n_images <= kMaxFlatImages)
+  for (int i = lane; i < n_images; i += 64) {
+    const unsigned int c = counters[i];
+    s_prefix[i + 1] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
+  }
+  wave_sync();
+  if (lane == 0) {
+    unsigned int acc = 0;
+    s_prefix[0] = 0;
+    for (int i = 1; i <= n_images; ++i) {
+      acc += s_prefix[i];
+      s_prefix[i] = acc;
+    }
+  }
+  wave_sync();
+  const unsigned int total = s_prefix[n_images];
+  const DescLaneConsts C = desc_lane_consts(lane);
+  const int exp0 = (__float_as_int(T.sub[0]) >> 23) & 0xff;
+
+  for (unsigned int g = blockIdx.x; g < total; g += gridDim.x) {
+    // image of item g: last i with prefix[i] <= g
+    int lo = 0, hi_ = n_images;
+    while (hi_ - lo > 1) {
+      const int mid = (lo + hi_) >> 1;
+      if (s_prefix[mid] <= g) lo = mid; else hi_ = mid;
+    }
+    cusift_point *pt = points + (long)lo * max_pts + (g - s_prefix[lo]);
+    const float px = pt->coords2D[0], py = pt->coords2D[1], kscale = pt->scale, sub = pt->subsampling;
+    int o = ((__float_as_int(sub) >> 23) & 0xff) - exp0;  // subsampling = sub0 * 2^octave
+    o = clampi(o, 0, T.n_oct - 1);
+    const float *img = T.base[o] + (long)lo * T.stride[o];
+    const int w = T.w[o], h = T.h[o], pitch = T.pitch[o];
+    const RowWindow rw{0, h};
+    // one patch for both stages: orientation taps reach 6 px, descriptor taps 7.5*spacing*sqrt(2)+1 at most
+    const float reach = fmaxf(7.5f * (12.0f / 16.0f * kscale) * 1.41422f + 1.0f + 0.01f, 6.0f);
+    Sampler tex{img, w, h, pitch, rw, S.patch, PatchGeom{0, 0, kDescPatch}, false, q, inv_q};
+    int pw, ph;
+    tex.use_patch = patch_for_reach(px, py, reach, tex.g, pw, ph);
+    if (tex.use_patch) stage_patch(img, w, h, pitch, rw, S.patch, tex.g, pw, ph, lane);
+    const float ori = kp_orientation(S, tex, px, py, kscale, lane);
+    float b0, b1;
+    kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
+    pt->data[lane] = b0;
+    pt->data[lane + 64] = b1;
+    if (lane == 0) {
+      pt->orientation = ori;
+      pt->coords2D[0] = px * sub;
+      pt->coords2D[1] = py * sub;
+      pt->scale = kscale * sub;
+    }
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvertSiftToRootSift: reference cuSIFT_D.cu:299-317 (sequential L1 sum, sqrt(max(0,v)/sum)).
+// One wave per point; the 128-term sum is kept sequential (lane 0) to match the reference order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) rootsift_kernel(cusift_point *__restrict__ points, int num_pts) {
+  __shared__ float v[128];
+  __shared__ float s_sum;
+  const int lane = threadIdx.x;
+  for (int p = blockIdx.x; p < num_pts; p += gridDim.x) {
+    cusift_point *pt = points + p;
+    v[lane] = pt->data[lane];
+    v[lane + 64] = pt->data[lane + 64];
+    __syncthreads();
+    if (lane == 0) {
+      float sum = 0.0f;
+      for (int i = 0; i < 128; ++i) sum += v[i];
+      s_sum = sum;
+    }
+    __syncthreads();
+    const float sum = s_sum;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float x = v[lane + 64 * r];
+      const double m = x > 0.0 ? (double)x : 0.0;
+      pt->data[lane + 64 * r] = sqrtf((float)(m / sum));
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace cusift

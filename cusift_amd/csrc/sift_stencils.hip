@@ -1,4 +1,5 @@
-// sift_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the SIFT extraction path.
+// sift_stencils.hip -- hand-written gfx950 (CDNA4) kernels of the SIFT extraction path: the image-sized
+// stencils (ScaleDown, blur+DoG, extrema, and their fusion).  Keypoint kernels: sift_keypoints.hip.
 //
 // Design (DESIGN.md has the full account):
 //  * The two HBM-bound stencils (blur+DoG, extrema) are "wave-autonomous column strips": a 64-lane
@@ -10,47 +11,9 @@
 //    reads the point count from device memory -- no host read-back between stages.
 //  * Arithmetic follows oracle/sift_oracle.c operation by operation (explicit fmaf chains in the
 //    filters, nothing else fused: this file is built with -ffp-contract=off).
-#include <hip/hip_runtime.h>
-
-#include "sift_types.h"
+#include "sift_device.h"
 
 namespace cusift {
-
-// ------------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-// global row -> row of the local band: clamp to the global image (the reference's border rule), translate,
-// then clamp into the band (memory safety only: with enough halo the second clamp never acts)
-__device__ __forceinline__ int local_row(int y_global, int h_local, RowWindow rw) {
-  return clampi(clampi(y_global, 0, rw.hg - 1) - rw.row0, 0, h_local - 1);
-}
-
-// lane i receives the value of lane i-1 (lane 0 receives 0): DPP wave_shr:1.  bound_ctrl makes the hardware
-// write 0 for the lane without a source, so no "old" value has to be materialised in front of every DPP move.
-__device__ __forceinline__ float from_prev_lane(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-// lane i receives the value of lane i+1 (lane 63 receives 0): DPP wave_shl:1
-__device__ __forceinline__ float from_next_lane(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-
-// XCD-aware work mapping.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each
-// with its own L2), so spatially adjacent tiles would land on different L2s and fetch their shared
-// halo lines twice.  Remapping id -> (id % 8) * (total / 8) + id / 8 gives every XCD a contiguous
-// run of tiles, dispatched in order, so neighbours meet in one L2.  Placement only affects speed.
-__device__ __forceinline__ void xcd_remap(int &bx, int &by, int &bz) {
-  const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
-  const int total = nx * ny * nz;
-  if ((total & 7) != 0) return;
-  int id = (bz * ny + by) * nx + bx;
-  id = (id & 7) * (total >> 3) + (id >> 3);
-  bx = id % nx;
-  const int t = id / nx;
-  by = t % ny;
-  bz = t / ny;
-}
 
 // ------------------------------------------------------------------------------------------------
 // ScaleDown: 5x5 separable low-pass + 2x decimation.  Reference: ScaleDown_D, cuSIFT_D.cu:37-182.
@@ -215,14 +178,6 @@ __global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restr
 //    check of a per-row buffer descriptor (num_records = w*4) -- no divergent branches in the loop.
 //  * the next source row is requested one full iteration before it is needed.
 // ------------------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-constexpr unsigned int kBufFlags = 0x00020000u;  // raw buffer, 32-bit data format (gfx9/CDNA dword 3)
-constexpr int kOobOffset = 0x7fffffff;           // lane offset beyond any num_records: store dropped
-
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 dpp_prev2(f2 v) { return f2{from_prev_lane(v.x), from_prev_lane(v.y)}; }
@@ -933,433 +888,6 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
     row_step(yy + 1, DB, DC, DA);
     if (yy + 2 > yb) break;
     row_step(yy + 2, DC, DA, DB);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Software model of the CUDA texture fetch the reference relies on (gfx950 has no image unit):
-// tex2D<float>(x, y), cudaFilterModeLinear, clamp, unnormalised coordinates (cuSIFT.cu:227-233).
-// xB = x - 0.5, i = floor(xB), alpha = frac(xB) rounded to `frac_bits` bits.  Same operation order
-// as oracle_tex2d.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw, float x,
-                                       float y, float q, float inv_q) {
-  const float xb = x - 0.5f, yb = y - 0.5f;
-  float fx = floorf(xb), fy = floorf(yb);
-  float a = xb - fx, b = yb - fy;
-  if (q > 0.0f) {
-    a = floorf(a * q + 0.5f) * inv_q;  // q is a power of two: * inv_q == / q exactly
-    b = floorf(b * q + 0.5f) * inv_q;
-  }
-  fx = fminf(fmaxf(fx, -1.0f), (float)w);
-  fy = fminf(fmaxf(fy, -1.0f), (float)rw.hg);
-  const int i = (int)fx, j = (int)fy;
-  const int i0 = clampi(i, 0, w - 1), i1 = clampi(i + 1, 0, w - 1);
-  const int j0 = local_row(j, h, rw), j1 = local_row(j + 1, h, rw);
-  const float s00 = img[(long)j0 * pitch + i0], s10 = img[(long)j0 * pitch + i1];
-  const float s01 = img[(long)j1 * pitch + i0], s11 = img[(long)j1 * pitch + i1];
-  const float ia = 1.0f - a, ib = 1.0f - b;
-  float t = (ia * ib) * s00;
-  t = t + (a * ib) * s10;
-  t = t + (ia * b) * s01;
-  t = t + (a * b) * s11;
-  return t;
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-staged image patches for the keypoint kernels.  A patch holds S[clamp(y0+r)][clamp(x0+c)] for the
-// UNCLAMPED coordinates (x0+c, y0+r), so a bilinear fetch whose 2x2 footprint lies inside the patch reads
-// exactly the pixels the clamping texture model would (a footprint clamped at the border interpolates
-// between equal values in both cases).  tex2d_patch() is tex2d() operation for operation, reading LDS.
-// ------------------------------------------------------------------------------------------------
-struct PatchGeom {
-  int x0, y0;  // image coordinate of patch element (0,0)
-  int stride;  // floats per patch row
-};
-
-__device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
-                                            float *lds, const PatchGeom &g, int pw, int ph, int lane) {
-  // rows of up to 32 columns are loaded two at a time, wider rows one at a time (wave-uniform choice)
-  const int cols = pw <= 32 ? 32 : 64;
-  const int rows_per_iter = 64 / cols;
-  const int c = lane & (cols - 1), rsub = lane / cols;
-  const int col = clampi(g.x0 + c, 0, w - 1);
-  for (int r = rsub; r < ph; r += rows_per_iter) {
-    const int row = local_row(g.y0 + r, h, rw);
-    if (c < pw) lds[r * g.stride + c] = img[(long)row * pitch + col];
-  }
-}
-
-__device__ __forceinline__ float tex2d_patch(const float *lds, const PatchGeom &g, float x, float y, float q,
-                                             float inv_q) {
-  const float xb = x - 0.5f, yb = y - 0.5f;
-  const float fx = floorf(xb), fy = floorf(yb);
-  float a = xb - fx, b = yb - fy;
-  if (q > 0.0f) {
-    a = floorf(a * q + 0.5f) * inv_q;
-    b = floorf(b * q + 0.5f) * inv_q;
-  }
-  const int i = (int)fx - g.x0, j = (int)fy - g.y0;
-  const float *p0 = lds + j * g.stride + i;
-  const float *p1 = p0 + g.stride;
-  const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
-  const float ia = 1.0f - a, ib = 1.0f - b;
-  float t = (ia * ib) * s00;
-  t = t + (a * ib) * s10;
-  t = t + (ia * b) * s01;
-  t = t + (a * b) * s11;
-  return t;
-}
-
-// ------------------------------------------------------------------------------------------------
-// ComputeOrientations: reference ComputeOrientations_D, cuSIFT_D.cu:319-396.
-// One wave per keypoint (persistent grid over [first, min(count,max_pts)) read from device memory).
-// 121 samples (11x11) -> 32-bin histogram in LDS.  The histogram is accumulated by lanes 0..31, each
-// walking the samples in index order, so the sums are deterministic and in the oracle's order.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) orientations_kernel(const float *__restrict__ img, int w, int h, int pitch,
-                                                         long img_stride, cusift_point *__restrict__ points,
-                                                         int max_pts, const unsigned int *__restrict__ first,
-                                                         const unsigned int *__restrict__ counters, float q,
-                                                         float inv_q, RowWindow rw) {
-  __shared__ float hist[64];
-  __shared__ float gauss[11];
-  __shared__ float2 s_sample[128];  // (bin as float bits, weight)
-  __shared__ float patch[16 * 16];
-  const int tx = threadIdx.x;
-  img += (long)blockIdx.y * img_stride;
-  points += (long)blockIdx.y * max_pts;
-  const unsigned int fst = first ? first[blockIdx.y] : 0u;
-  const unsigned int cnt = counters[blockIdx.y];
-  const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
-
-  for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
-    cusift_point *pt = points + bx;
-    const float scale = pt->scale;
-    const float kx = pt->coords2D[0], ky = pt->coords2D[1];
-    const float i2sigma2 = -1.0f / (4.5f * scale * scale);
-    if (tx < 11) gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
-    const float xp = kx - 5.0f;
-    const float yp = ky - 5.0f;
-    // every tap lies in [k-6, k+6]: its 2x2 footprint starts at floor(k-6.5) .. floor(k+5.5) -> a 16x16 patch
-    // (one spare column/row on each side).  Non-finite or absurd coordinates take the global path.
-    const bool use_patch = (fabsf(kx) < 1e6f) && (fabsf(ky) < 1e6f);
-    PatchGeom g;
-    g.x0 = (int)floorf(kx - 6.5f) - 1;
-    g.y0 = (int)floorf(ky - 6.5f) - 1;
-    g.stride = 16;
-    if (use_patch) {
-      const int col = clampi(g.x0 + (tx & 15), 0, w - 1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = (tx >> 4) + 4 * r;
-        patch[rr * 16 + (tx & 15)] = img[(long)local_row(g.y0 + rr, h, rw) * pitch + col];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      const int t = tx + 64 * rep;
-      if (t < 121) {
-        const int yd = t / 11;
-        const int xd = t - yd * 11;
-        const float xf = xp + xd;
-        const float yf = yp + yd;
-        float dx, dy;
-        if (use_patch) {
-          dx = tex2d_patch(patch, g, xf + 1.0f, yf, q, inv_q) - tex2d_patch(patch, g, xf - 1.0f, yf, q, inv_q);
-          dy = tex2d_patch(patch, g, xf, yf + 1.0f, q, inv_q) - tex2d_patch(patch, g, xf, yf - 1.0f, q, inv_q);
-        } else {
-          dx = tex2d(img, w, h, pitch, rw, xf + 1.0f, yf, q, inv_q) - tex2d(img, w, h, pitch, rw, xf - 1.0f, yf, q, inv_q);
-          dy = tex2d(img, w, h, pitch, rw, xf, yf + 1.0f, q, inv_q) - tex2d(img, w, h, pitch, rw, xf, yf - 1.0f, q, inv_q);
-        }
-        int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
-        if (bin > 31 || bin < 0) bin = 0;  // < 0 only for non-finite input
-        const float grad = sqrtf(dx * dx + dy * dy);
-        s_sample[t] = make_float2(__int_as_float(bin), grad * gauss[xd] * gauss[yd]);
-      }
-    }
-    __syncthreads();
-    if (tx < 32) {
-      // bins are lanes; samples are walked in index order so the sums are the oracle's, bit for bit
-      float acc = 0.0f;
-#pragma unroll 11
-      for (int t = 0; t < 121; ++t) {
-        const float2 sv = s_sample[t];
-        if (__float_as_int(sv.x) == tx) acc += sv.y;
-      }
-      hist[tx] = acc;
-    }
-    __syncthreads();
-    const int x1m = (tx >= 1 ? tx - 1 : tx + 31);
-    const int x1p = (tx <= 30 ? tx + 1 : tx - 31);
-    if (tx < 32) {
-      const int x2m = (tx >= 2 ? tx - 2 : tx + 30);
-      const int x2p = (tx <= 29 ? tx + 2 : tx - 30);
-      hist[tx + 32] = 6.0f * hist[tx] + 4.0f * (hist[x1m] + hist[x1p]) + (hist[x2m] + hist[x2p]);
-    }
-    __syncthreads();
-    float pk = 0.0f;
-    if (tx < 32) {
-      const float v = hist[32 + tx];
-      pk = (v > hist[32 + x1m] && v >= hist[32 + x1p]) ? v : 0.0f;
-    }
-    __syncthreads();
-    if (tx < 32) hist[tx] = pk;
-    __syncthreads();
-    if (tx == 0) {
-      float maxval1 = 0.0f;
-      int i1 = -1;
-      for (int i = 0; i < 32; ++i) {
-        const float v = hist[i];
-        if (v > maxval1) {
-          maxval1 = v;
-          i1 = i;
-        }
-      }
-      const float val1 = hist[32 + ((i1 + 1) & 31)];
-      const float val2 = hist[32 + ((i1 + 31) & 31)];
-      const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
-      pt->orientation = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-    }
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// ExtractSiftDescriptors: reference ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.
-// One wave per keypoint, no LDS float atomics (ds_add_f32 retires one lane at a time on gfx950:
-// ~150 cycles per wave instruction, measured -- it was half of this kernel's time).
-//   phase 0  the pixels the 1024 bilinear taps can touch are staged in LDS with coalesced row loads
-//            (kDescPatch^2 floats; larger keypoints sample global memory directly).
-//   phase 1  the 16x16 rotated sample grid, 4 samples per lane: gradient magnitude (with the Gaussian
-//            window), angle bin and angle fraction go to LDS.
-//   phase 2  gather: lane l = (cell l/4, row pair l%4) walks its 2x8 share of the 8x8 samples that reach
-//            its histogram cell, forms the same products as the reference (horizontal, vertical, then
-//            angle weight) and accumulates them into a private 8-bin LDS histogram (plain read-add-write,
-//            lane-private rows, stride 9 -> conflict free).  The reference's column-14 spill into the
-//            next row's first cell (guard `tx<=14`, cuSIFT_D.cu:243) is gathered the same way; its
-//            angle-index-8 spill (atan2f == +pi) is rare and goes through one LDS atomic.
-//   phase 3  the 4 partial histograms of each cell are summed in a fixed order; L2-normalise, clamp at
-//            0.2, L2-normalise with the reference's reduction tree; scale the keypoint by `subsampling`.
-// The order of the sums is fixed, so results are reproducible run to run.
-// ------------------------------------------------------------------------------------------------
-constexpr int kDescPatch = 40;  // LDS patch edge: covers descriptor windows up to scale ~2.1 at 45 degrees
-
-__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float *__restrict__ fin, int next_cell_base,
-                                              float grad, float angf, int angi, float wx, float wy) {
-  const float grad1 = wx * grad;
-  const float grad2 = wy * grad1;
-  const float v1 = (1.0f - angf) * grad2;
-  const float v2 = angf * grad2;
-  if (angi < 8) {
-    myhist[angi] += v1;
-  } else if (next_cell_base < 128) {
-    atomicAdd(fin + next_cell_base, v1);  // index angi+hist+off = 8 + ...: bin 0 of the next linear cell
-  }
-  const int angp = (angi < 7 ? angi + 1 : 0);
-  myhist[angp] += v2;
-}
-
-__global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict__ img, int w, int h, int pitch,
-                                                        long img_stride, cusift_point *__restrict__ points,
-                                                        int max_pts, const unsigned int *__restrict__ first,
-                                                        const unsigned int *__restrict__ counters, float subsampling,
-                                                        float q, float inv_q, RowWindow rw) {
-  __shared__ float s_grad[256];
-  __shared__ float s_angf[256];
-  __shared__ int s_angi[256];
-  __shared__ float s_hist[64 * 9];
-  __shared__ float fin[128];
-  __shared__ float sums[64];
-  __shared__ float patch[kDescPatch * kDescPatch];
-  const int lane = threadIdx.x;
-  img += (long)blockIdx.y * img_stride;
-  points += (long)blockIdx.y * max_pts;
-  const unsigned int fst = first ? first[blockIdx.y] : 0u;
-  const unsigned int cnt = counters[blockIdx.y];
-  const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
-
-  // phase-1 constants of this lane: sample idx = lane + 64*step -> column tx = lane%16, row y = lane/16 + 4*step
-  const int tx1 = lane & 15;
-  const float gx1 = expf(-(tx1 - 7.5f) * (tx1 - 7.5f) / 128.0f);
-  float gy1[4];
-#pragma unroll
-  for (int step = 0; step < 4; ++step) {
-    const int y = (lane >> 4) + 4 * step;
-    gy1[step] = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
-  }
-  // phase-2 geometry of this lane (independent of the keypoint)
-  const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
-  float *myhist = s_hist + lane * 9;
-  const int next_cell_base = 8 * (cell + 1);
-
-  for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
-    cusift_point *pt = points + bx;
-    const float theta = 2.0f * 3.1415f / 360.0f * pt->orientation;
-    const float sina = sinf(theta);
-    const float cosa = cosf(theta);
-    const float scale = 12.0f / 16.0f * pt->scale;
-    const float ssina = scale * sina;
-    const float scosa = scale * cosa;
-    const float px = pt->coords2D[0], py = pt->coords2D[1];
-    fin[lane] = 0.0f;
-    fin[lane + 64] = 0.0f;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) myhist[b] = 0.0f;
-
-    // ---- phase 0: stage the sampled neighbourhood in LDS when it fits (it does for scale <~ 2.5) ----
-    // every tap is within `reach` of the keypoint: 7.5*spacing*(|cos|+|sin|) for the grid + 1 for the tap
-    const float reach = 7.5f * scale * (fabsf(cosa) + fabsf(sina)) + 1.0f + 0.01f;
-    PatchGeom g;
-    g.stride = kDescPatch;
-    g.x0 = (int)floorf(px - reach - 0.5f) - 1;
-    g.y0 = (int)floorf(py - reach - 0.5f) - 1;
-    const int pw = (int)floorf(px + reach - 0.5f) + 2 - g.x0 + 1;
-    const int ph = (int)floorf(py + reach - 0.5f) + 2 - g.y0 + 1;
-    const bool use_patch = (reach < 0.5f * kDescPatch) && (fabsf(px) < 1e6f) && (fabsf(py) < 1e6f) &&
-                           pw <= kDescPatch && ph <= kDescPatch;  // wave-uniform
-    if (use_patch) stage_patch(img, w, h, pitch, rw, patch, g, pw, ph, lane);
-    __syncthreads();
-
-    // ---- phase 1: samples ----
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-      const int idx = lane + 64 * step;
-      const int y = idx >> 4, tx = tx1;
-      const float gy = gy1[step], gx = gx1;
-      const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
-      const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
-      float dx, dy;
-      if (use_patch) {
-        dx = tex2d_patch(patch, g, xpos + cosa, ypos + sina, q, inv_q) -
-             tex2d_patch(patch, g, xpos - cosa, ypos - sina, q, inv_q);
-        dy = tex2d_patch(patch, g, xpos - sina, ypos + cosa, q, inv_q) -
-             tex2d_patch(patch, g, xpos + sina, ypos - cosa, q, inv_q);
-      } else {
-        dx = tex2d(img, w, h, pitch, rw, xpos + cosa, ypos + sina, q, inv_q) -
-             tex2d(img, w, h, pitch, rw, xpos - cosa, ypos - sina, q, inv_q);
-        dy = tex2d(img, w, h, pitch, rw, xpos - sina, ypos + cosa, q, inv_q) -
-             tex2d(img, w, h, pitch, rw, xpos + sina, ypos - cosa, q, inv_q);
-      }
-      const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
-      float angf = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;
-      int angi = (int)angf;
-      angf -= angi;
-      if (angi < 0 || angi > 8) angi = 0;  // only for non-finite input
-      s_grad[idx] = grad;
-      s_angf[idx] = angf;
-      s_angi[idx] = angi;
-    }
-    __syncthreads();
-
-    // ---- phase 2: gather into the lane-private histogram ----
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int y = 4 * vi - 2 + 2 * kq + r;
-      if (y >= 0 && y <= 15) {
-        const int veri = (y + 2) / 4 - 1;
-        const float verf = (y - 1.5f) / 4.0f - veri;
-        const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
-#pragma unroll
-        for (int cx = 0; cx < 8; ++cx) {
-          const int tx = 4 * hi - 2 + cx;
-          if (tx >= 0 && tx <= 15) {
-            const int hori = (tx + 2) / 4 - 1;
-            const float horf = (tx - 1.5f) / 4.0f - hori;
-            const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
-            const int idx = y * 16 + tx;
-            gather_sample(myhist, fin, next_cell_base, s_grad[idx], s_angf[idx], s_angi[idx], wx, wy);
-          }
-        }
-      }
-    }
-    if (hi == 0 && vi >= 1) {
-      // the reference's right-hand adds of column 14 (hori+1 == 4) land in cell (row+1, 0)
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int y = 4 * (vi - 1) - 2 + 2 * kq + r;
-        if (y >= 0 && y <= 15) {
-          const int veri = (y + 2) / 4 - 1;
-          const float verf = (y - 1.5f) / 4.0f - veri;
-          const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
-          const float horf = (14 - 1.5f) / 4.0f - 3;
-          const int idx = y * 16 + 14;
-          gather_sample(myhist, fin, next_cell_base, s_grad[idx], s_angf[idx], s_angi[idx], horf, wy);
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- phase 3: cell sums (fixed order) and normalisation ----
-    float bsum[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int b = lane + 64 * r;
-      const float *hc = s_hist + (b >> 3) * 4 * 9 + (b & 7);
-      bsum[r] = ((hc[0] + hc[9]) + hc[18]) + hc[27];
-    }
-    float b0 = fin[lane] + bsum[0], b1 = fin[lane + 64] + bsum[1];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      sums[lane] = b0 * b0 + b1 * b1;
-      __syncthreads();
-      if (lane < 32) sums[lane] = sums[lane] + sums[lane + 32];
-      __syncthreads();
-      if (lane < 16) sums[lane] = sums[lane] + sums[lane + 16];
-      __syncthreads();
-      if (lane < 8) sums[lane] = sums[lane] + sums[lane + 8];
-      __syncthreads();
-      if (lane < 4) sums[lane] = sums[lane] + sums[lane + 4];
-      __syncthreads();
-      const float tsum = sums[0] + sums[1] + sums[2] + sums[3];
-      const float r = 1.0f / sqrtf(tsum);
-      b0 = b0 * r;
-      b1 = b1 * r;
-      if (pass == 0) {
-        if (b0 > 0.2f) b0 = 0.2f;
-        if (b1 > 0.2f) b1 = 0.2f;
-      }
-      __syncthreads();
-    }
-    pt->data[lane] = b0;
-    pt->data[lane + 64] = b1;
-    if (lane == 0) {
-      pt->coords2D[0] = px * subsampling;
-      pt->coords2D[1] = py * subsampling;
-      pt->scale = pt->scale * subsampling;
-    }
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// ConvertSiftToRootSift: reference cuSIFT_D.cu:299-317 (sequential L1 sum, sqrt(max(0,v)/sum)).
-// One wave per point; the 128-term sum is kept sequential (lane 0) to match the reference order.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) rootsift_kernel(cusift_point *__restrict__ points, int num_pts) {
-  __shared__ float v[128];
-  __shared__ float s_sum;
-  const int lane = threadIdx.x;
-  for (int p = blockIdx.x; p < num_pts; p += gridDim.x) {
-    cusift_point *pt = points + p;
-    v[lane] = pt->data[lane];
-    v[lane + 64] = pt->data[lane + 64];
-    __syncthreads();
-    if (lane == 0) {
-      float sum = 0.0f;
-      for (int i = 0; i < 128; ++i) sum += v[i];
-      s_sum = sum;
-    }
-    __syncthreads();
-    const float sum = s_sum;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const float x = v[lane + 64 * r];
-      const double m = x > 0.0 ? (double)x : 0.0;
-      pt->data[lane + 64 * r] = sqrtf((float)(m / sum));
-    }
-    __syncthreads();
   }
 }
 

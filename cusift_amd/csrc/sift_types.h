@@ -55,6 +55,16 @@ struct RowWindow {
   int hg;
 };
 
+// Per-octave base images of a batch, passed by value to describe_all_kernel (driver path).
+constexpr int kMaxFlatImages = 256;  // batch size up to which the flattened keypoint kernel is used
+struct OctaveTable {
+  const float *base[kMaxOctaves];  // image 0 of octave o
+  long stride[kMaxOctaves];        // floats between images
+  int w[kMaxOctaves], h[kMaxOctaves], pitch[kMaxOctaves];
+  float sub[kMaxOctaves];          // subsampling of octave o (sub[0] * 2^o)
+  int n_oct;
+};
+
 struct FindParams {
   float thr_pos;            // d_Threshold[0] = +peakThresh   (cuSIFT.cu:432)
   float thr_neg;            // d_Threshold[1] = -peakThresh

@@ -68,7 +68,8 @@ typedef struct cusift_params {
   int max_pts;         /* capacity per image (SiftData::maxPts) */
   int tex_frac_bits;   /* bilinear fraction bits of the texture-unit model: 8 = as the reference ran, 0 = fp32 */
   int fused_detect;    /* 1 (default): the drivers run LaplaceMulti+FindPointsMulti as one kernel that keeps the
-                          DoG planes on chip (identical results); 0: the two reference stages, DoG in HBM */
+                          DoG planes on chip, and orientation+descriptor of all octaves as one launch after the
+                          last detection (identical results); 0: the reference's per-octave stage sequence */
 } cusift_params;
 
 typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */
@@ -98,11 +99,11 @@ int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift
 size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
 /* Per-stage GPU timing with HIP events on the context's stream (TimerGPU, cutils.h:94-114, used at
  * cuSIFT.cu:64,177,208,238,249).  Stages: 0 ScaleDown, 1 LaplaceMulti, 2 FindPointsMulti,
- * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call, 6 fused detection.  Accumulates
+ * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call, 6 fused detection, 7 orientation+descriptor of all octaves in one launch.  Accumulates
  * milliseconds and launch counts until reset.  cusift_ctx_timing_read blocks. */
 enum { CUSIFT_STAGE_SCALEDOWN = 0, CUSIFT_STAGE_LAPLACE = 1, CUSIFT_STAGE_FINDPOINTS = 2,
        CUSIFT_STAGE_ORIENT = 3, CUSIFT_STAGE_DESCR = 4, CUSIFT_STAGE_TOTAL = 5, CUSIFT_STAGE_DETECT = 6,
-       CUSIFT_NUM_STAGES = 7 };
+       CUSIFT_STAGE_DESCRIBE_ALL = 7, CUSIFT_NUM_STAGES = 8 };
 int cusift_ctx_timing_enable(cusift_ctx *ctx, int on);
 int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGES], int launches[CUSIFT_NUM_STAGES]);
 int cusift_ctx_timing_reset(cusift_ctx *ctx);
