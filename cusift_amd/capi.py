@@ -79,6 +79,7 @@ SIGNATURES = {
     "cusift_ctx_timing_enable": (_i, [_vp, _i]),
     "cusift_ctx_timing_read": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
     "cusift_ctx_timing_reset": (_i, [_vp]),
+    "cusift_kernel_occupancy": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "cusift_malloc": (_i, [C.POINTER(_vp), _sz]),
     "cusift_free": (_i, [_vp]),
     "cusift_memset": (_i, [_vp, _vp, _i, _sz]),
@@ -306,6 +307,13 @@ class Context:
         check(lib().cusift_extract_host(self.handle, img.ctypes.data, w, h, C.byref(params), d_points, hp,
                                         C.byref(n)))
         return n.value
+
+
+def kernel_occupancy(name):
+    """(resident workgroups per CU, threads per workgroup) of a named kernel; needs a GPU."""
+    n, t = C.c_int(0), C.c_int(0)
+    check(lib().cusift_kernel_occupancy(name.encode(), C.byref(n), C.byref(t)))
+    return n.value, t.value
 
 
 def laplace_taps(init_blur):

@@ -24,6 +24,7 @@ __global__ void laplace_multi_kernel(const float *, float *, int, int, int, long
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                         FindParams);
+template <bool kIdent0>
 __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                     LaplaceTapsPk, FindParams, RowWindow, int, int);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
@@ -220,6 +221,10 @@ int ensure_arena(cusift_ctx *ctx, size_t bytes) {
 // rows each wave marches: as large as possible (less halo re-read) while the launch still has
 // >= ~2 waves per SIMD on 256 CUs.
 int pick_rows(int h, int strips, int n_images, int lo, int hi) {
+  if (const char *e = getenv("CUSIFT_ROWS_PER_WAVE")) {  // tuning/experiments only
+    const int r = atoi(e);
+    if (r > 0) return r;
+  }
   const long target_waves = 256L * 4 * 2 * 2;
   long r = (long)h * strips * n_images / target_waves;
   if (r < lo) r = lo;
@@ -437,6 +442,25 @@ extern "C" int cusift_ctx_timing_reset(cusift_ctx *ctx) {
     ctx->ms[i] = 0.f;
     ctx->launches[i] = 0;
   }
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, int *threads_per_block) {
+  if (!kernel || !blocks_per_cu || !threads_per_block) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  const std::string k(kernel);
+  int n = 0, t = 256;
+  hipError_t e = hipErrorInvalidValue;
+  if (k == "detect_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false>, t, 0);
+  else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel, t, 0);
+  else if (k == "find_points") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, find_points_fast_kernel, t, 0);
+  else if (k == "scale_down") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scale_down_fast_kernel, t, 0);
+  else if (k == "describe_all") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, describe_all_kernel, t = 64, 0);
+  else if (k == "orientations") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, orientations_kernel, t = 64, 0);
+  else if (k == "descriptors") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, descriptors_kernel, t = 64, 0);
+  else return fail(CUSIFT_ERR_INVALID, "unknown kernel '%s'", kernel);
+  if (e != hipSuccess) return fail(CUSIFT_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
+  *blocks_per_cu = n;
+  *threads_per_block = t;
   return CUSIFT_OK;
 }
 
@@ -660,9 +684,17 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   const int strips = idiv_up(w, 240);  // kDetStrip
   const int rows = pick_rows(rows_total, strips, n_images, 8, 32);
   dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), kWavesPerBlock), n_images);
+  // levels 0 and 1 both identity (initBlur >= their sigma)?  then the kernel passes them through
+  bool ident0 = true;
+  for (int lv = 0; lv < 2; ++lv)
+    for (int j = 0; j < 9; ++j) ident0 = ident0 && (taps[16 * lv + j] == (j == kBlurRadius ? 1.0f : 0.0f));
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
-  hipLaunchKernelGGL(detect_fused_kernel, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
-                     d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
+  if (ident0 && !getenv("CUSIFT_NO_IDENT"))
+    hipLaunchKernelGGL(detect_fused_kernel<true>, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch,
+                       (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
+  else
+    hipLaunchKernelGGL(detect_fused_kernel<false>, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch,
+                       (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   return check_launch("detect_multi");
 }
 

@@ -652,6 +652,10 @@ constexpr int kDetHaloLanes = 2;
 constexpr int kDetStrip = (64 - 2 * kDetHaloLanes) * kBlurCols;  // 240 columns of extremum centres per wave
 constexpr int kCubeCols = 64 * kBlurCols;                        // 256 floats per cube row
 
+// kIdent0: levels 0 and 1 have identity taps (initBlur >= their sigma: the "var <= 1e-6 => identity" rule, e.g.
+// octave 0 of the initBlur = 1.0 configuration).  1*c and fma(0, x, c) are exact for finite x, so the pair is
+// passed through instead of being filtered: L0 = L1 = S, DoG plane 0 = 0 -- bit-identical, 24 % less arithmetic.
+template <bool kIdent0>
 __device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTapsPk &T, f4 (&D)[kNumDog]) {
   const f4 ctr = win[4];
   const f4 p1 = win[3] + win[5];
@@ -659,8 +663,13 @@ __device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTa
   const f4 p3 = win[1] + win[7];
   const f4 p4 = win[0] + win[8];
   float prev_hi[4];
+  if (kIdent0) {
+    D[0] = f4{0.f, 0.f, 0.f, 0.f};  // S - S
 #pragma unroll
-  for (int q = 0; q < kNumLevels / 2; ++q) {
+    for (int j = 0; j < 4; ++j) prev_hi[j] = ctr[j];
+  }
+#pragma unroll
+  for (int q = kIdent0 ? 1 : 0; q < kNumLevels / 2; ++q) {
     const f2 k0 = T.k[q][0], k1 = T.k[q][1], k2 = T.k[q][2], k3 = T.k[q][3], k4 = T.k[q][4];
     f2 e[12];
 #pragma unroll
@@ -744,6 +753,7 @@ __device__ __forceinline__ void refine_from_cube(const float *cube, int col, int
   pt->subsampling = P.subsampling;
 }
 
+template <bool kIdent0>
 __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
                                                           long img_stride, cusift_point *__restrict__ points,
                                                           int max_pts, unsigned int *__restrict__ counters,
@@ -795,7 +805,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
   auto row_step = [&](int yy, f4 (&D0)[kNumDog], f4 (&D1)[kNumDog], f4 (&D2)[kNumDog]) {
     const f4 nxt = ahead;        // requested one iteration ago
     ahead = load_row(yy + 6);    // needed two iterations from now
-    blur_dog_row(win, T, D2);
+    blur_dog_row<kIdent0>(win, T, D2);
 
     if (yy >= ya + 1) {
       const int y = yy - 1;  // centre row: D0 = y-1, D1 = y, D2 = y+1
@@ -909,5 +919,10 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
     row_step(yy + 2, DC, DA, DB);
   }
 }
+
+template __global__ void detect_fused_kernel<false>(const float *, int, int, int, long, cusift_point *, int,
+                                                    unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, int, int);
+template __global__ void detect_fused_kernel<true>(const float *, int, int, int, long, cusift_point *, int,
+                                                   unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, int, int);
 
 }  // namespace cusift

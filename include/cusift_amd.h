@@ -108,6 +108,11 @@ int cusift_ctx_timing_enable(cusift_ctx *ctx, int on);
 int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGES], int launches[CUSIFT_NUM_STAGES]);
 int cusift_ctx_timing_reset(cusift_ctx *ctx);
 
+/* Introspection for DESIGN.md / tuning: resident workgroups per CU of a named kernel ("detect_fused",
+ * "laplace_multi", "find_points", "scale_down", "describe_all", "orientations", "descriptors") according to
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor. */
+int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, int *threads_per_block);
+
 /* ---- device memory helpers (so a host program needs no HIP headers) ----------------------- */
 /* cuImage::Allocate / SiftData ctor: cudaMallocPitch / cudaMalloc (cuImage.cu:30, cuSIFT.cu:29) */
 int cusift_malloc(void **d_ptr, size_t bytes);
