@@ -27,7 +27,7 @@ __global__ void write_only(f4* __restrict__ out, long n4, long plane4) {
 // (C) strip pattern: wave owns `cols` columns (lanes write 16 B each, lanes [lo,hi) active), marches `rows` rows,
 //     7 planes per row; strips start at strip*valid columns.  cols=256: valid=248 -> unaligned 992-B segments; valid=256 -> aligned
 __global__ void strip_pattern(const float* __restrict__ in, float* __restrict__ out, int w, int h, int pitch, int rows_per_wave,
-                              int valid, int do_read, int swz, int horiz) {
+                              int valid, int do_read, int swz, int horiz, int nt) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (swz) {  // XCD-aware remap: blocks that share an XCD (same linear id mod 8) take consecutive strips
@@ -54,7 +54,10 @@ __global__ void strip_pattern(const float* __restrict__ in, float* __restrict__ 
     if (do_read) acc += *(const f4*)(in + img_off + (long)y * pitch + cl);
     if (writer) {
 #pragma unroll
-      for (int p = 0; p < 7; ++p) *(f4*)(out + img_off * 7 + p * plane + (long)y * pitch + c0) = acc + (float)p;
+      for (int p = 0; p < 7; ++p) {
+        f4* dst = (f4*)(out + img_off * 7 + p * plane + (long)y * pitch + c0);
+        if (nt) __builtin_nontemporal_store(acc + (float)p, dst); else *dst = acc + (float)p;
+      }
     }
   }
 }
@@ -97,13 +100,13 @@ int main() {
   }
   timeit("D read-only (7 planes = 3.7 GB)", wr, [&] { hipLaunchKernelGGL(read_only, dim3(4096), dim3(256), 0, 0, (const f4*)out, in, n4 * 7); });
   for (int rows : {32}) {
-    for (int valid : {248, 224}) {
-      for (int horiz : {0, 1}) for (int swz : {0, 1}) {
+    for (int valid : {224, 256}) {
+      for (int nt : {0, 1}) for (int swz : {0, 1}) {
         char nm[96];
-        snprintf(nm, 96, "C strips valid=%d rows/wave=%d horiz=%d xcd_swizzle=%d", valid, rows, horiz, swz);
+        snprintf(nm, 96, "C strips valid=%d rows/wave=%d nontemporal=%d xcd_swizzle=%d", valid, rows, nt, swz);
         const int strips = (w + valid - 1) / valid, chunks = (h + rows - 1) / rows;
-        dim3 grid = horiz ? dim3((strips + 3) / 4, chunks, n) : dim3(strips, (chunks + 3) / 4, n);
-        timeit(nm, rw, [&] { hipLaunchKernelGGL(strip_pattern, grid, dim3(256), 0, 0, in, out, w, h, pitch, rows, valid, 1, swz, horiz); });
+        dim3 grid = dim3(strips, (chunks + 3) / 4, n);
+        timeit(nm, rw, [&] { hipLaunchKernelGGL(strip_pattern, grid, dim3(256), 0, 0, in, out, w, h, pitch, rows, valid, 1, swz, 0, nt); });
       }
     }
   }
