@@ -100,6 +100,8 @@ SIGNATURES = {
     "cusift_scale_down_band": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f]),
     "cusift_detect_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i, _vp]),
     "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i]),
+    "cusift_match": (_i, [_vp, _vp, _i, _vp, _i, _i]),
+    "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_extract": (_i, [_vp, _vp, _i, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
     "cusift_extract_host": (_i, [_vp, _vp, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
@@ -288,6 +290,11 @@ class Context:
     def rootsift(self, d_points, num_pts):
         check(lib().cusift_rootsift(self.handle, d_points, num_pts))
 
+    # ---- matcher ----
+    def match(self, d_sift1, n1, d_sift2, n2, distance=1):
+        """MatchSiftData on device records: distance 1 = L2 (2 - 2 x.y), 0 = dot product."""
+        check(lib().cusift_match(self.handle, d_sift1, n1, d_sift2, n2, distance))
+
     # ---- drivers ----
     def extract_batch(self, d_imgs, n_images, w, h, pitch, image_stride, params, d_points, d_counters):
         check(lib().cusift_extract_batch(self.handle, d_imgs, n_images, w, h, pitch, image_stride, C.byref(params),
@@ -356,3 +363,11 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def match_filter(points, score_threshold=999.0, ambiguity_threshold=1.0):
+    """The host-side filter of MatchSiftData (extras/matching.cu:318-349, MatchType2D): indices of the points
+    whose score < scoreThreshold^2 and ambiguity < ambiguityThreshold^2."""
+    t2 = np.float32(score_threshold) * np.float32(score_threshold)
+    a2 = np.float32(ambiguity_threshold) * np.float32(ambiguity_threshold)
+    return np.nonzero((points["score"] < t2) & (points["ambiguity"] < a2))[0]

@@ -35,6 +35,7 @@ __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_po
                                    const unsigned int *, float, float, float, RowWindow);
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float);
 __global__ void rootsift_kernel(cusift_point *, int);
+__global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int);
 }  // namespace cusift
 
 using namespace cusift;
@@ -787,6 +788,29 @@ extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_
   dim3 grid(std::min(num_pts, 256 * 32));
   hipLaunchKernelGGL(rootsift_kernel, grid, dim3(64), 0, ctx->stream, d_points, num_pts);
   return check_launch("rootsift");
+}
+
+// ------------------------------------------------------------------------------------------------
+// matcher
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1, const cusift_point *d_sift2,
+                            int num_pts2, int distance) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (num_pts1 <= 0 || num_pts2 <= 0) return CUSIFT_OK;  // extras/matching.cu:241-242: nothing to match
+  if (!d_sift1 || !d_sift2) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: missing data");
+  if (distance != 0 && distance != 1) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: distance must be 0 or 1");
+  dim3 grid(idiv_up(num_pts1, 64));
+  hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, ctx->stream, d_sift1, num_pts1, d_sift2, num_pts2, distance);
+  return check_launch("match");
+}
+
+extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src,
+                                   size_t src_pitch, size_t width_bytes, size_t rows) {
+  if (!ctx || !h_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  if (rows == 0 || width_bytes == 0) return CUSIFT_OK;
+  HIP_TRY(hipMemcpy2DAsync(h_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

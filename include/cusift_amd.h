@@ -186,6 +186,18 @@ int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int 
                          cusift_point *d_points, int max_pts, const unsigned int *d_first,
                          const unsigned int *d_counter, float subsampling, int tex_frac_bits);
 
+/* ---- matcher (first consumer of SiftData) ----------------------------- */
+/* MatchSiftData(data1, data2, distance, ...), extras/matching.cu:232-362: for every point of d_sift1 the best
+ * and second-best point of d_sift2 under `distance` (0 = MatchSiftDistanceDotProduct, 1 = MatchSiftDistanceL2,
+ * extras/matching.h:10-13); writes score, ambiguity, match, match_xpos, match_ypos of d_sift1 (extras/matching.cu:
+ * 140-150,219-229).  The score/ambiguity thresholds of the reference are a host-side filter over those fields
+ * (:318-349) and stay on the caller's side (include/matching.h does it).  Asynchronous on the context's stream. */
+int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1, const cusift_point *d_sift2, int num_pts2,
+                 int distance);
+/* cudaMemcpy2D device->host (extras/matching.cu:311-315 copies the 5 match fields of every record); blocking. */
+int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch,
+                        size_t width_bytes, size_t rows);
+
 /* ---- drivers ------------------------------------------------------------------------------ */
 /* Batch form of ExtractSiftLoop/ExtractSiftOctave (cuSIFT.cu:175-270) on device-resident images.
  * Asynchronous on the context's stream: no host read-back, no allocation once the arena is sized.

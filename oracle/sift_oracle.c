@@ -535,3 +535,98 @@ int oracle_extract(const float *img, int w, int h, const oracle_params *prm, ora
   free(sub);
   return counter < prm->max_pts ? counter : prm->max_pts; /* cuSIFT.cu:110 */
 }
+
+/* ------------------------------------------------------------------------------------------
+ * MatchSiftData: extras/matching.cu.  FLT_MAX is redefined to 999.0 there (:3).
+ * ComputeDistance (:12-58): thread (ty=p1 in tile, tx=p2 in tile) sums pt1[itx]*pt2[itx] for i = 0..127 with
+ * itx = (i + tx) & 127, i.e. the summation starts at element (p2 mod 16) and wraps; nvcc fuses a*b+sum.
+ * Columns p2 >= numPts2 of the padded width hold -1 (dot) / 999 (L2).
+ * FindMinCorr / FindMaxCorr: thread tx scans columns tx, tx+16, ... keeping (best, second, index) with strict
+ * comparisons, then a tree over tx (len = 8,4,2,1) that keeps the lower tx on ties.
+ * ---------------------------------------------------------------------------------------- */
+#define MATCH_FLT_MAX 999.0f
+
+typedef struct {
+  float best, second;
+  int idx;
+} top2_t;
+
+void oracle_match_sift_data(oracle_sift_point *sift1, int n1, const oracle_sift_point *sift2, int n2, int distance) {
+  if (n1 <= 0 || n2 <= 0) return;
+  const int corrWidth = ((n2 + 15) / 16) * 16;
+  float *corr = (float *)malloc(sizeof(float) * (size_t)corrWidth);
+  for (int p1 = 0; p1 < n1; p1++) {
+    const float *a = sift1[p1].data;
+    for (int p2 = 0; p2 < corrWidth; p2++) {
+      if (p2 >= n2) {
+        corr[p2] = distance == 1 ? MATCH_FLT_MAX : -1.0f;
+        continue;
+      }
+      const float *b = sift2[p2].data;
+      const int tx = p2 & 15;
+      float sum = 0.0f;
+      for (int i = 0; i < 128; i++) {
+        const int itx = (i + tx) & 127;
+        sum = fmaf(a[itx], b[itx], sum);
+      }
+      if (distance == 1) corr[p2] = sum > -1.0f ? 2 - 2 * sum : MATCH_FLT_MAX; /* :71-72 */
+      else corr[p2] = sum;
+    }
+    top2_t t[16];
+    for (int tx = 0; tx < 16; tx++) {
+      t[tx].best = t[tx].second = distance == 1 ? MATCH_FLT_MAX : -1.0f;
+      t[tx].idx = -1;
+      for (int i = tx; i < corrWidth; i += 16) {
+        const float val = corr[i];
+        const int better = distance == 1 ? (val < t[tx].best) : (val > t[tx].best);
+        const int better2 = distance == 1 ? (val < t[tx].second) : (val > t[tx].second);
+        if (better) {
+          t[tx].second = t[tx].best;
+          t[tx].best = val;
+          t[tx].idx = i;
+        } else if (better2) {
+          t[tx].second = val;
+        }
+      }
+    }
+    for (int len = 8; len > 0; len /= 2) {
+      for (int tx = 0; tx < len; tx++) { /* tx < 8 in the kernel; entries >= len are dead afterwards */
+        const float val = t[tx + len].best;
+        const int i = t[tx + len].idx;
+        const int better = distance == 1 ? (val < t[tx].best) : (val > t[tx].best);
+        const int better2 = distance == 1 ? (val < t[tx].second) : (val > t[tx].second);
+        if (better) {
+          t[tx].second = t[tx].best;
+          t[tx].best = val;
+          t[tx].idx = i;
+        } else if (better2) {
+          t[tx].second = val;
+        }
+        const float val2 = t[tx + len].second;
+        if (distance == 1 ? (val2 < t[tx].second) : (val2 > t[tx].second)) t[tx].second = val2;
+      }
+    }
+    oracle_sift_point *pt = sift1 + p1;
+    pt->score = t[0].best;
+    if (distance == 1) pt->ambiguity = (float)(t[0].best / (t[0].second + 1e-6));       /* :222 (double constant) */
+    else pt->ambiguity = (float)((1 - t[0].best) / (1 - t[0].second + 1e-6));            /* :143 */
+    pt->match = t[0].idx;
+    const int m = t[0].idx >= 0 && t[0].idx < n2 ? t[0].idx : 0;
+    pt->match_xpos = sift2[m].coords2D[0];
+    pt->match_ypos = sift2[m].coords2D[1];
+  }
+  free(corr);
+}
+
+int oracle_match_filter(const oracle_sift_point *sift1, int n1, float score_threshold, float ambiguity_threshold,
+                        int *idx) {
+  const float thresh2 = score_threshold * score_threshold;
+  const float athresh2 = ambiguity_threshold * ambiguity_threshold;
+  int n = 0;
+  for (int i = 0; i < n1; i++)
+    if (sift1[i].score < thresh2 && sift1[i].ambiguity < athresh2) { /* :336 */
+      if (idx) idx[n] = i;
+      n++;
+    }
+  return n;
+}

@@ -80,6 +80,18 @@ void oracle_rootsift(oracle_sift_point *points, int n);
 /* cuSIFT.cu:61-120,175-270: full driver on a dense host image (row stride w). Returns numPts. */
 int oracle_extract(const float *img, int w, int h, const oracle_params *prm, oracle_sift_point *points);
 
+/* MatchSiftData (extras/matching.cu:232-362) -- the first "next" row after the extraction path.
+ * distance: 0 = MatchSiftDistanceDotProduct, 1 = MatchSiftDistanceL2 (extras/matching.h:10-13).
+ * Writes score, ambiguity, match, match_xpos, match_ypos of every point of sift1 (ComputeDistance :12-58 with its
+ * rotated summation order, ComputeL2Distance :63-74, FindMaxCorr :76-152 / FindMinCorr :154-230).
+ * Pinned by the reference's own fixtures: sift/sift{1,2} + match_indices1_2 and the 340-match ratio test
+ * (test/test.cpp:25-56). */
+void oracle_match_sift_data(oracle_sift_point *sift1, int n1, const oracle_sift_point *sift2, int n2, int distance);
+/* The host-side filter of MatchSiftData (extras/matching.cu:318-349, MatchType2D): number of points of sift1
+ * with score < scoreThreshold^2 && ambiguity < ambiguityThreshold^2; their indices go to `idx` if not NULL. */
+int oracle_match_filter(const oracle_sift_point *sift1, int n1, float score_threshold, float ambiguity_threshold,
+                        int *idx);
+
 /* Software model of tex2D<float>(x, y) with cudaFilterModeLinear / clamp / unnormalised coords. */
 float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, int frac_bits);
 

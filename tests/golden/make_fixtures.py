@@ -39,3 +39,15 @@ for name in ("cusift1_check", "cusift1"):
         f.write(raw)
     print(name, "numPts =", n)
 print("gray1: min/max", g.min(), g.max())
+
+# ---- matcher fixtures (test/test.cpp:25-56) -------------------------------
+# sift/sift1, sift/sift2 : VLFeat dumps  u32 n; f32[n][4] (x, y, scale, orientation); f32[n][128] descriptors
+#                          (extras/debug.cpp:118-165)
+# match_indices1_2       : MATLAB match indices  u32 n; u32 i[n]; u32 j[n], 1-based (extras/debug.cpp:167-181)
+# The reference's MatchingRatioTest expects 340 matches for MatchSiftData(L2, 1000, 0.6) on this pair.
+import shutil
+for rel, name in (("sift/sift1", "vlfeat_sift1.bin"), ("sift/sift2", "vlfeat_sift2.bin"),
+                  ("match_indices/match_indices1_2", "match_indices1_2.bin")):
+    shutil.copyfile(os.path.join(src, rel), os.path.join(here, name))
+    os.chmod(os.path.join(here, name), 0o644)
+    print(name, os.path.getsize(os.path.join(here, name)), "bytes")

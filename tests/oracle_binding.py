@@ -88,6 +88,10 @@ class Oracle:
         lib.oracle_rootsift.restype = None
         lib.oracle_extract.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(OracleParams), _vp]
         lib.oracle_extract.restype = C.c_int
+        lib.oracle_match_sift_data.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int]
+        lib.oracle_match_sift_data.restype = None
+        lib.oracle_match_filter.argtypes = [_vp, C.c_int, C.c_float, C.c_float, _vp]
+        lib.oracle_match_filter.restype = C.c_int
         lib.oracle_tex2d.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
         lib.oracle_tex2d.restype = C.c_float
 
@@ -143,6 +147,16 @@ class Oracle:
         n = self.lib.oracle_extract(img.ctypes.data, w, h, C.byref(prm), points.ctypes.data)
         return points[:n]
 
+    def match(self, sift1, sift2, distance=1):
+        """MatchSiftData: fills score/ambiguity/match/match_xpos/match_ypos of sift1 in place."""
+        self.lib.oracle_match_sift_data(sift1.ctypes.data, len(sift1), sift2.ctypes.data, len(sift2), distance)
+
+    def match_filter(self, sift1, score_threshold=999.0, ambiguity_threshold=1.0):
+        idx = np.zeros(max(len(sift1), 1), dtype=np.int32)
+        n = self.lib.oracle_match_filter(sift1.ctypes.data, len(sift1), score_threshold, ambiguity_threshold,
+                                         idx.ctypes.data)
+        return idx[:n]
+
     def tex2d(self, img, w, h, x, y, frac_bits=8):
         img = _f32(img)
         return self.lib.oracle_tex2d(img.ctypes.data, w, h, img.shape[1], x, y, frac_bits)
@@ -156,3 +170,25 @@ def pitched(img):
     out = np.zeros((h, p), dtype=np.float32)
     out[:, :w] = img
     return out
+
+
+def read_vlfeat_sift(path):
+    """VLFeat dump (extras/debug.cpp:118-165): u32 n; f32[n][4] x,y,scale,orientation; f32[n][128] -> SiftPoint array."""
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[:4], dtype="<u4")[0])
+    pts = np.frombuffer(raw[4:4 + 16 * n], dtype="<f4").reshape(n, 4)
+    desc = np.frombuffer(raw[4 + 16 * n:], dtype="<f4").reshape(n, 128)
+    out = np.zeros(n, dtype=SIFT_POINT_DTYPE)
+    out["coords2D"] = pts[:, :2]
+    out["scale"] = pts[:, 2]
+    out["orientation"] = pts[:, 3]
+    out["data"] = desc
+    return out
+
+
+def read_match_indices(path):
+    """MATLAB match indices (extras/debug.cpp:167-181): u32 n; u32 i[n]; u32 j[n], 1-based."""
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw[:4], dtype="<u4")[0])
+    a = np.frombuffer(raw[4:], dtype="<u4")
+    return a[:n].astype(np.int64), a[n:2 * n].astype(np.int64)

@@ -8,17 +8,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(CPP, "detector_dropin")
+BIN_MATCH = os.path.join(CPP, "matching_dropin")
 
 
 def build():
-    subprocess.check_call(["make", "-C", CPP], stdout=subprocess.DEVNULL)
-    assert os.path.exists(BIN)
+    subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(BIN) and os.path.exists(BIN_MATCH)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    if os.path.exists(BIN):
-        os.remove(BIN)
+    for b in (BIN, BIN_MATCH):
+        if os.path.exists(b):
+            os.remove(b)
     build()
 
 
@@ -41,3 +43,15 @@ def test_dropin_detector_program_passes_on_gpu():
     assert "PASSED" in out.stdout
     assert "num pts: golden 4096, extracted 4096" in out.stdout
     assert "Total time incl memory" in out.stdout  # the reference prints this on every call (cuSIFT.cu:117-119)
+
+
+@pytest.mark.gpu
+def test_dropin_matching_program_passes_on_gpu():
+    """extras/matching.h surface: the reference's MatchingTest + MatchingRatioTest (test/test.cpp:25-56)."""
+    build()
+    g = os.path.join(ROOT, "tests", "golden")
+    out = subprocess.run([BIN_MATCH, os.path.join(g, "vlfeat_sift1.bin"), os.path.join(g, "vlfeat_sift2.bin"),
+                          os.path.join(g, "match_indices1_2.bin")], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "326 / 326 agree" in out.stdout and "ratio test: 340 matches" in out.stdout
