@@ -159,6 +159,7 @@ def main():
     # (two output slots); its one host read-back (the counts) then waits only for the side stream.
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream() if use_dist else None
+    packer = ex.make_packer(side_stream) if use_dist else None
     pending = []
     state = {"i": 0, "gathered": None}
 
@@ -166,7 +167,7 @@ def main():
         pts, cnt, ev = pending.pop(0)
         with torch.cuda.stream(side_stream):
             side_stream.wait_event(ev)
-            state["gathered"] = allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather)
+            state["gathered"] = allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather, packer=packer)
 
     def step():
         slot = state["i"] % len(ex.slots)

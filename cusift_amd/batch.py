@@ -53,6 +53,29 @@ class BatchExtractor:
                                self.params, self.points.data_ptr(), self.counts.data_ptr())
         return self.points, self.counts
 
+    def make_packer(self, stream=None):
+        """A `packer(points, counts, max_pts)` for cusift_amd.dist.allgather_siftdata that runs cusift_pack_points on
+        `stream` (a torch.cuda.Stream; default: this extractor's stream) through a context of its own that borrows
+        that stream -- so the exchange of step i can be packed and sent on a side stream while step i+1 is extracted."""
+        stream = self.stream if stream is None else stream
+        ctx = self.ctx if stream == self.stream else capi.Context(self.device.index, stream=stream.cuda_stream)
+        self._packer_ctxs = getattr(self, "_packer_ctxs", []) + [ctx]
+
+        def packer(points, counts, max_pts):
+            n = points.shape[0]
+            if n > 256 or not points.is_cuda:  # kMaxFlatImages
+                from .dist import pack_points
+                return pack_points(points, counts, max_pts)
+            with torch.cuda.stream(stream):
+                valid = torch.clamp(counts, max=max_pts)
+                total = int(valid.sum().item())  # the one host read-back of the packing
+                packed = torch.empty((total, capi.SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+                if total > 0:
+                    ctx.pack_points(points.data_ptr(), counts.data_ptr(), n, max_pts, packed.data_ptr(), total, None)
+            return packed, valid
+
+        return packer
+
     def valid_counts(self):
         return torch.clamp(self.counts, max=self.max_pts)
 

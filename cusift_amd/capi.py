@@ -102,6 +102,7 @@ SIGNATURES = {
     "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i]),
     "cusift_match": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    "cusift_pack_points": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_extract": (_i, [_vp, _vp, _i, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
     "cusift_extract_host": (_i, [_vp, _vp, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
@@ -289,6 +290,10 @@ class Context:
 
     def rootsift(self, d_points, num_pts):
         check(lib().cusift_rootsift(self.handle, d_points, num_pts))
+
+    def pack_points(self, d_points, d_counters, n_images, max_pts, d_packed, capacity, d_offsets=None):
+        check(lib().cusift_pack_points(self.handle, d_points, d_counters, n_images, max_pts, d_packed, capacity,
+                                       d_offsets))
 
     # ---- matcher ----
     def match(self, d_sift1, n1, d_sift2, n2, distance=1):

@@ -36,6 +36,8 @@ __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_po
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float);
 __global__ void rootsift_kernel(cusift_point *, int);
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int);
+__global__ void pack_points_kernel(const cusift_point *, const unsigned int *, int, int, cusift_point *, unsigned int,
+                                   unsigned int *);
 }  // namespace cusift
 
 using namespace cusift;
@@ -811,6 +813,20 @@ extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitc
   HIP_TRY(hipMemcpy2DAsync(h_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSIFT_OK;
+}
+
+extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
+                                  int n_images, int max_pts, cusift_point *d_packed, size_t capacity,
+                                  unsigned int *d_offsets) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_points || !d_counters || !d_packed) return fail(CUSIFT_ERR_INVALID, "pack: missing data");
+  if (n_images < 1 || n_images > kMaxFlatImages || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "pack: n_images must be in [1, %d]", kMaxFlatImages);
+  const size_t cap = std::min(capacity, (size_t)0xffffffffu);
+  dim3 grid((unsigned int)std::max<size_t>(1, std::min<size_t>(std::max<size_t>(cap, 1), 256 * 32)));
+  hipLaunchKernelGGL(pack_points_kernel, grid, dim3(64), 0, ctx->stream, d_points, d_counters, n_images, max_pts,
+                     d_packed, (unsigned int)cap, d_offsets);
+  return check_launch("pack_points");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -550,4 +550,49 @@ __global__ void __launch_bounds__(64) rootsift_kernel(cusift_point *__restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packing of a batch's SiftData for the all-gatherv (new: the reference is single-image, single-GPU).
+// [n][max_pts] records + per-image counters -> the valid records back to back in image order, plus the
+// exclusive prefix sums of the valid counts (offsets[n] = total).  One wave per record, 147 dwords each.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) pack_points_kernel(const cusift_point *__restrict__ points,
+                                                        const unsigned int *__restrict__ counters, int n_images,
+                                                        int max_pts, cusift_point *__restrict__ packed,
+                                                        unsigned int capacity, unsigned int *__restrict__ offsets) {
+  __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_images; i += 64) {
+    const unsigned int c = counters[i];
+    s_prefix[i + 1] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
+  }
+  wave_sync();
+  if (lane == 0) {
+    unsigned int acc = 0;
+    s_prefix[0] = 0;
+    for (int i = 1; i <= n_images; ++i) {
+      acc += s_prefix[i];
+      s_prefix[i] = acc;
+    }
+  }
+  wave_sync();
+  if (blockIdx.x == 0 && offsets)
+    for (int i = lane; i <= n_images; i += 64) offsets[i] = s_prefix[i];
+  const unsigned int total = min(s_prefix[n_images], capacity);
+  constexpr int kDwords = sizeof(cusift_point) / 4;  // 147
+  for (unsigned int g = blockIdx.x; g < total; g += gridDim.x) {
+    int lo = 0, hi_ = n_images;
+    while (hi_ - lo > 1) {
+      const int mid = (lo + hi_) >> 1;
+      if (s_prefix[mid] <= g) lo = mid; else hi_ = mid;
+    }
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(points + (long)lo * max_pts + (g - s_prefix[lo]));
+    unsigned int *dst = reinterpret_cast<unsigned int *>(packed + g);
+#pragma unroll
+    for (int k = 0; k < (kDwords + 63) / 64; ++k) {
+      const int e = lane + 64 * k;
+      if (e < kDwords) dst[e] = src[e];
+    }
+  }
+}
+
 }  // namespace cusift

@@ -33,7 +33,7 @@ def pack_points(points, counts, max_pts):
     return points[mask], valid.to(torch.int32)
 
 
-def allgather_siftdata(points, counts, max_pts, group=None, method="p2p"):
+def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer=None):
     """All-gatherv of SiftData.
 
     points : uint8 [n_local, max_pts, 588] on this rank; counts : int32 [n_local] raw counters.
@@ -43,7 +43,9 @@ def allgather_siftdata(points, counts, max_pts, group=None, method="p2p"):
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    packed, valid = pack_points(points, counts, max_pts)
+    # `packer(points, counts, max_pts) -> (packed [sum,588], valid counts)`: BatchExtractor.pack on the GPU (one
+    # HIP kernel); the torch expression below is the host/gloo form
+    packed, valid = (packer or pack_points)(points, counts, max_pts)
     n_local = torch.tensor([valid.numel()], dtype=torch.int32, device=points.device)
     n_all = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(n_all, n_local, group=group)

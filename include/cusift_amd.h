@@ -198,6 +198,12 @@ int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1, const cus
 int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch,
                         size_t width_bytes, size_t rows);
 
+/* Packs a batch's SiftData for an exchange (all-gatherv over RCCL): the valid records of all images back to back in
+ * image order into d_packed (room for `capacity` records; anything beyond is dropped) and the exclusive prefix sums
+ * of the valid counts into d_offsets[0 .. n_images] (may be NULL).  n_images <= 256.  Asynchronous. */
+int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters, int n_images,
+                       int max_pts, cusift_point *d_packed, size_t capacity, unsigned int *d_offsets);
+
 /* ---- drivers ------------------------------------------------------------------------------ */
 /* Batch form of ExtractSiftLoop/ExtractSiftOctave (cuSIFT.cu:175-270) on device-resident images.
  * Asynchronous on the context's stream: no host read-back, no allocation once the arena is sized.

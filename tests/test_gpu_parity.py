@@ -524,6 +524,32 @@ def test_full_size_batch_properties(ctx):
     np.testing.assert_array_equal(a["data"], b["data"])  # one wave per keypoint: reproducible sums
 
 
+def test_pack_points_matches_torch_expression(ctx, gray1):
+    """cusift_pack_points == the boolean-mask packing used on CPU (cusift_amd.dist.pack_points)."""
+    import torch
+
+    from cusift_amd.batch import BatchExtractor
+    from cusift_amd.dist import pack_points
+
+    imgs = np.stack([gray1, np.roll(gray1, (9, 31), axis=(0, 1)), np.full_like(gray1, 50.0), gray1[::-1].copy()])
+    ex = BatchExtractor(4, 640, 480, num_octaves=3, peak_thresh=1.0, max_pts=2048)
+    pts, cnt = ex.extract(ex.images_from_numpy(imgs))
+    torch.cuda.synchronize()
+    assert int(cnt[2]) == 0 and int(cnt[0]) > 100
+    want_p, want_v = pack_points(pts, cnt, ex.max_pts)
+    for stream in (None, torch.cuda.Stream()):
+        got_p, got_v = ex.make_packer(stream)(pts, cnt, ex.max_pts)
+        torch.cuda.synchronize()
+        assert torch.equal(got_v.cpu(), want_v.cpu())
+        assert torch.equal(got_p.cpu(), want_p.cpu())
+    # saturated counters are clamped to max_pts
+    cnt2 = cnt.clone()
+    cnt2[1] = 10 ** 6
+    got_p, got_v = ex.make_packer()(pts, cnt2, ex.max_pts)
+    assert int(got_v[1]) == ex.max_pts and got_p.shape[0] == int(got_v.sum())
+    ex.close()
+
+
 def test_stage_timers_report_every_stage(ctx, gray1):
     d_pts = DeviceBuffer(ctx, 4096 * 588)
     for fused in (1, 0):
