@@ -163,6 +163,7 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
   if (!prm) return fail(CUSIFT_ERR_INVALID, "params is NULL");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w)
     return fail(CUSIFT_ERR_INVALID, "bad geometry n=%d w=%d h=%d pitch=%d", n_images, w, h, pitch);
+  if (n_images > 65535) return fail(CUSIFT_ERR_INVALID, "at most 65535 images per batch (grid.z), got %d", n_images);
   if (prm->max_pts < 1) return fail(CUSIFT_ERR_INVALID, "max_pts must be >= 1");
   int n = std::max(1, std::min(prm->num_octaves, kMaxOctaves));
   pl.w[0] = w;

@@ -11,7 +11,7 @@ namespace cusift {
 // Software model of the CUDA texture fetch the reference relies on:
 // tex2D<float>(x, y), cudaFilterModeLinear, clamp, unnormalised coordinates (cuSIFT.cu:227-233).
 // xB = x - 0.5, i = floor(xB), alpha = frac(xB) rounded to `frac_bits` bits.  Same operation order
-// as oracle_tex2d.
+// as oracle_tex2d (first product, then three fused multiply-adds).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw, float x,
                                        float y, float q, float inv_q) {
@@ -19,8 +19,8 @@ __device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int
   float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
   if (q > 0.0f) {
-    a = floorf(a * q + 0.5f) * inv_q;  // q is a power of two: * inv_q == / q exactly
-    b = floorf(b * q + 0.5f) * inv_q;
+    a = floorf(fmaf(a, q, 0.5f)) * inv_q;  // q is a power of two: a*q is exact, * inv_q == / q exactly
+    b = floorf(fmaf(b, q, 0.5f)) * inv_q;
   }
   fx = fminf(fmaxf(fx, -1.0f), (float)w);
   fy = fminf(fmaxf(fy, -1.0f), (float)rw.hg);
@@ -31,9 +31,9 @@ __device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int
   const float s01 = img[(long)j1 * pitch + i0], s11 = img[(long)j1 * pitch + i1];
   const float ia = 1.0f - a, ib = 1.0f - b;
   float t = (ia * ib) * s00;
-  t = t + (a * ib) * s10;
-  t = t + (ia * b) * s01;
-  t = t + (a * b) * s11;
+  t = fmaf(a * ib, s10, t);
+  t = fmaf(ia * b, s01, t);
+  t = fmaf(a * b, s11, t);
   return t;
 }
 
@@ -69,8 +69,8 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, const PatchGeom &
   const float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
   if (q > 0.0f) {
-    a = floorf(a * q + 0.5f) * inv_q;
-    b = floorf(b * q + 0.5f) * inv_q;
+    a = floorf(fmaf(a, q, 0.5f)) * inv_q;
+    b = floorf(fmaf(b, q, 0.5f)) * inv_q;
   }
   const int i = (int)fx - g.x0, j = (int)fy - g.y0;
   const float *p0 = lds + j * g.stride + i;
@@ -78,9 +78,9 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, const PatchGeom &
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
   const float ia = 1.0f - a, ib = 1.0f - b;
   float t = (ia * ib) * s00;
-  t = t + (a * ib) * s10;
-  t = t + (ia * b) * s01;
-  t = t + (a * b) * s11;
+  t = fmaf(a * ib, s10, t);
+  t = fmaf(ia * b, s01, t);
+  t = fmaf(a * b, s11, t);
   return t;
 }
 
@@ -134,8 +134,8 @@ struct OriShared {
 
 // ------------------------------------------------------------------------------------------------
 // Dominant orientation.  Reference: ComputeOrientations_D, cuSIFT_D.cu:319-396 (second peak compiled out, :380).
-// 121 samples (11x11) -> 32-bin histogram: bins are lanes, samples are walked in index order, so the sums are
-// deterministic and in the oracle's order.  Every lane returns the orientation (degrees).
+// 121 samples (11x11) -> 32-bin histogram: bins are lanes, each half-wave walks half of the samples in index
+// order, so the sums are deterministic and in the oracle's order.  Every lane returns the orientation (degrees).
 // ------------------------------------------------------------------------------------------------
 template <typename SH>
 __device__ __forceinline__ float kp_orientation(SH &S, const Sampler &tex, float kx, float ky, float scale, int tx) {
@@ -161,14 +161,19 @@ __device__ __forceinline__ float kp_orientation(SH &S, const Sampler &tex, float
     }
   }
   wave_sync();
-  if (tx < 32) {
+  {
+    // bins are lanes (lane & 31); the lower half-wave sums samples 0..60 in index order, the upper half-wave
+    // samples 61..120, then hist = lower + upper -- the oracle accumulates in exactly this order
+    const int b = tx & 31;
+    const int t0 = tx < 32 ? 0 : 61, t1 = tx < 32 ? 61 : 121;
     float acc = 0.0f;
-#pragma unroll 11
-    for (int t = 0; t < 121; ++t) {
+    for (int t = t0; t < t1; ++t) {
       const float2 sv = S.sample[t];
-      if (__float_as_int(sv.x) == tx) acc += sv.y;
+      if (__float_as_int(sv.x) == b) acc += sv.y;
     }
-    S.hist[tx] = acc;
+    if (tx >= 32) S.hist[tx] = acc;  // hist[32 + b]: scratch until the smoothing pass overwrites it
+    wave_sync();
+    if (tx < 32) S.hist[tx] = acc + S.hist[tx + 32];
   }
   wave_sync();
   const int x1m = (tx >= 1 ? tx - 1 : tx + 31);

@@ -289,10 +289,12 @@ float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, 
   float s00 = img[(size_t)j0 * pitch + i0], s10 = img[(size_t)j0 * pitch + i1];
   float s01 = img[(size_t)j1 * pitch + i0], s11 = img[(size_t)j1 * pitch + i1];
   float ia = 1.0f - a, ib = 1.0f - b;
+  /* interpolation order of this restatement: first product, then three fused multiply-adds
+   * (the texture unit's own arithmetic is not documented; nvcc would fuse exactly like this) */
   float t = (ia * ib) * s00;
-  t = t + (a * ib) * s10;
-  t = t + (ia * b) * s01;
-  t = t + (a * b) * s11;
+  t = fmaf(a * ib, s10, t);
+  t = fmaf(ia * b, s01, t);
+  t = fmaf(a * b, s11, t);
   return t;
 }
 
@@ -304,10 +306,12 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
   for (int bx = first; bx < last; bx++) {
     oracle_sift_point *pt = points + bx;
     float hist[64];
+    float hist_hi[32];
     float gauss[11];
     float i2sigma2 = -1.0f / (4.5f * pt->scale * pt->scale);
     for (int tx = 0; tx < 11; tx++) gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
     for (int i = 0; i < 64; i++) hist[i] = 0.0f;
+    for (int i = 0; i < 32; i++) hist_hi[i] = 0.0f;
     float xp = pt->coords2D[0] - 5.0f;
     float yp = pt->coords2D[1] - 5.0f;
     for (int tx = 0; tx < 121; tx++) { /* threads 121..127 have yd == 11 and skip */
@@ -322,9 +326,12 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
       int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
       if (bin > 31 || bin < 0) bin = 0; /* < 0 only for non-finite input (memory safety) */
       float grad = sqrtf(dx * dx + dy * dy);
-      /* device: LDS float atomicAdd in arbitrary order; oracle: increasing tx */
-      hist[bin] += grad * gauss[xd] * gauss[yd];
+      /* reference: LDS float atomicAdd in arbitrary order.  This restatement (and the HIP kernel) fixes one:
+       * samples 0..60 and 61..120 are summed separately in index order, then added. */
+      if (tx < 61) hist[bin] += grad * gauss[xd] * gauss[yd];
+      else hist_hi[bin] += grad * gauss[xd] * gauss[yd];
     }
+    for (int i = 0; i < 32; i++) hist[i] = hist[i] + hist_hi[i];
     for (int tx = 0; tx < 32; tx++) {
       int x1m = (tx >= 1 ? tx - 1 : tx + 31);
       int x1p = (tx <= 30 ? tx + 1 : tx - 31);

@@ -456,6 +456,16 @@ def test_extract_1080p_matches_oracle(ctx, oracle):
     compare_sets(want, got)
 
 
+def test_extract_large_image_matches_oracle(ctx, oracle):
+    """A 4096 x 3072 image (12.6 Mpx, 6 octaves): the strip/chunk geometry far from the 1080p case."""
+    img = synth.tile(31, 4096, 3072, preblur=0.8)
+    kw = dict(num_octaves=6, init_blur=0.8, peak_thresh=3.5, edge_thresh=10.0, max_pts=262144)
+    want = oracle.extract(img, **kw)
+    got = gpu_extract(ctx, img, **kw)
+    assert len(want) > 10000
+    compare_sets(want, got)
+
+
 def test_extract_device_image_and_odd_size(ctx, oracle):
     """Legacy ExtractSift path: image already on the device in a caller-pitched buffer; odd w/h."""
     w, h = 333, 251
