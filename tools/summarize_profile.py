@@ -18,7 +18,10 @@ from collections import defaultdict
 
 def short(name):
     n = name.split("(")[0]
-    return n.replace("cusift::", "").replace("void ", "")[:60]
+    n = n.replace("cusift::", "").replace("void ", "")
+    if n.startswith("detect_fused_kernel"):  # template instances <true>/<false> are one kernel here
+        n = "detect_fused_kernel"
+    return n[:60]
 
 
 def read_csv(path):
