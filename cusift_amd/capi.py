@@ -89,6 +89,9 @@ SIGNATURES = {
     "cusift_image_d2h": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "cusift_malloc_host": (_i, [C.POINTER(_vp), _sz]),
     "cusift_free_host": (_i, [_vp]),
+    "cusift_image_u8_h2d": (_i, [_vp, _vp, _i, _vp, _i, _i]),
+    "cusift_u8_to_f32": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i]),
+    "cusift_gaussian3x3": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
     "cusift_scale_down": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
     "cusift_laplace_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _vp, _sz, _i]),
     "cusift_laplace_taps": (_i, [_f, _vp]),
@@ -233,6 +236,25 @@ class Context:
     def d2h(self, arr, d_ptr):
         assert arr.flags["C_CONTIGUOUS"]
         check(lib().cusift_memcpy_d2h(self.handle, arr.ctypes.data, C.c_void_p(d_ptr), arr.nbytes))
+
+    # ---- front-end ----
+    def image_u8_h2d(self, d_dst, dst_pitch, img_u8):
+        img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        h, w = img_u8.shape
+        check(lib().cusift_image_u8_h2d(self.handle, d_dst, dst_pitch, img_u8.ctypes.data, w, h))
+
+    def u8_to_f32(self, d_dst, dst_pitch, d_src, w, h, src_pitch_bytes, n_images=1, dst_stride=None, src_stride=None):
+        dst_stride = h * dst_pitch if dst_stride is None else dst_stride
+        src_stride = h * src_pitch_bytes if src_stride is None else src_stride
+        check(lib().cusift_u8_to_f32(self.handle, d_dst, dst_pitch, dst_stride, d_src, w, h, src_pitch_bytes,
+                                     src_stride, n_images))
+
+    def gaussian3x3(self, d_dst, dst_pitch, d_src, w, h, src_pitch, sigma, n_images=1, dst_stride=None,
+                    src_stride=None):
+        dst_stride = h * dst_pitch if dst_stride is None else dst_stride
+        src_stride = h * src_pitch if src_stride is None else src_stride
+        check(lib().cusift_gaussian3x3(self.handle, d_dst, dst_pitch, dst_stride, d_src, w, h, src_pitch, src_stride,
+                                       n_images, sigma))
 
     # ---- stage entry points (device pointers are plain ints) ----
     def scale_down(self, d_dst, dst_pitch, d_src, w, h, src_pitch, n_images=1, dst_stride=None, src_stride=None,

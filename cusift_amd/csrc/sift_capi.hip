@@ -35,7 +35,10 @@ __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_po
                                    const unsigned int *, float, float, float, RowWindow);
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float);
 __global__ void rootsift_kernel(cusift_point *, int);
-__global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int);
+__global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, int, MatchPartial *, int);
+__global__ void match_merge_kernel(cusift_point *, int, const cusift_point *, int, int, const MatchPartial *, int, int);
+__global__ void u8_to_f32_kernel(float *, int, long, const unsigned char *, int, int, int, long, int);
+__global__ void gaussian3x3_kernel(float *, int, long, const float *, int, int, int, long, float, float);
 __global__ void pack_points_kernel(const cusift_point *, const unsigned int *, int, int, cusift_point *, unsigned int,
                                    unsigned int *);
 }  // namespace cusift
@@ -84,6 +87,7 @@ struct TimedSpan {
 
 struct cusift_ctx {
   int device = 0;
+  int num_cus = 256;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
   // scratch arena (one allocation, grown on demand, never shrunk)
@@ -92,6 +96,12 @@ struct cusift_ctx {
   // DoG planes of the two-stage path ([n][7][h0][p0] floats); allocated only when that path runs
   float *dog = nullptr;
   size_t dog_bytes = 0;
+  // per-split partial results of the matcher (cusift_match)
+  MatchPartial *match_scratch = nullptr;
+  size_t match_scratch_bytes = 0;
+  // staging buffer for 8-bit uploads (cusift_image_u8_h2d)
+  unsigned char *u8_stage = nullptr;
+  size_t u8_stage_bytes = 0;
   // small persistent device scratch for the blocking single-image entry points
   unsigned int *d_counter1 = nullptr;
   int describe_grid = 0;  // resident blocks of describe_all_kernel on this device (occupancy query, cached)
@@ -359,6 +369,8 @@ static int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool 
   HIP_TRY(hipSetDevice(device));
   cusift_ctx *ctx = new cusift_ctx();
   ctx->device = device;
+  (void)hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (ctx->num_cus < 1) ctx->num_cus = 256;
   if (borrow) {
     ctx->stream = (hipStream_t)hip_stream;  // NULL = the null stream
   } else {
@@ -398,6 +410,8 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->dog) (void)hipFree(ctx->dog);
+  if (ctx->u8_stage) (void)hipFree(ctx->u8_stage);
+  if (ctx->match_scratch) (void)hipFree(ctx->match_scratch);
   if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -532,6 +546,61 @@ extern "C" int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_sr
                            hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSIFT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// front-end
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_u8_to_f32(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride,
+                                const unsigned char *d_src, int w, int h, int src_pitch_bytes,
+                                size_t src_stride_bytes, int n_images) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "u8_to_f32: missing data");
+  if (n_images < 1 || n_images > 65535 || w < 1 || h < 1 || h > 65535 || dst_pitch < w || src_pitch_bytes < w)
+    return fail(CUSIFT_ERR_INVALID, "u8_to_f32: bad geometry");
+  const int vec_ok = (dst_pitch % 4 == 0) && (((uintptr_t)d_dst % 16) == 0) && (dst_stride % 4 == 0) &&
+                     (src_pitch_bytes % 4 == 0) && (((uintptr_t)d_src % 4) == 0) && (src_stride_bytes % 4 == 0);
+  dim3 grid(idiv_up(idiv_up(w, 4), 256), h, n_images);
+  hipLaunchKernelGGL(u8_to_f32_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride, d_src, w, h,
+                     src_pitch_bytes, (long)src_stride_bytes, vec_ok);
+  return check_launch("u8_to_f32");
+}
+
+extern "C" int cusift_image_u8_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const unsigned char *h_src, int w,
+                                   int h) {
+  if (!ctx || !d_dst || !h_src || w < 1 || h < 1 || dst_pitch < w) return fail(CUSIFT_ERR_INVALID, "bad argument");
+  const size_t spitch = align_up_sz((size_t)w, 4);
+  const size_t bytes = spitch * h;
+  if (bytes > ctx->u8_stage_bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->u8_stage) HIP_TRY(hipFree(ctx->u8_stage));
+    ctx->u8_stage = nullptr;
+    ctx->u8_stage_bytes = 0;
+    hipError_t e = hipMalloc((void **)&ctx->u8_stage, bytes);
+    if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ctx->u8_stage_bytes = bytes;
+  }
+  HIP_TRY(hipMemcpy2DAsync(ctx->u8_stage, spitch, h_src, (size_t)w, (size_t)w, h, hipMemcpyHostToDevice, ctx->stream));
+  TRY(cusift_u8_to_f32(ctx, d_dst, dst_pitch, (size_t)dst_pitch * h, ctx->u8_stage, w, h, (int)spitch, bytes, 1));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_gaussian3x3(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
+                                  int w, int h, int src_pitch, size_t src_stride, int n_images, float sigma) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!d_dst || !d_src || d_dst == d_src) return fail(CUSIFT_ERR_INVALID, "gaussian3x3: need distinct src and dst");
+  if (n_images < 1 || n_images > 65535 || w < 1 || h < 1 || h > 65535 || dst_pitch < w || src_pitch < w ||
+      !(sigma > 0.0f))
+    return fail(CUSIFT_ERR_INVALID, "gaussian3x3: bad argument");
+  // cv::getGaussianKernel(3, sigma, CV_32F): exp(-x^2/(2 sigma^2)) in double, normalised, stored as float
+  const double e1 = exp(-1.0 / (2.0 * (double)sigma * (double)sigma));
+  const double sum = 1.0 + 2.0 * e1;
+  const float k0 = (float)(1.0 / sum), k1 = (float)(e1 / sum);
+  dim3 grid(idiv_up(w, 256), h, n_images);
+  hipLaunchKernelGGL(gaussian3x3_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride, d_src, w,
+                     h, src_pitch, (long)src_stride, k0, k1);
+  return check_launch("gaussian3x3");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -802,8 +871,33 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
   if (num_pts1 <= 0 || num_pts2 <= 0) return CUSIFT_OK;  // extras/matching.cu:241-242: nothing to match
   if (!d_sift1 || !d_sift2) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: missing data");
   if (distance != 0 && distance != 1) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: distance must be 0 or 1");
-  dim3 grid(idiv_up(num_pts1, 64));
-  hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, ctx->stream, d_sift1, num_pts1, d_sift2, num_pts2, distance);
+  // Column splits: aim at >= 4 workgroups per CU, keep >= 4 LDS tiles (128 columns) per split.
+  const int row_blocks = idiv_up(num_pts1, 64);
+  int splits = std::max(1, std::min(idiv_up(4 * ctx->num_cus, row_blocks), idiv_up(num_pts2, 128)));
+  if (const char *e = getenv("CUSIFT_MATCH_SPLITS")) splits = std::max(1, std::min(atoi(e), idiv_up(num_pts2, 32)));
+  splits = std::min(splits, 65535);
+  const int cols_per_split = idiv_up(idiv_up(num_pts2, splits), 32) * 32;
+  splits = idiv_up(num_pts2, cols_per_split);
+  const int n1_pad = row_blocks * 64;
+  MatchPartial *partials = nullptr;
+  if (splits > 1) {
+    const size_t bytes = sizeof(MatchPartial) * (size_t)splits * n1_pad;
+    if (bytes > ctx->match_scratch_bytes) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (ctx->match_scratch) HIP_TRY(hipFree(ctx->match_scratch));
+      ctx->match_scratch = nullptr;
+      ctx->match_scratch_bytes = 0;
+      hipError_t e = hipMalloc((void **)&ctx->match_scratch, bytes);
+      if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      ctx->match_scratch_bytes = bytes;
+    }
+    partials = ctx->match_scratch;
+  }
+  hipLaunchKernelGGL(match_kernel, dim3(row_blocks, splits), dim3(256), 0, ctx->stream, d_sift1, num_pts1, d_sift2,
+                     num_pts2, distance, cols_per_split, partials, n1_pad);
+  if (splits > 1)
+    hipLaunchKernelGGL(match_merge_kernel, dim3(idiv_up(num_pts1, 256)), dim3(256), 0, ctx->stream, d_sift1, num_pts1,
+                       d_sift2, num_pts2, distance, partials, n1_pad, splits);
   return check_launch("match");
 }
 

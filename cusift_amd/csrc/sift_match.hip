@@ -8,6 +8,10 @@
 // v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain, no reduced-precision path), and every lane keeps the
 // running (best, second, index) of its rows for the columns it sees -- exactly what reference thread `tx` sees
 // (columns tx, tx+16, ...), followed by the reference's tree over tx.  N1*N2*4 bytes of HBM traffic never exist.
+// The next tile's global loads are in flight while the current one is multiplied (register staging), and image 2's
+// columns are split over blockIdx.y so that a few thousand keypoints still fill the chip; per-split results are
+// folded in column order by match_merge_kernel (equal to the single scan except for exact score ties between
+// columns of different splits).
 //
 // Numerics: the reference sums pt1[k]*pt2[k] starting at k = (p2 mod 16) and wrapping; the MFMA chain visits k in
 // the order 16u+j, 16u+4+j, 16u+8+j, 16u+12+j (u = 0..7, j = 0..3).  Scores agree to ~1e-7; indices agree except
@@ -37,26 +41,50 @@ __device__ __forceinline__ void top2_scan(float &best, float &second, int &idx, 
   }
 }
 
+// the tail of FindMinCorr/FindMaxCorr (extras/matching.cu:140-150,220-229): the five fields MatchSiftData fills
+__device__ __forceinline__ void write_match(cusift_point *pt, const cusift_point *__restrict__ sift2, int n2,
+                                            float best, float second, int idx, bool l2) {
+  pt->score = best;
+  // the 1e-6 is a double constant in the reference (:143,:222): evaluate in double, store float
+  pt->ambiguity = l2 ? (float)(best / (second + 1e-6)) : (float)((1 - best) / (1 - second + 1e-6));
+  pt->match = idx;
+  const int m = (idx >= 0 && idx < n2) ? idx : 0;  // the reference reads sift2[-1] here
+  pt->match_xpos = sift2[m].coords2D[0];
+  pt->match_ypos = sift2[m].coords2D[1];
+}
+
+// 16-byte loads from the 588-byte records: descriptors are only 4-byte aligned
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// One workgroup = 64 descriptors of image 1 (16 per wave) x one contiguous range of image 2's columns
+// (blockIdx.y = column split; the host picks the number of splits so that the grid fills 256 CUs even for a few
+// thousand keypoints).  With one split the kernel writes the final fields; otherwise the (best, second, index)
+// partial of every row goes to `partials[split][row]` and match_merge_kernel folds the splits in column order.
 __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ sift1, int n1,
-                                                   const cusift_point *__restrict__ sift2, int n2, int l2_mode) {
+                                                   const cusift_point *__restrict__ sift2, int n2, int l2_mode,
+                                                   int cols_per_split, MatchPartial *__restrict__ partials,
+                                                   int n1_pad) {
   __shared__ float sB[kMatchTileCols * kBStride];
   const bool l2 = l2_mode != 0;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int p1_base = blockIdx.x * kMatchRowsPerBlock + wv * 16;
-  const int corr_width = ((n2 + 15) / 16) * 16;  // extras/matching.cu:254
+  const int col_begin = blockIdx.y * cols_per_split;
+  const int col_end = min(col_begin + cols_per_split, n2);  // padded columns (:57) can never win: skip them
 
   // A fragments: lane (r, g) holds elements 16u + 4g + j of descriptor p1_base + r (u = 0..7, j = 0..3)
   float a[8][4];
   {
     const float *d1 = sift1[min(p1_base + r, n1 - 1)].data;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 8; ++u) {
+      const f4u v = *reinterpret_cast<const f4u *>(d1 + 16 * u + 4 * g);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[u][j] = d1[16 * u + 4 * g + j];
+      for (int j = 0; j < 4; ++j) a[u][j] = v[j];
+    }
   }
-  // running top-2 of rows 4g + reg for the columns this lane sees (p2 = r mod 16): reference thread tx = r
+  // running top-2 of rows 4g + q for the columns this lane sees (p2 = r mod 16): reference thread tx = r
   float best[4], second[4];
   int bidx[4];
 #pragma unroll
@@ -65,36 +93,51 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
     bidx[q] = -1;
   }
 
-  for (int c0 = 0; c0 < corr_width; c0 += kMatchTileCols) {
+  // staging: thread t moves four 16-byte chunks per tile; chunk c = t + 256 i -> descriptor c >> 5, floats 4 (c & 31)
+  f4u stage[4];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      const int col = c0 + (c >> 5);
+      stage[i] = (col < col_end) ? *reinterpret_cast<const f4u *>(sift2[col].data + 4 * (c & 31)) : f4u{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (col_begin < col_end) fetch(col_begin);
+  for (int c0 = col_begin; c0 < col_end; c0 += kMatchTileCols) {
     __syncthreads();  // the previous tile has been consumed
-    for (int e = threadIdx.x; e < kMatchTileCols * 128; e += 256) {
-      const int row = e >> 7, k = e & 127;
-      sB[row * kBStride + k] = (c0 + row < n2) ? sift2[c0 + row].data[k] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      *reinterpret_cast<f4 *>(sB + (c >> 5) * kBStride + 4 * (c & 31)) = f4{stage[i][0], stage[i][1], stage[i][2], stage[i][3]};
     }
     __syncthreads();
+    if (c0 + kMatchTileCols < col_end) fetch(c0 + kMatchTileCols);  // in flight while this tile is multiplied
+
+    // two independent 16x16 accumulators (columns c0 + r and c0 + 16 + r), each a k-ordered chain
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float *brow = sB + r * kBStride + 4 * g;
 #pragma unroll
-    for (int t = 0; t < kMatchTileCols / 16; ++t) {
-      if (c0 + 16 * t >= corr_width) break;  // wave-uniform
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float *brow = sB + (16 * t + r) * kBStride + 4 * g;
+    for (int u = 0; u < 8; ++u) {
+      const f4 b0 = *reinterpret_cast<const f4 *>(brow + 16 * u);
+      const f4 b1 = *reinterpret_cast<const f4 *>(brow + 16 * kBStride + 16 * u);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const f4 b = *reinterpret_cast<const f4 *>(brow + 16 * u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b1[j], acc1, 0, 0, 0);
       }
-      // acc[q] = <descriptor p1_base + 4g + q, descriptor c0 + 16t + r>
-      const int p2 = c0 + 16 * t + r;
+    }
+    // acc[q] = <descriptor p1_base + 4g + q, descriptor p2>
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float val;
-        if (p2 < n2) {
-          const float dot = acc[q];
-          val = l2 ? (dot > -1.0f ? 2 - 2 * dot : kMatchFltMax) : dot;  // ComputeL2Distance :71-72
-        } else {
-          val = l2 ? kMatchFltMax : -1.0f;  // padded columns, ComputeDistance :57
+    for (int t = 0; t < 2; ++t) {
+      const int p2 = c0 + 16 * t + r;
+      if (p2 < col_end) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float dot = t ? acc1[q] : acc0[q];
+          const float val = l2 ? (dot > -1.0f ? 2 - 2 * dot : kMatchFltMax) : dot;  // ComputeL2Distance :71-72
+          top2_scan(best[q], second[q], bidx[q], val, p2, l2);
         }
-        top2_scan(best[q], second[q], bidx[q], val, p2, l2);
       }
     }
   }
@@ -116,18 +159,35 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p1 = p1_base + 4 * g + q;
-      if (p1 < n1) {
-        cusift_point *pt = sift1 + p1;
-        pt->score = best[q];
-        // the 1e-6 is a double constant in the reference (:143,:222): evaluate in double, store float
-        pt->ambiguity = l2 ? (float)(best[q] / (second[q] + 1e-6)) : (float)((1 - best[q]) / (1 - second[q] + 1e-6));
-        pt->match = bidx[q];
-        const int m = (bidx[q] >= 0 && bidx[q] < n2) ? bidx[q] : 0;  // the reference reads sift2[-1] here
-        pt->match_xpos = sift2[m].coords2D[0];
-        pt->match_ypos = sift2[m].coords2D[1];
+      if (p1 >= n1) continue;
+      if (partials) {
+        MatchPartial mp;
+        mp.best = best[q];
+        mp.second = second[q];
+        mp.idx = bidx[q];
+        partials[(size_t)blockIdx.y * n1_pad + p1] = mp;
+      } else {
+        write_match(sift1 + p1, sift2, n2, best[q], second[q], bidx[q], l2);
       }
     }
   }
+}
+
+// Folds the column splits of one row in column order: the same update the tree applies between lanes.
+__global__ void __launch_bounds__(256) match_merge_kernel(cusift_point *__restrict__ sift1, int n1,
+                                                         const cusift_point *__restrict__ sift2, int n2, int l2_mode,
+                                                         const MatchPartial *__restrict__ partials, int n1_pad,
+                                                         int n_splits) {
+  const bool l2 = l2_mode != 0;
+  const int p1 = blockIdx.x * 256 + threadIdx.x;
+  if (p1 >= n1) return;
+  MatchPartial m = partials[p1];
+  for (int s = 1; s < n_splits; ++s) {
+    const MatchPartial o = partials[(size_t)s * n1_pad + p1];
+    top2_scan(m.best, m.second, m.idx, o.best, o.idx, l2);
+    if (beats(o.second, m.second, l2)) m.second = o.second;
+  }
+  write_match(sift1 + p1, sift2, n2, m.best, m.second, m.idx, l2);
 }
 
 }  // namespace cusift

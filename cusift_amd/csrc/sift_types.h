@@ -74,6 +74,12 @@ struct FindParams {
   float subsampling;
 };
 
+// per-(column split, row) result of the matcher, folded by match_merge_kernel
+struct MatchPartial {
+  float best, second;
+  int idx;
+};
+
 static_assert(sizeof(cusift_point) == 588, "SiftPoint is a 588-byte ABI record (cuSIFT.h:10-30)");
 
 }  // namespace cusift

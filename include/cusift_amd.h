@@ -128,6 +128,20 @@ int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_src, int src_
 int cusift_malloc_host(void **h_ptr, size_t bytes);
 int cusift_free_host(void *h_ptr);
 
+/* ---- caller-side front-end on the device ------------------------------------ */
+/* The reference's callers decode 8-bit images with OpenCV, convertTo(CV_32FC1) and optionally
+ * cv::GaussianBlur(img, img, Size(3,3), 0.5) on the HOST, then upload 4 bytes per pixel (main.cpp:300-318,
+ * test/detector.cpp:19-27).  These do the same after uploading 1 byte per pixel.
+ * cusift_image_u8_h2d: dense 8-bit host rows (w bytes) -> pitched float device image (exact conversion); blocking.
+ * cusift_u8_to_f32:    the conversion alone on device-resident 8-bit images (batch form); asynchronous.
+ * cusift_gaussian3x3:  3x3 separable Gaussian as cv::GaussianBlur(Size(3,3), sigma) evaluates its float path
+ *                      (symmetric small filters, BORDER_REFLECT_101); d_dst != d_src; asynchronous. */
+int cusift_image_u8_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const unsigned char *h_src, int w, int h);
+int cusift_u8_to_f32(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const unsigned char *d_src,
+                     int w, int h, int src_pitch_bytes, size_t src_stride_bytes, int n_images);
+int cusift_gaussian3x3(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w,
+                       int h, int src_pitch, size_t src_stride, int n_images, float sigma);
+
 /* ---- stage entry points (the reference's launch wrappers) --------------------------------- */
 /* ScaleDown(res, src, variance), cuSIFT.cu:313-353 + ScaleDown_D cuSIFT_D.cu:37-182.  `variance` sets the
  * 5-tap Gaussian exp(-(j-2)^2/(2*variance)) (the pyramid uses 0.5, cuSIFT.cu:185).

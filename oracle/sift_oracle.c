@@ -637,3 +637,44 @@ int oracle_match_filter(const oracle_sift_point *sift1, int n1, float score_thre
     }
   return n;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Caller-side front-end: what the reference's programs do on the host before upload,
+ * main.cpp:300-318 and test/detector.cpp:19-27: cv::Mat::convertTo(CV_32FC1) and the optional
+ * cv::GaussianBlur(img, img, cv::Size(3, 3), 0.5).
+ *
+ * PARITY UNPINNED for the blur: OpenCV is a system dependency of the reference (find_package(OpenCV),
+ * CMakeLists.txt:12-13, no version pinned) and is not in this image.  This restates the published algorithm of its
+ * float path: getGaussianKernel(3, sigma) = exp(-x^2 / (2 sigma^2)) evaluated in double, normalised, stored as
+ * float; separable, rows then columns, each as (S[-1] + S[+1]) * k1 + S[0] * k0 (the symmetric small-kernel
+ * filters), border BORDER_REFLECT_101 (the default border type).
+ * ------------------------------------------------------------------------------------------------ */
+void oracle_u8_to_f32(const unsigned char *src, int w, int h, int src_pitch, float *dst, int dst_pitch) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) dst[(long)y * dst_pitch + x] = (float)src[(long)y * src_pitch + x];
+}
+
+static int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) return -i;
+  if (i >= n) return 2 * n - 2 - i;
+  return i;
+}
+
+void oracle_gaussian3x3(const float *src, int w, int h, int src_pitch, float *dst, int dst_pitch, float sigma) {
+  const double e1 = exp(-1.0 / (2.0 * (double)sigma * (double)sigma));
+  const double sum = 1.0 + 2.0 * e1;
+  const float k0 = (float)(1.0 / sum), k1 = (float)(e1 / sum);
+  float *rows = (float *)malloc(sizeof(float) * (size_t)w * (size_t)h);
+  for (int y = 0; y < h; ++y) {
+    const float *s = src + (long)y * src_pitch;
+    for (int x = 0; x < w; ++x)
+      rows[(long)y * w + x] = (s[reflect101(x - 1, w)] + s[reflect101(x + 1, w)]) * k1 + s[x] * k0;
+  }
+  for (int y = 0; y < h; ++y) {
+    const float *r0 = rows + (long)reflect101(y - 1, h) * w, *r1 = rows + (long)y * w,
+                *r2 = rows + (long)reflect101(y + 1, h) * w;
+    for (int x = 0; x < w; ++x) dst[(long)y * dst_pitch + x] = (r0[x] + r2[x]) * k1 + r1[x] * k0;
+  }
+  free(rows);
+}

@@ -92,6 +92,11 @@ void oracle_match_sift_data(oracle_sift_point *sift1, int n1, const oracle_sift_
 int oracle_match_filter(const oracle_sift_point *sift1, int n1, float score_threshold, float ambiguity_threshold,
                         int *idx);
 
+/* Caller-side front-end (main.cpp:300-318, test/detector.cpp:19-27): convertTo(CV_32FC1) and
+ * cv::GaussianBlur(Size(3,3), sigma).  The blur is PARITY UNPINNED (OpenCV is absent here; see the .c file). */
+void oracle_u8_to_f32(const unsigned char *src, int w, int h, int src_pitch, float *dst, int dst_pitch);
+void oracle_gaussian3x3(const float *src, int w, int h, int src_pitch, float *dst, int dst_pitch, float sigma);
+
 /* Software model of tex2D<float>(x, y) with cudaFilterModeLinear / clamp / unnormalised coords. */
 float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, int frac_bits);
 

@@ -92,6 +92,10 @@ class Oracle:
         lib.oracle_match_sift_data.restype = None
         lib.oracle_match_filter.argtypes = [_vp, C.c_int, C.c_float, C.c_float, _vp]
         lib.oracle_match_filter.restype = C.c_int
+        lib.oracle_u8_to_f32.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int]
+        lib.oracle_u8_to_f32.restype = None
+        lib.oracle_gaussian3x3.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_float]
+        lib.oracle_gaussian3x3.restype = None
         lib.oracle_tex2d.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
         lib.oracle_tex2d.restype = C.c_float
 
@@ -156,6 +160,20 @@ class Oracle:
         n = self.lib.oracle_match_filter(sift1.ctypes.data, len(sift1), score_threshold, ambiguity_threshold,
                                          idx.ctypes.data)
         return idx[:n]
+
+    def u8_to_f32(self, img_u8):
+        img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        h, w = img_u8.shape
+        out = np.zeros((h, w), dtype=np.float32)
+        self.lib.oracle_u8_to_f32(img_u8.ctypes.data, w, h, w, out.ctypes.data, w)
+        return out
+
+    def gaussian3x3(self, img, sigma):
+        img = _f32(img)
+        h, w = img.shape
+        out = np.zeros((h, w), dtype=np.float32)
+        self.lib.oracle_gaussian3x3(img.ctypes.data, w, h, w, out.ctypes.data, w, sigma)
+        return out
 
     def tex2d(self, img, w, h, x, y, frac_bits=8):
         img = _f32(img)

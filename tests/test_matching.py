@@ -117,6 +117,40 @@ def test_gpu_matcher_ragged_sizes(ctx, oracle, n1, n2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2", [(3000, 2900), (200, 5000), (5000, 130)])
+def test_gpu_matcher_column_splits_fold_to_the_single_scan(ctx, oracle, monkeypatch, n1, n2):
+    """The matcher splits image 2's columns over the grid (auto: several splits at these sizes) and folds the splits
+    in column order; forced to one split it is the plain scan.  Both must agree with each other and the oracle."""
+    rng = np.random.default_rng(n1 + n2)
+
+    def rand_pts(n):
+        p = np.zeros(n, dtype=SIFT_POINT_DTYPE)
+        d = np.abs(rng.normal(size=(n, 128))).astype(np.float32)
+        p["data"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        p["coords2D"] = rng.uniform(0, 1000, (n, 2)).astype(np.float32)
+        return p
+
+    s1, s2 = rand_pts(n1), rand_pts(n2)
+    for distance in (1, 0):
+        runs = {}
+        for splits in ("auto", "1", "7", "1000"):
+            if splits == "auto":
+                monkeypatch.delenv("CUSIFT_MATCH_SPLITS", raising=False)
+            else:
+                monkeypatch.setenv("CUSIFT_MATCH_SPLITS", splits)
+            runs[splits] = gpu_match(ctx, s1, s2, distance)
+        monkeypatch.delenv("CUSIFT_MATCH_SPLITS", raising=False)
+        for k in ("auto", "7", "1000"):
+            for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
+                np.testing.assert_array_equal(runs[k][f], runs["1"][f], err_msg="%s splits, %s" % (k, f))
+        want = s1.copy()
+        oracle.match(want, s2, distance)
+        np.testing.assert_allclose(runs["auto"]["score"], want["score"], atol=2e-6, rtol=0)
+        assert (runs["auto"]["match"] == want["match"]).mean() >= 0.99
+        np.testing.assert_array_equal(runs["auto"]["match_xpos"], s2["coords2D"][runs["auto"]["match"], 0])
+
+
+@pytest.mark.gpu
 def test_gpu_matcher_on_extracted_siftdata(ctx, oracle, gray1):
     """End to end: extract two views on the GPU, match them on the GPU, compare with the oracle's matcher."""
     from cusift_amd import capi

@@ -4,7 +4,7 @@ from cusift_amd import capi
 from cusift_amd.capi import DeviceBuffer, SIFT_POINT_DTYPE
 ctx=capi.Context(0)
 rng=np.random.default_rng(0)
-for n in (1024, 4096, 16384):
+for n in (1024, 2048, 4096, 8192, 16384, 32768):
     p=np.zeros(n,dtype=SIFT_POINT_DTYPE); d=np.abs(rng.normal(size=(n,128))).astype(np.float32); p["data"]=d/np.linalg.norm(d,axis=1,keepdims=True)
     d1=DeviceBuffer.from_numpy(ctx,p); d2=DeviceBuffer.from_numpy(ctx,p[::-1].copy())
     for _ in range(3): ctx.match(d1.ptr,n,d2.ptr,n,1)
