@@ -53,6 +53,7 @@ class Params(C.Structure):
         ("max_pts", C.c_int),
         ("tex_frac_bits", C.c_int),
         ("fused_detect", C.c_int),
+        ("root_sift", C.c_int),
     ]
 
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "cusift_memset": (_i, [_vp, _vp, _i, _sz]),
     "cusift_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "cusift_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "cusift_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "cusift_image_h2d": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "cusift_image_d2h": (_i, [_vp, _vp, _vp, _i, _i, _i]),
     "cusift_malloc_host": (_i, [C.POINTER(_vp), _sz]),

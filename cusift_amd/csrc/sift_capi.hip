@@ -32,8 +32,8 @@ __global__ void find_points_kernel(const float *, int, int, int, long, cusift_po
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                     const unsigned int *, float, float, RowWindow);
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
-                                   const unsigned int *, float, float, float, RowWindow);
-__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float);
+                                   const unsigned int *, float, float, float, RowWindow, int);
+__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int);
 __global__ void rootsift_kernel(cusift_point *, int);
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, int, MatchPartial *, int);
 __global__ void match_merge_kernel(cusift_point *, int, const cusift_point *, int, int, const MatchPartial *, int, int);
@@ -355,6 +355,7 @@ extern "C" void cusift_default_params(cusift_params *p) {
   p->max_pts = 1024;  // SiftData ctor default (cuSIFT.h:56)
   p->tex_frac_bits = 8;
   p->fused_detect = 1;
+  p->root_sift = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,6 +528,14 @@ extern "C" int cusift_memcpy_h2d(cusift_ctx *ctx, void *d_dst, const void *h_src
 extern "C" int cusift_memcpy_d2h(cusift_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
   if (!ctx || !h_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
   HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_memcpy_d2d(cusift_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+  if (!ctx || !d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  if (bytes == 0) return CUSIFT_OK;
+  HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSIFT_OK;
 }
@@ -812,7 +821,7 @@ static int orientations_impl(cusift_ctx *ctx, const float *d_img, int w, int h, 
 static int descriptors_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
                             cusift_point *d_points, int max_pts, const unsigned int *d_first,
                             const unsigned int *d_counters, float subsampling, int tex_frac_bits, int n_images,
-                            RowWindow rw) {
+                            RowWindow rw, int root_sift = 0) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -822,7 +831,7 @@ static int descriptors_impl(cusift_ctx *ctx, const float *d_img, int w, int h, i
   dim3 grid(keypoint_grid_x(max_pts, n_images), n_images);
   StageTimer t(ctx, CUSIFT_STAGE_DESCR);
   hipLaunchKernelGGL(descriptors_kernel, grid, dim3(64), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
-                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q, rw);
+                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q, rw, root_sift);
   return check_launch("extract_descriptors");
 }
 
@@ -989,8 +998,8 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     }
     TRY(cusift_compute_orientations(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
                                     d_counters, prm->tex_frac_bits, n_images));
-    TRY(cusift_extract_descriptors(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
-                                   d_counters, pl.sub[o], prm->tex_frac_bits, n_images));
+    TRY(descriptors_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst, d_counters,
+                         pl.sub[o], prm->tex_frac_bits, n_images, RowWindow{0, pl.h[o]}, prm->root_sift));
   }
   if (all_fused) {
     OctaveTable T;
@@ -1018,7 +1027,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     dim3 grid((unsigned int)std::max(1L, std::min(cap, (long)ctx->describe_grid)));
     StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
     hipLaunchKernelGGL(describe_all_kernel, grid, dim3(64), 0, ctx->stream, T, d_points, prm->max_pts, d_counters,
-                       n_images, q, inv_q);
+                       n_images, q, inv_q, prm->root_sift);
     TRY(check_launch("describe_all"));
   }
   return CUSIFT_OK;

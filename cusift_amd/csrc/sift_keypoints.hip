@@ -63,18 +63,18 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
   }
 }
 
-__device__ __forceinline__ float tex2d_patch(const float *lds, const PatchGeom &g, float x, float y, float q,
-                                             float inv_q) {
+template <int kStride, bool kQuant>
+__device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, float x, float y, float q, float inv_q) {
   const float xb = x - 0.5f, yb = y - 0.5f;
   const float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
-  if (q > 0.0f) {
+  if (kQuant) {
     a = floorf(fmaf(a, q, 0.5f)) * inv_q;
     b = floorf(fmaf(b, q, 0.5f)) * inv_q;
   }
-  const int i = (int)fx - g.x0, j = (int)fy - g.y0;
-  const float *p0 = lds + j * g.stride + i;
-  const float *p1 = p0 + g.stride;
+  const int i = (int)fx - x0, j = (int)fy - y0;
+  const float *p0 = lds + j * kStride + i;
+  const float *p1 = p0 + kStride;
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
   const float ia = 1.0f - a, ib = 1.0f - b;
   float t = (ia * ib) * s00;
@@ -93,18 +93,33 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // Where a keypoint's taps come from: an LDS patch (usual) or global memory (footprint larger than the patch).
-struct Sampler {
+// The choice is wave-uniform and made ONCE per keypoint -- the whole keypoint body is instantiated per sampler
+// type, so there is no branch, no runtime stride multiply and no vmcnt wait around the individual taps (with one
+// run-time Sampler the compiler guarded each of the 24 taps per lane with two branches).
+template <int kStride, bool kQuant>
+struct PatchSampler {
+  const float *patch;
+  int x0, y0;  // image coordinate of patch element (0,0)
+  float q, inv_q;
+  __device__ __forceinline__ float operator()(float x, float y) const {
+    return tex2d_patch<kStride, kQuant>(patch, x0, y0, x, y, q, inv_q);
+  }
+};
+struct GlobalSampler {
   const float *img;
   int w, h, pitch;
   RowWindow rw;
-  const float *patch;
-  PatchGeom g;
-  bool use_patch;  // wave-uniform
   float q, inv_q;
   __device__ __forceinline__ float operator()(float x, float y) const {
-    return use_patch ? tex2d_patch(patch, g, x, y, q, inv_q) : tex2d(img, w, h, pitch, rw, x, y, q, inv_q);
+    return tex2d(img, w, h, pitch, rw, x, y, q, inv_q);
   }
 };
+
+// A value every lane loaded from the same address, declared wave-uniform: it then lives in an SGPR and whatever
+// is derived from it alone (patch origin, loop bounds, the patch-or-global decision) is scalar work.
+__device__ __forceinline__ float uniform(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 // LDS of one keypoint wave (8.75 KB => 16 waves per CU together with the 1 KB prefix table of describe_all).
 // The descriptor's histogram buffers are only needed after its sampling phase, when the patch is dead, so they
@@ -137,8 +152,22 @@ struct OriShared {
 // 121 samples (11x11) -> 32-bin histogram: bins are lanes, each half-wave walks half of the samples in index
 // order, so the sums are deterministic and in the oracle's order.  Every lane returns the orientation (degrees).
 // ------------------------------------------------------------------------------------------------
-template <typename SH>
-__device__ __forceinline__ float kp_orientation(SH &S, const Sampler &tex, float kx, float ky, float scale, int tx) {
+// max over the 16 lanes of each DPP row, then over the row pairs (0,1) and (2,3): lanes 0..31 all return the
+// maximum of lanes 0..31.  max() is exact, so the order of the reduction does not matter.
+template <int kCtrl>
+__device__ __forceinline__ float dpp_perm(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), kCtrl, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float max_over_32(float v) {
+  v = fmaxf(v, dpp_perm<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_perm<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_perm<0x141>(v));  // row_half_mirror
+  v = fmaxf(v, dpp_perm<0x140>(v));  // row_mirror
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+
+template <typename SH, typename TEX>
+__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
   if (tx < 11) S.gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
   const float xp = kx - 5.0f;
@@ -189,27 +218,18 @@ __device__ __forceinline__ float kp_orientation(SH &S, const Sampler &tex, float
     const float v = S.hist[32 + tx];
     pk = (v > S.hist[32 + x1m] && v >= S.hist[32 + x1p]) ? v : 0.0f;
   }
-  wave_sync();
-  if (tx < 32) S.hist[tx] = pk;
-  wave_sync();
-  if (tx == 0) {
-    float maxval1 = 0.0f;
-    int i1 = -1;
-    for (int i = 0; i < 32; ++i) {
-      const float v = S.hist[i];
-      if (v > maxval1) {
-        maxval1 = v;
-        i1 = i;
-      }
-    }
-    const float val1 = S.hist[32 + ((i1 + 1) & 31)];
-    const float val2 = S.hist[32 + ((i1 + 31) & 31)];
-    const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);
-    S.gauss[0] = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-  }
-  wave_sync();
-  const float ori = S.gauss[0];
-  wave_sync();
+  // The reference's thread 0 scans the 32 peaks for the first strict maximum (cuSIFT_D.cu:369-379):
+  // maxval1 = max(0, max pk), i1 = first index that attains it, -1 if no peak is positive.  Same result from a
+  // wave reduction + ballot (pk is never NaN: it comes out of ordered comparisons).
+  const float maxval1 = max_over_32(pk);  // lanes >= 32 hold pk = 0 and reduce among themselves
+  const unsigned long long hit = __ballot(tx < 32 && pk == maxval1 && maxval1 > 0.0f);
+  const int i1 = hit ? (int)__builtin_ctzll(hit) : -1;
+  const float mv = uniform(maxval1);  // lane 0's value = the maximum of lanes 0..31
+  const float val1 = S.hist[32 + ((i1 + 1) & 31)];
+  const float val2 = S.hist[32 + ((i1 + 31) & 31)];
+  const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * mv - val1 - val2);
+  const float ori = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+  wave_sync();  // every lane has read hist before the caller reuses the buffers
   return ori;
 }
 
@@ -265,7 +285,8 @@ __device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float 
   myhist[angp] += v2;
 }
 
-__device__ __forceinline__ void kp_descriptor(KpShared &S, const Sampler &tex, const DescLaneConsts &C, float px,
+template <typename TEX>
+__device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const DescLaneConsts &C, float px,
                                               float py, float kp_scale, float orientation, int lane, float &out0,
                                               float &out1) {
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
@@ -374,6 +395,24 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const Sampler &tex, c
   out1 = b1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RootSIFT of one descriptor held in LDS (v[0..127]): ConvertSiftToRootSift_D, cuSIFT_D.cu:299-317 -- sequential
+// L1 sum in index order, then sqrtf(max(0.0, x) / sum) (the max promotes to double there).  Every lane forms the
+// same sum from broadcast reads.  Used by the stand-alone kernel and, with cusift_params.root_sift, as the
+// descriptor epilogue (the fusion the reference leaves as a TODO, cuSIFT.cu:376-379) -- same bits either way.
+// Lane l returns elements l and l+64.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rootsift_lanes(const float *v, int lane, float &o0, float &o1) {
+  float sum = 0.0f;
+#pragma unroll 16
+  for (int i = 0; i < 128; ++i) sum += v[i];
+  const float x0 = v[lane], x1 = v[lane + 64];
+  const double m0 = x0 > 0.0 ? (double)x0 : 0.0;
+  const double m1 = x1 > 0.0 ? (double)x1 : 0.0;
+  o0 = sqrtf((float)(m0 / sum));
+  o1 = sqrtf((float)(m1 / sum));
+}
+
 // patch that covers every tap within `reach` of (px, py); false if it does not fit kDescPatch^2
 __device__ __forceinline__ bool patch_for_reach(float px, float py, float reach, PatchGeom &g, int &pw, int &ph) {
   g.stride = kDescPatch;
@@ -403,17 +442,42 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
 
   for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
     cusift_point *pt = points + bx;
-    const float scale = pt->scale;
-    const float kx = pt->coords2D[0], ky = pt->coords2D[1];
+    const float scale = uniform(pt->scale);
+    const float kx = uniform(pt->coords2D[0]), ky = uniform(pt->coords2D[1]);
     // every tap lies in [k-6, k+6]; its 2x2 footprint starts at floor(k-6.5) .. floor(k+5.5): a 16x16 patch
-    Sampler tex{img, w, h, pitch, rw, S.patch, PatchGeom{0, 0, 16}, false, q, inv_q};
-    tex.use_patch = (fabsf(kx) < 1e6f) && (fabsf(ky) < 1e6f);
-    tex.g.x0 = (int)floorf(kx - 6.5f) - 1;
-    tex.g.y0 = (int)floorf(ky - 6.5f) - 1;
-    if (tex.use_patch) stage_patch(img, w, h, pitch, rw, S.patch, tex.g, 16, 16, tx);
-    const float ori = kp_orientation(S, tex, kx, ky, scale, tx);
+    const bool use_patch = (fabsf(kx) < 1e6f) && (fabsf(ky) < 1e6f);
+    float ori;
+    if (use_patch) {
+      const PatchGeom g{(int)floorf(kx - 6.5f) - 1, (int)floorf(ky - 6.5f) - 1, 16};
+      stage_patch(img, w, h, pitch, rw, S.patch, g, 16, 16, tx);
+      if (q > 0.0f)
+        ori = kp_orientation(S, PatchSampler<16, true>{S.patch, g.x0, g.y0, q, inv_q}, kx, ky, scale, tx);
+      else
+        ori = kp_orientation(S, PatchSampler<16, false>{S.patch, g.x0, g.y0, q, inv_q}, kx, ky, scale, tx);
+    } else {
+      ori = kp_orientation(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, kx, ky, scale, tx);
+    }
     if (tx == 0) pt->orientation = ori;
     wave_sync();
+  }
+}
+
+// RootSIFT epilogue (wave-uniform flag) + the record stores of ExtractSiftDescriptors_D, cuSIFT_D.cu:288-296
+__device__ __forceinline__ void finish_descriptor(KpShared &S, cusift_point *pt, float b0, float b1, float px,
+                                                  float py, float kscale, float sub, int lane, int root_sift) {
+  if (root_sift) {
+    float *v = S.fin();
+    v[lane] = b0;
+    v[lane + 64] = b1;
+    wave_sync();
+    rootsift_lanes(v, lane, b0, b1);
+  }
+  pt->data[lane] = b0;
+  pt->data[lane + 64] = b1;
+  if (lane == 0) {
+    pt->coords2D[0] = px * sub;
+    pt->coords2D[1] = py * sub;
+    pt->scale = kscale * sub;
   }
 }
 
@@ -424,7 +488,7 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
                                                         long img_stride, cusift_point *__restrict__ points,
                                                         int max_pts, const unsigned int *__restrict__ first,
                                                         const unsigned int *__restrict__ counters, float subsampling,
-                                                        float q, float inv_q, RowWindow rw) {
+                                                        float q, float inv_q, RowWindow rw, int root_sift) {
   __shared__ KpShared S;
   const int lane = threadIdx.x;
   img += (long)blockIdx.y * img_stride;
@@ -436,24 +500,28 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
 
   for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
     cusift_point *pt = points + bx;
-    const float px = pt->coords2D[0], py = pt->coords2D[1], kscale = pt->scale, ori = pt->orientation;
+    const float px = uniform(pt->coords2D[0]), py = uniform(pt->coords2D[1]);
+    const float kscale = uniform(pt->scale), ori = uniform(pt->orientation);
     // every tap is within `reach` of the keypoint: 7.5*spacing*(|cos|+|sin|) for the grid + 1 for the tap
     const float theta = 2.0f * 3.1415f / 360.0f * ori;
     const float reach = 7.5f * (12.0f / 16.0f * kscale) * (fabsf(cosf(theta)) + fabsf(sinf(theta))) + 1.0f + 0.01f;
-    Sampler tex{img, w, h, pitch, rw, S.patch, PatchGeom{0, 0, kDescPatch}, false, q, inv_q};
+    PatchGeom g;
     int pw, ph;
-    tex.use_patch = patch_for_reach(px, py, reach, tex.g, pw, ph);
-    if (tex.use_patch) stage_patch(img, w, h, pitch, rw, S.patch, tex.g, pw, ph, lane);
-    wave_sync();
+    const bool use_patch = patch_for_reach(px, py, reach, g, pw, ph);
     float b0, b1;
-    kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
-    pt->data[lane] = b0;
-    pt->data[lane + 64] = b1;
-    if (lane == 0) {  // cuSIFT_D.cu:292-296
-      pt->coords2D[0] = px * subsampling;
-      pt->coords2D[1] = py * subsampling;
-      pt->scale = kscale * subsampling;
+    if (use_patch) {
+      stage_patch(img, w, h, pitch, rw, S.patch, g, pw, ph, lane);
+      wave_sync();
+      if (q > 0.0f)
+        kp_descriptor(S, PatchSampler<kDescPatch, true>{S.patch, g.x0, g.y0, q, inv_q}, C, px, py, kscale, ori, lane,
+                      b0, b1);
+      else
+        kp_descriptor(S, PatchSampler<kDescPatch, false>{S.patch, g.x0, g.y0, q, inv_q}, C, px, py, kscale, ori, lane,
+                      b0, b1);
+    } else {
+      kp_descriptor(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, px, py, kscale, ori, lane, b0, b1);
     }
+    finish_descriptor(S, pt, b0, b1, px, py, kscale, subsampling, lane, root_sift);
     wave_sync();
   }
 }
@@ -465,9 +533,20 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
 // -- so images with more keypoints do not leave the rest of the grid idle, one patch load serves both stages,
 // and 2 x octaves launches become one.  Same device functions as the two stage kernels => same results.
 // ------------------------------------------------------------------------------------------------
+template <typename TEX>
+__device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, const DescLaneConsts &C,
+                                                  cusift_point *pt, float px, float py, float kscale, float sub,
+                                                  int lane, int root_sift) {
+  const float ori = kp_orientation(S, tex, px, py, kscale, lane);
+  float b0, b1;
+  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
+  if (lane == 0) pt->orientation = ori;
+  finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
+}
+
 __global__ void __launch_bounds__(64) describe_all_kernel(OctaveTable T, cusift_point *__restrict__ points, int max_pts,
                                                          const unsigned int *__restrict__ counters, int n_images,
-                                                         float q, float inv_q) {
+                                                         float q, float inv_q, int root_sift) {
   __shared__ KpShared S;
   __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
   const int lane = threadIdx.x;
@@ -490,36 +569,32 @@ __global__ void __launch_bounds__(64) describe_all_kernel(OctaveTable T, cusift_
   const DescLaneConsts C = desc_lane_consts(lane);
   const int exp0 = (__float_as_int(T.sub[0]) >> 23) & 0xff;
 
+  int im = 0;  // image of the current item; items are visited in increasing order, so it only moves forward
   for (unsigned int g = blockIdx.x; g < total; g += gridDim.x) {
-    // image of item g: last i with prefix[i] <= g
-    int lo = 0, hi_ = n_images;
-    while (hi_ - lo > 1) {
-      const int mid = (lo + hi_) >> 1;
-      if (s_prefix[mid] <= g) lo = mid; else hi_ = mid;
-    }
-    cusift_point *pt = points + (long)lo * max_pts + (g - s_prefix[lo]);
-    const float px = pt->coords2D[0], py = pt->coords2D[1], kscale = pt->scale, sub = pt->subsampling;
+    while (__builtin_amdgcn_readfirstlane(s_prefix[im + 1]) <= g) ++im;  // ends: g < total = s_prefix[n_images]
+    cusift_point *pt = points + (long)im * max_pts + (g - __builtin_amdgcn_readfirstlane(s_prefix[im]));
+    const float px = uniform(pt->coords2D[0]), py = uniform(pt->coords2D[1]);
+    const float kscale = uniform(pt->scale), sub = uniform(pt->subsampling);
     int o = ((__float_as_int(sub) >> 23) & 0xff) - exp0;  // subsampling = sub0 * 2^octave
     o = clampi(o, 0, T.n_oct - 1);
-    const float *img = T.base[o] + (long)lo * T.stride[o];
+    const float *img = T.base[o] + (long)im * T.stride[o];
     const int w = T.w[o], h = T.h[o], pitch = T.pitch[o];
     const RowWindow rw{0, h};
     // one patch for both stages: orientation taps reach 6 px, descriptor taps 7.5*spacing*sqrt(2)+1 at most
     const float reach = fmaxf(7.5f * (12.0f / 16.0f * kscale) * 1.41422f + 1.0f + 0.01f, 6.0f);
-    Sampler tex{img, w, h, pitch, rw, S.patch, PatchGeom{0, 0, kDescPatch}, false, q, inv_q};
+    PatchGeom pg;
     int pw, ph;
-    tex.use_patch = patch_for_reach(px, py, reach, tex.g, pw, ph);
-    if (tex.use_patch) stage_patch(img, w, h, pitch, rw, S.patch, tex.g, pw, ph, lane);
-    const float ori = kp_orientation(S, tex, px, py, kscale, lane);
-    float b0, b1;
-    kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
-    pt->data[lane] = b0;
-    pt->data[lane + 64] = b1;
-    if (lane == 0) {
-      pt->orientation = ori;
-      pt->coords2D[0] = px * sub;
-      pt->coords2D[1] = py * sub;
-      pt->scale = kscale * sub;
+    const bool use_patch = patch_for_reach(px, py, reach, pg, pw, ph);
+    if (use_patch) {
+      stage_patch(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
+      if (q > 0.0f)
+        describe_keypoint(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
+                          sub, lane, root_sift);
+      else
+        describe_keypoint(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
+                          sub, lane, root_sift);
+    } else {
+      describe_keypoint(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift);
     }
     wave_sync();
   }
@@ -527,30 +602,20 @@ __global__ void __launch_bounds__(64) describe_all_kernel(OctaveTable T, cusift_
 
 // ------------------------------------------------------------------------------------------------
 // ConvertSiftToRootSift: reference cuSIFT_D.cu:299-317 (sequential L1 sum, sqrt(max(0,v)/sum)).
-// One wave per point; the 128-term sum is kept sequential (lane 0) to match the reference order.
+// One wave per point; the 128-term sum is kept sequential to match the reference order (rootsift_lanes).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) rootsift_kernel(cusift_point *__restrict__ points, int num_pts) {
   __shared__ float v[128];
-  __shared__ float s_sum;
   const int lane = threadIdx.x;
   for (int p = blockIdx.x; p < num_pts; p += gridDim.x) {
     cusift_point *pt = points + p;
     v[lane] = pt->data[lane];
     v[lane + 64] = pt->data[lane + 64];
     __syncthreads();
-    if (lane == 0) {
-      float sum = 0.0f;
-      for (int i = 0; i < 128; ++i) sum += v[i];
-      s_sum = sum;
-    }
-    __syncthreads();
-    const float sum = s_sum;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const float x = v[lane + 64 * r];
-      const double m = x > 0.0 ? (double)x : 0.0;
-      pt->data[lane + 64 * r] = sqrtf((float)(m / sum));
-    }
+    float o0, o1;
+    rootsift_lanes(v, lane, o0, o1);
+    pt->data[lane] = o0;
+    pt->data[lane + 64] = o1;
     __syncthreads();
   }
 }

@@ -215,11 +215,15 @@ class SiftData {
   float peakThresh;
   float edgeThresh;
   float lowestScale;
+  // new: emit RootSIFT descriptors from Extract (fused into the descriptor kernel; the reference's commented-out
+  // ExtractRootSift, cuSIFT.cu:122-134, ran ConvertSiftToRootSift as a second pass).  Last field: layout of the
+  // reference's members is unchanged.
+  bool rootSift;
 
   // cuSIFT.cu:13-32
   explicit SiftData(int maxPts_ = 1024, bool host = false, bool dev = false)
       : numPts(0), maxPts(0), h_data(nullptr), d_data(nullptr), numOctaves(5), numScales(5), initBlur(0.0),
-        initSubsampling(1.0f), peakThresh(0.1f), edgeThresh(10.0f), lowestScale(0.0f) {
+        initSubsampling(1.0f), peakThresh(0.1f), edgeThresh(10.0f), lowestScale(0.0f), rootSift(false) {
     allocate(maxPts_, host, dev);
   }
   ~SiftData() { release(); }
@@ -298,6 +302,7 @@ class SiftData {
     p.lowest_scale = lowestScale;
     p.subsampling = subsampling;
     p.max_pts = maxPts;
+    p.root_sift = rootSift ? 1 : 0;
     return p;
   }
   void require_device(const char *who) const {
@@ -340,7 +345,22 @@ inline void ExtractSift(SiftData &siftData, cuImage &img, int numOctaves, double
   siftData.peakThresh = thresh;
   siftData.lowestScale = lowestScale;
   siftData.edgeThresh = 10.0f;
+  siftData.rootSift = false;
   siftData.Extract(img, subsampling);
+}
+// The reference's ExtractRootSift is commented out ("TODO: bring rootsift back", cuSIFT.cu:122-134: ExtractSift,
+// then ConvertSiftToRootSift, then Synchronize; its argument list lost thresh/lowestScale).  Same result in one
+// pass: RootSIFT is the descriptor kernel's epilogue.
+inline void ExtractRootSift(SiftData &siftData, cuImage &img, int numOctaves, double initBlur, float thresh,
+                            float lowestScale = 0.0f, float subsampling = 1.0f) {
+  siftData.numOctaves = numOctaves;
+  siftData.initBlur = initBlur;
+  siftData.peakThresh = thresh;
+  siftData.lowestScale = lowestScale;
+  siftData.edgeThresh = 10.0f;
+  siftData.rootSift = true;
+  siftData.Extract(img, subsampling);
+  siftData.rootSift = false;
 }
 
 #endif  // CUSIFT_AMD_DROPIN_H

@@ -70,6 +70,9 @@ typedef struct cusift_params {
   int fused_detect;    /* 1 (default): the drivers run LaplaceMulti+FindPointsMulti as one kernel that keeps the
                           DoG planes on chip, and orientation+descriptor of all octaves as one launch after the
                           last detection (identical results); 0: the reference's per-octave stage sequence */
+  int root_sift;       /* 0 (default): SIFT descriptors; 1: the drivers emit RootSIFT -- ConvertSiftToRootSift
+                          (cuSIFT.cu:383-395) applied in the descriptor kernel's epilogue, the fusion the reference
+                          leaves as a TODO (cuSIFT.cu:122-134,376-379); same bits as extract + cusift_rootsift() */
 } cusift_params;
 
 typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */
@@ -121,6 +124,8 @@ int cusift_memset(cusift_ctx *ctx, void *d_ptr, int value, size_t bytes);
 /* SiftData::Synchronize (cuSIFT.cu:52-59) and raw copies; blocking. */
 int cusift_memcpy_h2d(cusift_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int cusift_memcpy_d2h(cusift_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* cudaMemcpyDeviceToDevice as AddSiftData uses it when it grows a SiftData (extras/debug.cpp:436-441); blocking. */
+int cusift_memcpy_d2d(cusift_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* cuImage::HostToDevice / DeviceToHost (cuImage.cu:83-117): dense host rows (w floats) <-> pitched device rows. */
 int cusift_image_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const float *h_src, int w, int h);
 int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_src, int src_pitch, int w, int h);

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "cuImage.h"
@@ -131,6 +132,30 @@ int main(int argc, char **argv) {
   for (int k = 0; k < 128; k++) l2 += (double)siftData1.h_data[0].data[k] * siftData1.h_data[0].data[k];
   std::printf("RootSIFT |d|^2 of point 0: %.6f\n", l2);
   if (std::fabs(l2 - 1.0) > 1e-4) ++failures;
+  {
+    // ExtractRootSift (the reference's commented-out entry point, cuSIFT.cu:122-134): RootSIFT as the descriptor
+    // kernel's epilogue must give the bits of ExtractSift + ConvertSiftToRootSift.  Compared on the deterministic
+    // coarse-octave block (the octave-0 tail of the capped run is order-dependent).
+    SiftData siftData2;
+    InitSiftData(siftData2, 4096, true, true);
+    ExtractRootSift(siftData2, img1, 6, 0.0f, 0.1f, 0.0f);
+    int same = 0, matched = 0;
+    for (int i = 0; i < 1555; i++) {
+      const SiftPoint &a = siftData1.h_data[i];
+      for (int j = 0; j < 1555; j++) {
+        const SiftPoint &b = siftData2.h_data[j];
+        if (a.coords2D[0] == b.coords2D[0] && a.coords2D[1] == b.coords2D[1] && a.scale == b.scale) {
+          ++matched;
+          same += std::memcmp(a.data, b.data, sizeof(a.data)) == 0;
+          break;
+        }
+      }
+    }
+    std::printf("ExtractRootSift: %d points; coarse block %d matched, %d bit-identical descriptors\n", siftData2.numPts,
+                matched, same);
+    if (siftData2.numPts != siftData1.numPts || matched != 1555 || same != 1555) ++failures;
+    FreeSiftData(siftData2);
+  }
   FreeSiftData(siftData1);
 
   delete siftData;

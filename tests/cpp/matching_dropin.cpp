@@ -7,47 +7,22 @@
 #include <vector>
 
 #include "cuSIFT.h"
+#include "debug.h"
 #include "matching.h"
-
-// extras/debug.cpp:118-165 (ReadVLFeatSiftData) + :413-454 (AddSiftData): host records -> SiftData (host + device)
-static bool read_vlfeat(SiftData &data, const char *path) {
-  FILE *fp = std::fopen(path, "rb");
-  if (!fp) return false;
-  uint32_t n = 0;
-  if (std::fread(&n, sizeof(n), 1, fp) != 1) return false;
-  std::vector<float> pts(4 * (size_t)n), desc(128 * (size_t)n);
-  if (std::fread(pts.data(), sizeof(float), pts.size(), fp) != pts.size()) return false;
-  if (std::fread(desc.data(), sizeof(float), desc.size(), fp) != desc.size()) return false;
-  std::fclose(fp);
-  InitSiftData(data, (int)n, true, true);
-  std::memset(data.h_data, 0, sizeof(SiftPoint) * n);
-  for (uint32_t i = 0; i < n; i++) {
-    data.h_data[i].coords2D[0] = pts[4 * i];
-    data.h_data[i].coords2D[1] = pts[4 * i + 1];
-    data.h_data[i].scale = pts[4 * i + 2];
-    data.h_data[i].orientation = pts[4 * i + 3];
-    std::memcpy(data.h_data[i].data, &desc[128 * (size_t)i], sizeof(float) * 128);
-  }
-  data.numPts = (int)n;
-  safeCall(cusift_memcpy_h2d(cusift_dropin::ctx(), data.d_data, data.h_data, sizeof(SiftPoint) * n));
-  return true;
-}
 
 int main(int argc, char **argv) {
   if (argc < 4) return 2;
   InitCuda(0);
   int failures = 0;
   {
+    // test/test.cpp:30-38: default-constructed SiftData filled by ReadVLFeatSiftData -> AddSiftData
     SiftData siftData1, siftData2;
-    if (!read_vlfeat(siftData1, argv[1]) || !read_vlfeat(siftData2, argv[2])) return 2;
-    FILE *fp = std::fopen(argv[3], "rb");
-    if (!fp) return 2;
-    uint32_t numMatches = 0;
-    if (std::fread(&numMatches, sizeof(uint32_t), 1, fp) != 1) return 2;
+    if (ReadVLFeatSiftData(siftData1, argv[1]) < 0 || ReadVLFeatSiftData(siftData2, argv[2]) < 0) return 2;
+    const int n = ReadMATLABMatchIndices(argv[3]);
+    if (n < 0) return 2;
+    const uint32_t numMatches = (uint32_t)n;
     std::vector<uint32_t> indices_i(numMatches), indices_j(numMatches);
-    if (std::fread(indices_i.data(), sizeof(uint32_t), numMatches, fp) != numMatches) return 2;
-    if (std::fread(indices_j.data(), sizeof(uint32_t), numMatches, fp) != numMatches) return 2;
-    std::fclose(fp);
+    if (ReadMATLABMatchIndices(argv[3], indices_i.data(), indices_j.data()) != n) return 2;
 
     // TEST(Matching, MatchingTest)
     std::vector<SiftMatch *> matches = MatchSiftData(siftData1, siftData2, MatchSiftDistanceL2);
@@ -64,6 +39,33 @@ int main(int argc, char **argv) {
     std::printf("ratio test: %zu matches (reference expects 340)\n", matches.size());
     if (matches.size() != 340) ++failures;
     for (SiftMatch *m : matches) delete m;
+  }
+  {
+    // AddSiftData (extras/debug.cpp:413-454): growth by doubling keeps host and device copies in step, and the
+    // dump format round-trips (WriteVLFeatSiftData -> ReadVLFeatSiftData)
+    SiftData a, b;
+    if (ReadVLFeatSiftData(a, argv[1]) < 0) return 2;
+    const int n1 = a.numPts, cap1 = a.maxPts;
+    std::vector<SiftPoint> again(a.h_data, a.h_data + n1);
+    AddSiftData(a, again.data(), n1);  // 884 + 884 > 1024 -> capacity doubles
+    AddSiftData(a, again.data(), n1);  // 2652 > 2048 -> doubles again
+    std::printf("AddSiftData: %d -> %d points, capacity %d -> %d\n", n1, a.numPts, cap1, a.maxPts);
+    if (a.numPts != 3 * n1 || a.maxPts != 4 * cap1) ++failures;
+    std::vector<SiftPoint> dev(a.numPts);
+    safeCall(cusift_memcpy_d2h(cusift_dropin::ctx(), dev.data(), a.d_data, sizeof(SiftPoint) * a.numPts));
+    if (std::memcmp(dev.data(), a.h_data, sizeof(SiftPoint) * a.numPts) != 0) ++failures;
+    for (int k = 0; k < 3; k++)
+      if (std::memcmp(a.h_data + k * n1, again.data(), sizeof(SiftPoint) * n1) != 0) ++failures;
+    const char *tmp = "/tmp/cusift_dropin_roundtrip.bin";
+    if (!WriteVLFeatSiftData(a, tmp) || ReadVLFeatSiftData(b, tmp) != a.numPts) ++failures;
+    int same = 0;
+    for (int i = 0; i < a.numPts && i < b.numPts; i++)
+      same += a.h_data[i].coords2D[0] == b.h_data[i].coords2D[0] && a.h_data[i].scale == b.h_data[i].scale &&
+              a.h_data[i].orientation == b.h_data[i].orientation &&
+              std::memcmp(a.h_data[i].data, b.h_data[i].data, sizeof(a.h_data[i].data)) == 0;
+    std::printf("dump round trip: %d / %d records identical\n", same, a.numPts);
+    if (same != a.numPts) ++failures;
+    std::remove(tmp);
   }
   cusift_dropin::shutdown();
   std::printf(failures ? "FAILED (%d)\n" : "PASSED\n", failures);

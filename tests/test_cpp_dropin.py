@@ -30,6 +30,12 @@ def test_dropin_header_exports_the_reference_surface():
                    "FreeSiftData(", "ScaleDown(", "InitCuda(", "ConvertSiftToRootSift", "Synchronize"):
         assert needle in text, needle
     assert "#include <hip" not in text and "cuda_runtime" not in text  # plain C++ over the C ABI
+    assert "ExtractRootSift(" in text
+    dbg = open(os.path.join(ROOT, "include", "debug.h")).read()
+    for needle in ("AddSiftData(", "ReadVLFeatSiftData(", "WriteVLFeatSiftData(", "ReadMATLABMatchIndices(",
+                   "PrintSiftData("):
+        assert needle in dbg, needle
+    assert "#include <hip" not in dbg and "opencv" not in dbg.replace("OpenCV", "")
 
 
 @pytest.mark.gpu
@@ -43,6 +49,7 @@ def test_dropin_detector_program_passes_on_gpu():
     assert "PASSED" in out.stdout
     assert "num pts: golden 4096, extracted 4096" in out.stdout
     assert "Total time incl memory" in out.stdout  # the reference prints this on every call (cuSIFT.cu:117-119)
+    assert "coarse block 1555 matched, 1555 bit-identical descriptors" in out.stdout  # ExtractRootSift
 
 
 @pytest.mark.gpu
@@ -55,3 +62,6 @@ def test_dropin_matching_program_passes_on_gpu():
     print(out.stdout[-2000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "326 / 326 agree" in out.stdout and "ratio test: 340 matches" in out.stdout
+    # extras/debug.h surface: AddSiftData doubling (884 -> 2652 points, 1024 -> 4096 slots), dump round trip
+    assert "AddSiftData: 884 -> 2652 points, capacity 1024 -> 4096" in out.stdout
+    assert "dump round trip: 2652 / 2652 records identical" in out.stdout

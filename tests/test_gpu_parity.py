@@ -373,6 +373,31 @@ def gpu_extract(ctx, img, **kw):
     return h_pts[:n]
 
 
+def canonical(p):
+    return p[np.lexsort((p["scale"], p["coords2D"][:, 0], p["coords2D"][:, 1], -p["subsampling"]))]
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_root_sift_epilogue_equals_second_pass(ctx, oracle, gray1, fused):
+    """cusift_params.root_sift (the fusion the reference leaves as a TODO, cuSIFT.cu:122-134,376-379): RootSIFT as
+    the descriptor kernel's epilogue == Extract followed by ConvertSiftToRootSift, bit for bit, on both drivers;
+    and it is the oracle's RootSIFT of the plain descriptors."""
+    kw = dict(num_octaves=4, peak_thresh=0.5, max_pts=8192, fused_detect=fused)
+    plain = canonical(gpu_extract(ctx, gray1, **kw))
+    rooted = canonical(gpu_extract(ctx, gray1, root_sift=1, **kw))
+    assert len(plain) == len(rooted) > 1000
+    for f in ("coords2D", "scale", "orientation", "sharpness", "edgeness", "subsampling"):
+        assert np.array_equal(plain[f], rooted[f]), f
+    d_pts = DeviceBuffer.from_numpy(ctx, plain)
+    ctx.rootsift(d_pts.ptr, len(plain))
+    second_pass = d_pts.to_numpy(SIFT_POINT_DTYPE, (len(plain),))
+    assert np.array_equal(second_pass["data"], rooted["data"])
+    want = plain.copy()
+    oracle.rootsift(want, len(want))
+    np.testing.assert_allclose(rooted["data"], want["data"], rtol=2e-7, atol=1e-9)
+    np.testing.assert_allclose((rooted["data"].astype(np.float64) ** 2).sum(axis=1), 1.0, atol=1e-5)
+
+
 def compare_sets(want, got, frac_ok=0.99):
     """Set-wise comparison of two extractions of the same image.
 
