@@ -109,6 +109,10 @@ SIGNATURES = {
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "cusift_pack_points": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
+    "cusift_graph_create": (_i, [_vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
+    "cusift_graph_launch": (_i, [_vp]),
+    "cusift_graph_nodes": (_i, [_vp]),
+    "cusift_graph_destroy": (_i, [_vp]),
     "cusift_extract": (_i, [_vp, _vp, _i, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
     "cusift_extract_host": (_i, [_vp, _vp, _i, _i, _PP, _vp, _vp, C.POINTER(_i)]),
 }
@@ -329,6 +333,10 @@ class Context:
         check(lib().cusift_extract_batch(self.handle, d_imgs, n_images, w, h, pitch, image_stride, C.byref(params),
                                          d_points, d_counters))
 
+    def record_graph(self, d_imgs, n_images, w, h, pitch, image_stride, params, d_points, d_counters):
+        """cusift_graph_create: extract_batch for fixed buffers, recorded once as a hipGraph (see ExtractGraph)."""
+        return ExtractGraph(self, d_imgs, n_images, w, h, pitch, image_stride, params, d_points, d_counters)
+
     def extract(self, d_img, w, h, pitch, params, d_points, h_points=None):
         n = C.c_int(0)
         hp = h_points.ctypes.data if h_points is not None else None
@@ -343,6 +351,34 @@ class Context:
         check(lib().cusift_extract_host(self.handle, img.ctypes.data, w, h, C.byref(params), d_points, hp,
                                         C.byref(n)))
         return n.value
+
+
+class ExtractGraph:
+    """A recorded extract_batch (cusift_graph_*): launch() replays all of its kernels with one host call."""
+
+    def __init__(self, ctx, d_imgs, n_images, w, h, pitch, image_stride, params, d_points, d_counters):
+        self._g = C.c_void_p()
+        self.ctx = ctx  # keeps the context alive
+        check(lib().cusift_graph_create(ctx.handle, C.byref(self._g), d_imgs, n_images, w, h, pitch, image_stride,
+                                        C.byref(params), d_points, d_counters))
+
+    @property
+    def nodes(self):
+        return lib().cusift_graph_nodes(self._g)
+
+    def launch(self):
+        check(lib().cusift_graph_launch(self._g))
+
+    def close(self):
+        if self._g:
+            lib().cusift_graph_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def kernel_occupancy(name):

@@ -1033,6 +1033,95 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   return CUSIFT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// replayable extraction: the launch sequence of cusift_extract_batch recorded once as a hipGraph
+// ------------------------------------------------------------------------------------------------
+struct cusift_graph {
+  cusift_ctx *ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  size_t arena_bytes = 0;  // the recording refers to the arena as it was: a later growth invalidates it
+  char *arena = nullptr;
+  int nodes = 0;
+};
+
+extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const float *d_imgs, int n_images, int w, int h,
+                                   int pitch, size_t image_stride, const cusift_params *prm, cusift_point *d_points,
+                                   unsigned int *d_counters) {
+  if (!ctx || !out) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (!ctx->stream) return fail(CUSIFT_ERR_INVALID, "graph capture needs a real stream (the context borrows the null stream)");
+  Plan pl;
+  TRY(make_plan(pl, n_images, w, h, pitch, prm));
+  // everything that allocates or synchronises happens before the capture starts
+  TRY(ensure_arena(ctx, pl.total));
+  bool need_dog = !prm->fused_detect || getenv("CUSIFT_FORCE_GENERIC");
+  for (int o = 0; o < pl.n_oct && !need_dog; ++o) {
+    const float *b = o == 0 ? d_imgs : (const float *)(ctx->arena + pl.base_off[o]);
+    const size_t st = o == 0 ? image_stride : (size_t)pl.h[o] * pl.p[o];
+    if (!detect_fused_ok(b, pl.w[o], pl.h[o], pl.p[o], st)) need_dog = true;
+  }
+  if (need_dog) TRY(ensure_dog(ctx, pl.dog_bytes));  // the two-stage path's DoG planes
+  if (ctx->describe_grid == 0) {
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, describe_all_kernel, 64, 0));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    ctx->describe_grid = std::max(1, per_cu) * std::max(1, cus);
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const bool timing = ctx->timing;
+  ctx->timing = false;  // event records are not part of the recording
+  cusift_graph *g = new cusift_graph();
+  g->ctx = ctx;
+  hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    ctx->timing = timing;
+    delete g;
+    return fail(CUSIFT_ERR_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+  }
+  const int rc = cusift_extract_batch(ctx, d_imgs, n_images, w, h, pitch, image_stride, prm, d_points, d_counters);
+  e = hipStreamEndCapture(ctx->stream, &g->graph);
+  ctx->timing = timing;
+  if (rc != CUSIFT_OK || e != hipSuccess || !g->graph) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    if (rc != CUSIFT_OK) return rc;
+    return fail(CUSIFT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return fail(CUSIFT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
+  size_t n_nodes = 0;
+  (void)hipGraphGetNodes(g->graph, nullptr, &n_nodes);
+  g->nodes = (int)n_nodes;
+  g->arena = ctx->arena;
+  g->arena_bytes = ctx->arena_bytes;
+  *out = g;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_graph_launch(cusift_graph *g) {
+  if (!g || !g->exec) return fail(CUSIFT_ERR_INVALID, "graph is NULL");
+  if (g->ctx->arena != g->arena || g->ctx->arena_bytes != g->arena_bytes)
+    return fail(CUSIFT_ERR_INVALID, "the context's arena was re-allocated after this graph was recorded; record it again");
+  HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_graph_nodes(cusift_graph *g) { return g ? g->nodes : 0; }
+
+extern "C" int cusift_graph_destroy(cusift_graph *g) {
+  if (!g) return CUSIFT_OK;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, const cusift_params *prm,
                               cusift_point *d_points, cusift_point *h_points, int *num_pts) {
   if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");

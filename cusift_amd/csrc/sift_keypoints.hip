@@ -72,8 +72,11 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, f
     a = floorf(fmaf(a, q, 0.5f)) * inv_q;
     b = floorf(fmaf(b, q, 0.5f)) * inv_q;
   }
-  const int i = (int)fx - x0, j = (int)fy - y0;
-  const float *p0 = lds + j * kStride + i;
+  // element index (fy - y0) * kStride + (fx - x0), formed in floating point: all three terms are small integers
+  // (patch_for_reach bounds |coordinates| by 1e5), so the fma is exact -- one v_fma + one v_cvt instead of two
+  // conversions, two integer subtractions and an integer multiply
+  const int e = (int)fmaf(fy - (float)y0, (float)kStride, fx - (float)x0);
+  const float *p0 = lds + e;
   const float *p1 = p0 + kStride;
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
   const float ia = 1.0f - a, ib = 1.0f - b;
@@ -294,8 +297,8 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   float *fin = S.fin(), *sums = S.sums();
   const int next_cell_base = 8 * (cell + 1);
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
-  const float sina = sinf(theta);
-  const float cosa = cosf(theta);
+  float sina, cosa;
+  sincosf(theta, &sina, &cosa);  // OCML: one argument reduction, the same polynomials as sinf() and cosf()
   const float scale = 12.0f / 16.0f * kp_scale;
   const float ssina = scale * sina;
   const float scosa = scale * cosa;
@@ -420,7 +423,7 @@ __device__ __forceinline__ bool patch_for_reach(float px, float py, float reach,
   g.y0 = (int)floorf(py - reach - 0.5f) - 1;
   pw = (int)floorf(px + reach - 0.5f) + 2 - g.x0 + 1;
   ph = (int)floorf(py + reach - 0.5f) + 2 - g.y0 + 1;
-  return (reach < 0.5f * kDescPatch) && (fabsf(px) < 1e6f) && (fabsf(py) < 1e6f) && pw <= kDescPatch &&
+  return (reach < 0.5f * kDescPatch) && (fabsf(px) < 1e5f) && (fabsf(py) < 1e5f) && pw <= kDescPatch &&
          ph <= kDescPatch;
 }
 
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
     const float scale = uniform(pt->scale);
     const float kx = uniform(pt->coords2D[0]), ky = uniform(pt->coords2D[1]);
     // every tap lies in [k-6, k+6]; its 2x2 footprint starts at floor(k-6.5) .. floor(k+5.5): a 16x16 patch
-    const bool use_patch = (fabsf(kx) < 1e6f) && (fabsf(ky) < 1e6f);
+    const bool use_patch = (fabsf(kx) < 1e5f) && (fabsf(ky) < 1e5f);
     float ori;
     if (use_patch) {
       const PatchGeom g{(int)floorf(kx - 6.5f) - 1, (int)floorf(ky - 6.5f) - 1, 16};

@@ -231,6 +231,21 @@ int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsi
 int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_images, int w, int h, int pitch,
                          size_t image_stride, const cusift_params *p, cusift_point *d_points,
                          unsigned int *d_counters);
+/* Replayable form of cusift_extract_batch for a caller that extracts again and again from the SAME buffers and
+ * geometry (a video pipeline: new frame copied into d_imgs, results read from d_points): the launch sequence is
+ * recorded once into a hipGraph and replayed with one call, which removes the per-launch host cost that bounds
+ * single-image latency (a 5-octave 1080p extraction is 11 short dependent kernels).  New: the reference has no
+ * counterpart (it re-creates textures, symbols and buffers on every call, cuSIFT.cu:61-120).
+ * The context must own or borrow a real stream (not the null stream).  The recording refers to the context's
+ * scratch arena: a later call that grows the arena invalidates it (cusift_graph_launch then fails with
+ * CUSIFT_ERR_INVALID).  cusift_graph_launch is asynchronous on the context's stream. */
+typedef struct cusift_graph cusift_graph;
+int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const float *d_imgs, int n_images, int w, int h,
+                        int pitch, size_t image_stride, const cusift_params *p, cusift_point *d_points,
+                        unsigned int *d_counters);
+int cusift_graph_launch(cusift_graph *g);
+int cusift_graph_nodes(cusift_graph *g); /* kernel/memset/copy nodes in the recording */
+int cusift_graph_destroy(cusift_graph *g);
 /* The legacy ExtractSift(siftData, cuImage&, numOctaves, initBlur, thresh, lowestScale, subsampling)
  * (main.cpp:99-103,324-328; cuSIFT.cu:123-134): image already on the device.  Blocking; writes
  * *num_pts = min(count, max_pts) (cuSIFT.cu:107-110) and, if h_points != NULL, copies that many

@@ -507,6 +507,60 @@ def test_extract_device_image_and_odd_size(ctx, oracle):
     compare_sets(want, h_pts[:n])
 
 
+def test_graph_replay_equals_eager(ctx, gray1):
+    """cusift_graph_*: the recorded launch sequence replays to the same SiftData as the eager driver, also after the
+    caller has put a new frame into the same input buffer (the use it exists for)."""
+    h, w = gray1.shape
+    kw = dict(num_octaves=5, init_blur=0.0, peak_thresh=0.5, max_pts=8192)
+    prm = capi.default_params(**kw)
+    frames = [gray1, np.roll(gray1, (31, 77), axis=(0, 1)), gray1[::-1].copy()]
+    src = pitched(frames[0])
+    p = src.shape[1]
+    d_img = DeviceBuffer.from_numpy(ctx, src)
+    d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
+    d_cnt = DeviceBuffer(ctx, 4)
+
+    def read():
+        ctx.synchronize()
+        n = min(int(d_cnt.to_numpy(np.uint32, (1,))[0]), prm.max_pts)
+        return canonical(d_pts.to_numpy(SIFT_POINT_DTYPE, (prm.max_pts,))[:n])
+
+    graph = ctx.record_graph(d_img.ptr, 1, w, h, p, h * p, prm, d_pts.ptr, d_cnt.ptr)
+    assert graph.nodes >= 10  # memset + 4 ScaleDown + 5 detections + describe_all
+    for f in frames:
+        ctx.h2d(d_img.ptr, pitched(f))
+        d_pts.zero()
+        ctx.extract_batch(d_img.ptr, 1, w, h, p, h * p, prm, d_pts.ptr, d_cnt.ptr)
+        eager = read()
+        assert len(eager) > 500
+        for _ in range(2):
+            d_pts.zero()
+            graph.launch()
+            again = read()
+            assert len(again) == len(eager)
+            for fld in ("coords2D", "scale", "orientation", "sharpness", "edgeness", "subsampling", "data"):
+                assert np.array_equal(again[fld], eager[fld]), fld
+    graph.close()
+    # a recording is tied to the arena it was made with: growing the arena invalidates it, loudly
+    with capi.Context(0) as fresh:
+        d_img2 = DeviceBuffer.from_numpy(fresh, src)
+        d_pts2 = DeviceBuffer(fresh, prm.max_pts * 588)
+        d_cnt2 = DeviceBuffer(fresh, 4)
+        g2 = fresh.record_graph(d_img2.ptr, 1, w, h, p, h * p, prm, d_pts2.ptr, d_cnt2.ptr)
+        g2.launch()
+        fresh.synchronize()
+        fresh.reserve(4, 2048, 2048, prm)
+        with pytest.raises(capi.CusiftError):
+            g2.launch()
+        g2.close()
+        for b in (d_img2, d_pts2, d_cnt2):
+            b.free()
+    # the null stream cannot be captured: refused, not crashed
+    with capi.Context(0, stream=0) as null_ctx:
+        with pytest.raises(capi.CusiftError):
+            null_ctx.record_graph(d_img.ptr, 1, w, h, p, h * p, prm, d_pts.ptr, d_cnt.ptr)
+
+
 def test_extract_batch_equals_single(ctx, oracle, gray1):
     """Batch form: n images in one launch sequence == n single extractions (set-wise)."""
     imgs = [gray1, np.roll(gray1, (13, 57), axis=(0, 1)), gray1[::-1, ::-1].copy()]

@@ -99,14 +99,14 @@ int main() {
     timeit(nm, wr, [&] { hipLaunchKernelGGL(write_only, dim3(grid), dim3(256), 0, 0, (f4*)out, n4, n4); });
   }
   timeit("D read-only (7 planes = 3.7 GB)", wr, [&] { hipLaunchKernelGGL(read_only, dim3(4096), dim3(256), 0, 0, (const f4*)out, in, n4 * 7); });
-  for (int rows : {32}) {
+  for (int rows : {32, 68}) {
     for (int valid : {224, 256}) {
-      for (int nt : {0, 1}) for (int swz : {0, 1}) {
-        char nm[96];
-        snprintf(nm, 96, "C strips valid=%d rows/wave=%d nontemporal=%d xcd_swizzle=%d", valid, rows, nt, swz);
+      for (int nt : {0, 1}) for (int swz : {0, 1}) for (int horiz : {0, 1}) {
+        char nm[128];
+        snprintf(nm, 128, "C strips valid=%d rows/wave=%d nontemporal=%d xcd_swizzle=%d horiz=%d", valid, rows, nt, swz, horiz);
         const int strips = (w + valid - 1) / valid, chunks = (h + rows - 1) / rows;
-        dim3 grid = dim3(strips, (chunks + 3) / 4, n);
-        timeit(nm, rw, [&] { hipLaunchKernelGGL(strip_pattern, grid, dim3(256), 0, 0, in, out, w, h, pitch, rows, valid, 1, swz, 0, nt); });
+        dim3 grid = horiz ? dim3((strips + 3) / 4, chunks, n) : dim3(strips, (chunks + 3) / 4, n);
+        timeit(nm, rw, [&] { hipLaunchKernelGGL(strip_pattern, grid, dim3(256), 0, 0, in, out, w, h, pitch, rows, valid, 1, swz, horiz, nt); });
       }
     }
   }
