@@ -107,6 +107,7 @@ SIGNATURES = {
     "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i]),
     "cusift_match": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    "cusift_find_homography": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, C.POINTER(_i), _vp, _vp]),
     "cusift_pack_points": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_graph_create": (_i, [_vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
@@ -327,6 +328,21 @@ class Context:
     def match(self, d_sift1, n1, d_sift2, n2, distance=1):
         """MatchSiftData on device records: distance 1 = L2 (2 - 2 x.y), 0 = dot product."""
         check(lib().cusift_match(self.handle, d_sift1, n1, d_sift2, n2, distance))
+
+    def find_homography(self, d_sift, num_pts, rand_pts, thresh=5.0, want_all=False):
+        """cusift_find_homography: rand_pts is an int32 array [4, num_loops] of sample indices into d_sift.
+        Returns (H[9], num_matches) or, with want_all, (H, num_matches, all_homographies[8, L], all_counts[L])."""
+        rand_pts = np.ascontiguousarray(rand_pts, dtype=np.int32)
+        assert rand_pts.ndim == 2 and rand_pts.shape[0] == 4, rand_pts.shape
+        loops = rand_pts.shape[1]
+        hom = np.zeros(9, dtype=np.float32)
+        n = C.c_int(0)
+        all_h = np.zeros((8, loops), dtype=np.float32) if want_all else None
+        all_c = np.zeros(loops, dtype=np.int32) if want_all else None
+        check(lib().cusift_find_homography(self.handle, d_sift, num_pts, rand_pts.ctypes.data, loops, thresh,
+                                           hom.ctypes.data, C.byref(n), all_h.ctypes.data if want_all else None,
+                                           all_c.ctypes.data if want_all else None))
+        return (hom, n.value, all_h, all_c) if want_all else (hom, n.value)
 
     # ---- drivers ----
     def extract_batch(self, d_imgs, n_images, w, h, pitch, image_stride, params, d_points, d_counters):

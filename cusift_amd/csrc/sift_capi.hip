@@ -37,6 +37,9 @@ __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsi
 __global__ void rootsift_kernel(cusift_point *, int);
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, int, MatchPartial *, int);
 __global__ void match_merge_kernel(cusift_point *, int, const cusift_point *, int, int, const MatchPartial *, int, int);
+__global__ void homography_gather_kernel(const cusift_point *, int, float *);
+__global__ void homography_solve_kernel(const float *, int, const int *, int, float *);
+__global__ void homography_test_kernel(const float *, int, const float *, int, float, int *);
 __global__ void u8_to_f32_kernel(float *, int, long, const unsigned char *, int, int, int, long, int);
 __global__ void gaussian3x3_kernel(float *, int, long, const float *, int, int, int, long, float, float);
 __global__ void pack_points_kernel(const cusift_point *, const unsigned int *, int, int, cusift_point *, unsigned int,
@@ -99,6 +102,9 @@ struct cusift_ctx {
   // per-split partial results of the matcher (cusift_match)
   MatchPartial *match_scratch = nullptr;
   size_t match_scratch_bytes = 0;
+  // coordinates / samples / hypotheses / counts of cusift_find_homography
+  char *homo_scratch = nullptr;
+  size_t homo_scratch_bytes = 0;
   // staging buffer for 8-bit uploads (cusift_image_u8_h2d)
   unsigned char *u8_stage = nullptr;
   size_t u8_stage_bytes = 0;
@@ -412,6 +418,7 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->dog) (void)hipFree(ctx->dog);
   if (ctx->u8_stage) (void)hipFree(ctx->u8_stage);
+  if (ctx->homo_scratch) (void)hipFree(ctx->homo_scratch);
   if (ctx->match_scratch) (void)hipFree(ctx->match_scratch);
   if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -908,6 +915,68 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
     hipLaunchKernelGGL(match_merge_kernel, dim3(idiv_up(num_pts1, 256)), dim3(256), 0, ctx->stream, d_sift1, num_pts1,
                        d_sift2, num_pts2, distance, partials, n1_pad, splits);
   return check_launch("match");
+}
+
+// ------------------------------------------------------------------------------------------------
+// RANSAC homography
+// ------------------------------------------------------------------------------------------------
+extern "C" int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sift, int num_pts, const int *h_rand_pts,
+                                      int num_loops, float thresh, float h_homography[9], int *num_matches,
+                                      float *h_all_homo, int *h_all_counts) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  if (!h_homography || !num_matches) return fail(CUSIFT_ERR_INVALID, "FindHomography: NULL output");
+  static const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // extras/homography.cu:184-187
+  memcpy(h_homography, ident, sizeof(ident));
+  *num_matches = 0;
+  if (!d_sift || !h_rand_pts) return fail(CUSIFT_ERR_INVALID, "FindHomography: missing data");
+  if (num_pts < 1 || num_loops < 1) return fail(CUSIFT_ERR_INVALID, "FindHomography: num_pts and num_loops must be >= 1");
+  for (long i = 0; i < 4L * num_loops; ++i)
+    if (h_rand_pts[i] < 0 || h_rand_pts[i] >= num_pts)
+      return fail(CUSIFT_ERR_INVALID, "FindHomography: sample index %d out of range [0, %d)", h_rand_pts[i], num_pts);
+  const size_t coord_b = align_up_sz(sizeof(float) * 4 * (size_t)num_pts, 256);
+  const size_t rand_b = align_up_sz(sizeof(int) * 4 * (size_t)num_loops, 256);
+  const size_t homo_b = align_up_sz(sizeof(float) * 8 * (size_t)num_loops, 256);
+  const size_t cnt_b = align_up_sz(sizeof(int) * (size_t)num_loops, 256);
+  const size_t bytes = coord_b + rand_b + homo_b + cnt_b;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (bytes > ctx->homo_scratch_bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->homo_scratch) HIP_TRY(hipFree(ctx->homo_scratch));
+    ctx->homo_scratch = nullptr;
+    ctx->homo_scratch_bytes = 0;
+    hipError_t e = hipMalloc((void **)&ctx->homo_scratch, bytes);
+    if (e != hipSuccess) return fail(CUSIFT_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ctx->homo_scratch_bytes = bytes;
+  }
+  float *d_coord = (float *)ctx->homo_scratch;
+  int *d_rand = (int *)(ctx->homo_scratch + coord_b);
+  float *d_homo = (float *)(ctx->homo_scratch + coord_b + rand_b);
+  int *d_counts = (int *)(ctx->homo_scratch + coord_b + rand_b + homo_b);
+  HIP_TRY(hipMemcpyAsync(d_rand, h_rand_pts, sizeof(int) * 4 * (size_t)num_loops, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(homography_gather_kernel, dim3(idiv_up(num_pts, 256)), dim3(256), 0, ctx->stream, d_sift, num_pts,
+                     d_coord);
+  hipLaunchKernelGGL(homography_solve_kernel, dim3(idiv_up(num_loops, 64)), dim3(64), 0, ctx->stream, d_coord, num_pts,
+                     d_rand, num_loops, d_homo);
+  hipLaunchKernelGGL(homography_test_kernel, dim3(num_loops), dim3(64), 0, ctx->stream, d_coord, num_pts, d_homo,
+                     num_loops, thresh * thresh, d_counts);
+  TRY(check_launch("find_homography"));
+  std::vector<int> counts((size_t)num_loops);
+  std::vector<float> homo(8 * (size_t)num_loops);
+  HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * (size_t)num_loops, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(homo.data(), d_homo, sizeof(float) * 8 * (size_t)num_loops, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  int best = -1, best_count = -1;  // extras/homography.cu:249-254: first maximum
+  for (int i = 0; i < num_loops; ++i)
+    if (counts[i] > best_count) {
+      best_count = counts[i];
+      best = i;
+    }
+  *num_matches = best_count;
+  for (int j = 0; j < 8; ++j) h_homography[j] = homo[(size_t)j * num_loops + best];
+  if (h_all_homo) memcpy(h_all_homo, homo.data(), sizeof(float) * homo.size());
+  if (h_all_counts) memcpy(h_all_counts, counts.data(), sizeof(int) * counts.size());
+  return CUSIFT_OK;
 }
 
 extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src,

@@ -217,6 +217,19 @@ int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1, const cus
 int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch,
                         size_t width_bytes, size_t rows);
 
+/* ---- RANSAC homography from matched SiftData ------------------------------ */
+/* The device part and the final selection of FindHomography(data, homography, numMatches, numLoops, minScore,
+ * maxAmbiguity, thresh), extras/homography.cu:182-269: for num_loops hypotheses -- h_rand_pts[i*num_loops + l] is
+ * the i-th (of 4) sample of hypothesis l, an index into d_sift; the reference draws them on the host with rand()
+ * from the points that pass minScore/maxAmbiguity (:208-235), and so does include/homography.h -- solve the 8x8
+ * system (ComputeHomographies :89-130), count the points with reprojection error < thresh (TestHomographies
+ * :135-178, over coords2D -> match_xpos/ypos of ALL num_pts records) and return the first hypothesis with the
+ * most inliers: h_homography[0..7], h_homography[8] = 1, *num_matches = its count.  h_all_homo ([8][num_loops])
+ * and h_all_counts ([num_loops]) may be NULL.  Blocking. */
+int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sift, int num_pts, const int *h_rand_pts,
+                           int num_loops, float thresh, float h_homography[9], int *num_matches, float *h_all_homo,
+                           int *h_all_counts);
+
 /* Packs a batch's SiftData for an exchange (all-gatherv over RCCL): the valid records of all images back to back in
  * image order into d_packed (room for `capacity` records; anything beyond is dropped) and the exclusive prefix sums
  * of the valid counts into d_offsets[0 .. n_images] (may be NULL).  n_images <= 256.  Asynchronous. */

@@ -678,3 +678,174 @@ void oracle_gaussian3x3(const float *src, int w, int h, int src_pitch, float *ds
   }
   free(rows);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * RANSAC homography: FindHomography, extras/homography.cu:182-269, with its
+ * kernels ComputeHomographies (:89-130, one 8x8 solve per hypothesis through InvertMatrix<8>, :3-87) and
+ * TestHomographies (:135-178, inlier count of every hypothesis).  PARITY UNPINNED: the reference holds no test
+ * or fixture for it (only main.cpp calls it), so this restatement is the only oracle.
+ *
+ * Arithmetic: where nvcc's default -fmad=true contracts `sum -= a*b` / `sum += a*b` the fused form is written
+ * out (fmaf); the 1.0/x of the pivot scaling is a double division rounded to float, as the literal 1.0 makes it;
+ * the inlier test multiplies with round-toward-zero (__fmul_rz, which also keeps nvcc from fusing).
+ * Not reproduced: TestHomographies walks numPtsUp = iDivUp(numPts,16)*16 entries of d_coord, i.e. up to 15
+ * uninitialised floats per coordinate row beyond numPts (:152,218-221); only the numPts real points are tested.
+ * ------------------------------------------------------------------------------------------------ */
+static float mul_rz(float a, float b) {
+  const double p = (double)a * (double)b; /* exact: 24 + 24 bits */
+  float f = (float)p;                     /* to nearest ... */
+  if (fabs((double)f) > fabs(p)) f = nextafterf(f, 0.0f); /* ... then back towards zero */
+  return f;
+}
+
+/* InvertMatrix<8>, extras/homography.cu:3-87: LU with implicit row scaling, then column-by-column
+ * forward/back substitution of the identity. */
+static void invert8(float m[8][8], float inv[8][8]) {
+  int perm[8];
+  float rhs[8], rowscale[8];
+  int imax = 0;
+  for (int i = 0; i < 8; i++) {
+    perm[i] = 0;
+    float big = 0.0f;
+    for (int j = 0; j < 8; j++) {
+      const float t = fabsf(m[i][j]);
+      if (t > big) big = t;
+    }
+    rowscale[i] = big > 0.0f ? (float)(1.0 / (double)big) : 1e16f; /* :22-25 */
+  }
+  for (int j = 0; j < 8; j++) {
+    for (int i = 0; i < j; i++) {
+      float sum = m[i][j];
+      for (int k = 0; k < i; k++) sum = fmaf(-m[i][k], m[k][j], sum);
+      m[i][j] = sum;
+    }
+    float big = 0.0f;
+    for (int i = j; i < 8; i++) {
+      float sum = m[i][j];
+      for (int k = 0; k < j; k++) sum = fmaf(-m[i][k], m[k][j], sum);
+      m[i][j] = sum;
+      const float dum = rowscale[i] * fabsf(sum);
+      if (dum >= big) { /* :42-45: ties go to the later row */
+        big = dum;
+        imax = i;
+      }
+    }
+    if (j != imax) {
+      for (int k = 0; k < 8; k++) {
+        const float t = m[imax][k];
+        m[imax][k] = m[j][k];
+        m[j][k] = t;
+      }
+      rowscale[imax] = rowscale[j];
+    }
+    perm[j] = imax;
+    if (m[j][j] == 0.0f) m[j][j] = 1e-16f; /* :57-58 */
+    if (j != 7) {
+      const float dum = (float)(1.0 / (double)m[j][j]);
+      for (int i = j + 1; i < 8; i++) m[i][j] *= dum;
+    }
+  }
+  for (int c = 0; c < 8; c++) {
+    for (int k = 0; k < 8; k++) rhs[k] = 0.0f;
+    rhs[c] = 1.0f;
+    int first = -1;
+    for (int i = 0; i < 8; i++) {
+      const int ip = perm[i];
+      float sum = rhs[ip];
+      rhs[ip] = rhs[i];
+      if (first != -1)
+        for (int k = first; k < i; k++) sum = fmaf(-m[i][k], rhs[k], sum);
+      else if (sum != 0.0f)
+        first = i;
+      rhs[i] = sum;
+    }
+    for (int i = 7; i >= 0; i--) {
+      float sum = rhs[i];
+      for (int k = i + 1; k < 8; k++) sum = fmaf(-m[i][k], rhs[k], sum);
+      rhs[i] = sum / m[i][i];
+    }
+    for (int i = 0; i < 8; i++) inv[i][c] = rhs[i];
+  }
+}
+
+/* ComputeHomographies, extras/homography.cu:89-130.  coord = [4][num_pts] (x1, y1, x2, y2 rows),
+ * rand_pts = [4][num_loops] point indices, homo = [8][num_loops]. */
+void oracle_compute_homographies(const float *coord, int num_pts, const int *rand_pts, int num_loops, float *homo) {
+  for (int idx = 0; idx < num_loops; idx++) {
+    float a[8][8], ia[8][8], b[8];
+    for (int i = 0; i < 4; i++) {
+      const int pt = rand_pts[i * num_loops + idx];
+      const float x1 = coord[pt], y1 = coord[pt + num_pts];
+      const float x2 = coord[pt + 2 * num_pts], y2 = coord[pt + 3 * num_pts];
+      float *r1 = a[2 * i], *r2 = a[2 * i + 1];
+      r1[0] = x1, r1[1] = y1, r1[2] = 1.0f, r1[3] = r1[4] = r1[5] = 0.0f, r1[6] = -x2 * x1, r1[7] = -x2 * y1;
+      r2[0] = r2[1] = r2[2] = 0.0f, r2[3] = x1, r2[4] = y1, r2[5] = 1.0f, r2[6] = -y2 * x1, r2[7] = -y2 * y1;
+      b[2 * i] = x2;
+      b[2 * i + 1] = y2;
+    }
+    invert8(a, ia);
+    for (int j = 0; j < 8; j++) {
+      float sum = 0.0f;
+      for (int i = 0; i < 8; i++) sum = fmaf(ia[j][i], b[i], sum);
+      homo[j * num_loops + idx] = sum;
+    }
+  }
+}
+
+/* TestHomographies, extras/homography.cu:135-178: inliers of every hypothesis over the num_pts points. */
+void oracle_test_homographies(const float *coord, int num_pts, const float *homo, int num_loops, float thresh2,
+                              int *counts) {
+  for (int idx = 0; idx < num_loops; idx++) {
+    float a[8];
+    for (int i = 0; i < 8; i++) a[i] = homo[i * num_loops + idx];
+    int cnt = 0;
+    for (int i = 0; i < num_pts; i++) {
+      const float x1 = coord[i], y1 = coord[i + num_pts], x2 = coord[i + 2 * num_pts], y2 = coord[i + 3 * num_pts];
+      const float nomx = mul_rz(a[0], x1) + mul_rz(a[1], y1) + a[2];
+      const float nomy = mul_rz(a[3], x1) + mul_rz(a[4], y1) + a[5];
+      const float deno = mul_rz(a[6], x1) + mul_rz(a[7], y1) + 1.0f;
+      const float errx = mul_rz(x2, deno) - nomx;
+      const float erry = mul_rz(y2, deno) - nomy;
+      const float err2 = mul_rz(errx, errx) + mul_rz(erry, erry);
+      if (err2 < mul_rz(thresh2, mul_rz(deno, deno))) cnt++;
+    }
+    counts[idx] = cnt;
+  }
+}
+
+/* The device part + the final selection of FindHomography (extras/homography.cu:237-258) for given samples:
+ * rand_pts = [4][num_loops] indices into `pts` (the host draws them with rand(), :222-235 -- the caller's job).
+ * homography[9] (h[8] = 1, :184-186); returns the index of the winning hypothesis (first maximum, :249-254).
+ * all_homo ([8][num_loops]) and all_counts ([num_loops]) may be NULL. */
+int oracle_find_homography(const oracle_sift_point *pts, int num_pts, const int *rand_pts, int num_loops, float thresh,
+                           float homography[9], int *num_matches, float *all_homo, int *all_counts) {
+  static const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  memcpy(homography, ident, sizeof(ident));
+  *num_matches = 0;
+  if (num_pts < 1 || num_loops < 1) return -1;
+  float *coord = (float *)malloc(sizeof(float) * 4 * (size_t)num_pts);
+  float *homo = (float *)malloc(sizeof(float) * 8 * (size_t)num_loops);
+  int *counts = (int *)malloc(sizeof(int) * (size_t)num_loops);
+  for (int i = 0; i < num_pts; i++) { /* :237-240 */
+    coord[i] = pts[i].coords2D[0];
+    coord[i + num_pts] = pts[i].coords2D[1];
+    coord[i + 2 * num_pts] = pts[i].match_xpos;
+    coord[i + 3 * num_pts] = pts[i].match_ypos;
+  }
+  oracle_compute_homographies(coord, num_pts, rand_pts, num_loops, homo);
+  oracle_test_homographies(coord, num_pts, homo, num_loops, thresh * thresh, counts);
+  int best = -1, best_count = -1;
+  for (int i = 0; i < num_loops; i++)
+    if (counts[i] > best_count) {
+      best_count = counts[i];
+      best = i;
+    }
+  *num_matches = best_count;
+  for (int j = 0; j < 8; j++) homography[j] = homo[j * num_loops + best];
+  if (all_homo) memcpy(all_homo, homo, sizeof(float) * 8 * (size_t)num_loops);
+  if (all_counts) memcpy(all_counts, counts, sizeof(int) * (size_t)num_loops);
+  free(coord);
+  free(homo);
+  free(counts);
+  return best;
+}

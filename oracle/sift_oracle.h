@@ -92,6 +92,16 @@ void oracle_match_sift_data(oracle_sift_point *sift1, int n1, const oracle_sift_
 int oracle_match_filter(const oracle_sift_point *sift1, int n1, float score_threshold, float ambiguity_threshold,
                         int *idx);
 
+/* RANSAC homography (PARITY UNPINNED -- the reference has no test or fixture for it):
+ * ComputeHomographies (extras/homography.cu:89-130, InvertMatrix<8> :3-87), TestHomographies (:135-178) and the
+ * selection at the end of FindHomography (:237-258).  Layouts: coord [4][num_pts], rand_pts [4][num_loops],
+ * homo [8][num_loops].  The random draws (host rand(), :222-235) are the caller's. */
+void oracle_compute_homographies(const float *coord, int num_pts, const int *rand_pts, int num_loops, float *homo);
+void oracle_test_homographies(const float *coord, int num_pts, const float *homo, int num_loops, float thresh2,
+                              int *counts);
+int oracle_find_homography(const oracle_sift_point *pts, int num_pts, const int *rand_pts, int num_loops, float thresh,
+                           float homography[9], int *num_matches, float *all_homo, int *all_counts);
+
 /* Caller-side front-end (main.cpp:300-318, test/detector.cpp:19-27): convertTo(CV_32FC1) and
  * cv::GaussianBlur(Size(3,3), sigma).  The blur is PARITY UNPINNED (OpenCV is absent here; see the .c file). */
 void oracle_u8_to_f32(const unsigned char *src, int w, int h, int src_pitch, float *dst, int dst_pitch);

@@ -98,6 +98,9 @@ class Oracle:
         lib.oracle_gaussian3x3.restype = None
         lib.oracle_tex2d.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
         lib.oracle_tex2d.restype = C.c_float
+        lib.oracle_find_homography.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_float, _vp, C.POINTER(C.c_int), _vp,
+                                               _vp]
+        lib.oracle_find_homography.restype = C.c_int
 
     # ---- stage functions on pitched numpy images (2-D float32 arrays, pitch = arr.shape[1]) ----
     def scale_down(self, src, w, h):
@@ -174,6 +177,19 @@ class Oracle:
         out = np.zeros((h, w), dtype=np.float32)
         self.lib.oracle_gaussian3x3(img.ctypes.data, w, h, w, out.ctypes.data, w, sigma)
         return out
+
+    def find_homography(self, points, rand_pts, thresh=5.0):
+        """Device part + selection of FindHomography for the given samples (int32 [4, num_loops]).
+        Returns (H[9], num_matches, best index, all homographies [8, L], all counts [L])."""
+        rand_pts = np.ascontiguousarray(rand_pts, dtype=np.int32)
+        loops = rand_pts.shape[1]
+        hom = np.zeros(9, dtype=np.float32)
+        n = C.c_int(0)
+        all_h = np.zeros((8, loops), dtype=np.float32)
+        all_c = np.zeros(loops, dtype=np.int32)
+        best = self.lib.oracle_find_homography(points.ctypes.data, len(points), rand_pts.ctypes.data, loops, thresh,
+                                               hom.ctypes.data, C.byref(n), all_h.ctypes.data, all_c.ctypes.data)
+        return hom, n.value, best, all_h, all_c
 
     def tex2d(self, img, w, h, x, y, frac_bits=8):
         img = _f32(img)

@@ -9,16 +9,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(CPP, "detector_dropin")
 BIN_MATCH = os.path.join(CPP, "matching_dropin")
+BIN_HOMO = os.path.join(CPP, "homography_dropin")
 
 
 def build():
     subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
-    assert os.path.exists(BIN) and os.path.exists(BIN_MATCH)
+    assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH):
+    for b in (BIN, BIN_MATCH, BIN_HOMO):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -65,3 +66,13 @@ def test_dropin_matching_program_passes_on_gpu():
     # extras/debug.h surface: AddSiftData doubling (884 -> 2652 points, 1024 -> 4096 slots), dump round trip
     assert "AddSiftData: 884 -> 2652 points, capacity 1024 -> 4096" in out.stdout
     assert "dump round trip: 2652 / 2652 records identical" in out.stdout
+
+
+@pytest.mark.gpu
+def test_dropin_homography_program_passes_on_gpu():
+    """extras/homography.h surface: FindHomography (RANSAC on the GPU) + ImproveHomography on planted matches."""
+    build()
+    out = subprocess.run([BIN_HOMO], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "PASSED" in out.stdout and "FindHomography:" in out.stdout and "ImproveHomography:" in out.stdout
