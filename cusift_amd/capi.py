@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcusift_amd.so")
+LIB_PATH = os.environ.get("CUSIFT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcusift_amd.so")
 
 CUSIFT_OK = 0
 NUM_STAGES = 8

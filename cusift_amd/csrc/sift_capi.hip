@@ -252,6 +252,16 @@ int pick_rows(int h, int strips, int n_images, int lo, int hi) {
   return (int)r;
 }
 
+// [lo, hi] of pick_rows for a stage, overridable for tuning experiments: CUSIFT_<STAGE>_ROWS_LO / _HI
+void rows_bounds(const char *stage, int &lo, int &hi) {
+  char name[64];
+  snprintf(name, sizeof(name), "CUSIFT_%s_ROWS_HI", stage);
+  if (const char *e = getenv(name)) hi = std::max(1, atoi(e));
+  snprintf(name, sizeof(name), "CUSIFT_%s_ROWS_LO", stage);
+  if (const char *e = getenv(name)) lo = std::max(1, atoi(e));
+  lo = std::min(lo, hi);
+}
+
 void scale_down_taps(ScaleDownTaps &T, float variance) {
   // cuSIFT.cu:320-341 (the pyramid passes variance = 0.5, cuSIFT.cu:185)
   float k[5], sum = 0.0f;
@@ -642,7 +652,9 @@ static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t 
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
   if (fast) {
     const int strips = idiv_up(ow, 124);  // kDownStrip
-    const int rows = pick_rows(oh, strips, n_images, 4, 32);
+    int rlo = 4, rhi = 32;
+    rows_bounds("SCALEDOWN", rlo, rhi);
+    const int rows = pick_rows(oh, strips, n_images, rlo, rhi);
     dim3 grid(idiv_up(strips, kWavesPerBlock), idiv_up(oh, rows), n_images);
     hipLaunchKernelGGL(scale_down_fast_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride,
                        d_src, w, h, src_pitch, (long)src_stride, rows, T, src_rw, dst_row0, r_begin, r_end);
@@ -694,7 +706,11 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
   const int vec_ok = (pitch % 4 == 0) && (((uintptr_t)d_img % 16) == 0) && (((uintptr_t)d_dog % 16) == 0) &&
                      (img_stride % 4 == 0) && (dog_stride % 4 == 0) && (((size_t)h * pitch) % 4 == 0);
   const int strips = idiv_up(w, kBlurStrip);
-  const int rows = pick_rows(h, strips, n_images, 8, 32);
+  // short chunks: the halo rows they re-read come from L2, and the chip sustains a visibly higher store rate when
+  // many short waves write than when few long ones do (tools/probe_rows.py, 64x1080p: r = 6 0.737 ms, r = 32 0.820 ms)
+  int rlo = 3, rhi = 6;
+  rows_bounds("LAPLACE", rlo, rhi);
+  const int rows = pick_rows(h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
   // fast path: aligned float4 rows, whole lanes inside/outside the image, 32-bit buffer offsets
   const bool fast = vec_ok && (w % 4 == 0) && w >= 4 && ((size_t)h * pitch * sizeof(float) < (1ull << 31)) &&
@@ -729,7 +745,9 @@ extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int
   const int vec_ok = (pitch % 2 == 0) && (((uintptr_t)d_dog % 8) == 0) && (dog_stride % 2 == 0) &&
                      (((size_t)h * pitch) % 2 == 0);
   const int strips = idiv_up(w, kFindStrip);
-  const int rows = pick_rows(h, strips, n_images, 8, 32);
+  int rlo = 4, rhi = 16;  // tools/probe_rows.py, 64x1080p: r = 16 0.770 ms, r = 32 0.803 ms
+  rows_bounds("FINDPOINTS", rlo, rhi);
+  const int rows = pick_rows(h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
   const bool fast = vec_ok && (w % 2 == 0) && w >= 2 &&
                     ((size_t)kNumDog * h * pitch * sizeof(float) < (1ull << 31)) && !getenv("CUSIFT_FORCE_GENERIC");
@@ -771,7 +789,15 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   find_params(P, peak_thresh, edge_thresh, subsampling);
   const int rows_total = cy_end - cy_begin;
   const int strips = idiv_up(w, 240);  // kDetStrip
-  const int rows = pick_rows(rows_total, strips, n_images, 8, 32);
+  // Chunk height.  A chunk of r centre rows costs r + 2 blurred rows (+ an 8-row window fill), so tall chunks waste
+  // the least arithmetic -- but the launch ends with a tail in which the last chunks run on a part-empty chip, and
+  // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work): measured optima on MI355X
+  // (tools/probe_rows.py, 64 images): 1920x1080 r = 16 (0.685 ms; r = 32: 0.731), 960x540 r = 8 (0.199 vs 0.248),
+  // 480x270 r = 6-8, 240x135 r = 2-4, 120x67 r = 3 -- all within 3 % of 0.022 * sqrt(rows * strips * images).
+  int rows_lo = 2, rows_hi = 24;
+  rows_bounds("DETECT", rows_lo, rows_hi);
+  const double wave_rows = (double)rows_total * strips * n_images;
+  const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(0.022 * sqrt(wave_rows))));
   dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), kWavesPerBlock), n_images);
   // levels 0 and 1 both identity (initBlur >= their sigma)?  then the kernel passes them through
   bool ident0 = true;
