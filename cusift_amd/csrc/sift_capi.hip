@@ -486,7 +486,8 @@ extern "C" int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, i
   const std::string k(kernel);
   int n = 0, t = 256;
   hipError_t e = hipErrorInvalidValue;
-  if (k == "detect_fused") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false>, t, 0);
+  if (k == "detect_fused")  // single-wave workgroups, 9 KB refinement cube each
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false>, t = 64, 9 * 256 * sizeof(float));
   else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel, t, 0);
   else if (k == "find_points") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, find_points_fast_kernel, t, 0);
   else if (k == "scale_down") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scale_down_fast_kernel, t, 0);
@@ -652,7 +653,9 @@ static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t 
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
   if (fast) {
     const int strips = idiv_up(ow, 124);  // kDownStrip
-    int rlo = 4, rhi = 32;
+    // measured (tools/probe_rows.py, 64 images): 1920x1080 -> 960x540 streams from HBM and likes short chunks
+    // (r = 4: 0.137 ms, r = 32: 0.150 ms); the smaller levels are served by the Infinity Cache and like tall ones
+    int rlo = 4, rhi = (long)oh * strips * n_images > 200000 ? 4 : 32;
     rows_bounds("SCALEDOWN", rlo, rhi);
     const int rows = pick_rows(oh, strips, n_images, rlo, rhi);
     dim3 grid(idiv_up(strips, kWavesPerBlock), idiv_up(oh, rows), n_images);
@@ -723,7 +726,10 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
         TP.k[q][j].x = taps[16 * (2 * q) + j];
         TP.k[q][j].y = taps[16 * (2 * q + 1) + j];
       }
-    hipLaunchKernelGGL(laplace_multi_fast_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
+    int wpb = kWavesPerBlock;
+    if (const char *e = getenv("CUSIFT_LAPLACE_WAVES")) wpb = std::max(1, std::min(4, atoi(e)));  // experiments only
+    dim3 fgrid(strips, idiv_up(idiv_up(h, rows), wpb), n_images);
+    hipLaunchKernelGGL(laplace_multi_fast_kernel, fgrid, dim3(64 * wpb), 0, ctx->stream, d_img, d_dog, w, h, pitch,
                        (long)img_stride, (long)dog_stride, rows, TP);
   } else {
     hipLaunchKernelGGL(laplace_multi_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
@@ -793,22 +799,29 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   // the least arithmetic -- but the launch ends with a tail in which the last chunks run on a part-empty chip, and
   // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work): measured optima on MI355X
   // (tools/probe_rows.py, 64 images): 1920x1080 r = 16 (0.685 ms; r = 32: 0.731), 960x540 r = 8 (0.199 vs 0.248),
-  // 480x270 r = 6-8, 240x135 r = 2-4, 120x67 r = 3 -- all within 3 % of 0.022 * sqrt(rows * strips * images).
+  // 480x270 r = 6-8, 240x135 r = 2-4, 120x67 r = 2-3 -- all within 4 % of 0.022 * sqrt(rows * strips * images)
+  // (the same optima with one and with four waves per workgroup).
   int rows_lo = 2, rows_hi = 24;
   rows_bounds("DETECT", rows_lo, rows_hi);
   const double wave_rows = (double)rows_total * strips * n_images;
   const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(0.022 * sqrt(wave_rows))));
-  dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), kWavesPerBlock), n_images);
+  // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
+  // threshold pre-test makes the waves' run times uneven -- measured 64x1080p, r = 16: 4 waves per workgroup 0.693 ms,
+  // 2: 0.645 ms, 1: 0.630 ms (tools/probe_rows.py with CUSIFT_DETECT_WAVES).
+  int wpb = 1;
+  if (const char *e = getenv("CUSIFT_DETECT_WAVES")) wpb = std::max(1, std::min(4, atoi(e)));  // experiments only
+  dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), wpb), n_images);
+  const size_t cube_bytes = (size_t)wpb * 9 * 256 * sizeof(float);  // kCubeCols = 256
   // levels 0 and 1 both identity (initBlur >= their sigma)?  then the kernel passes them through
   bool ident0 = true;
   for (int lv = 0; lv < 2; ++lv)
     for (int j = 0; j < 9; ++j) ident0 = ident0 && (taps[16 * lv + j] == (j == kBlurRadius ? 1.0f : 0.0f));
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
   if (ident0 && !getenv("CUSIFT_NO_IDENT"))
-    hipLaunchKernelGGL(detect_fused_kernel<true>, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch,
+    hipLaunchKernelGGL(detect_fused_kernel<true>, grid, dim3(64 * wpb), cube_bytes, ctx->stream, d_img, w, h, pitch,
                        (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   else
-    hipLaunchKernelGGL(detect_fused_kernel<false>, grid, dim3(256), 0, ctx->stream, d_img, w, h, pitch,
+    hipLaunchKernelGGL(detect_fused_kernel<false>, grid, dim3(64 * wpb), cube_bytes, ctx->stream, d_img, w, h, pitch,
                        (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   return check_launch("detect_multi");
 }

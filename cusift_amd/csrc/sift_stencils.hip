@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   xcd_remap(bx, by, bz);
-  const int y0 = (by * kWavesPerBlock + wv) * rows_per_wave;
+  const int y0 = (by * (int)(blockDim.x >> 6) + wv) * rows_per_wave;  // 1..4 waves per workgroup, stacked vertically
   if (y0 >= h) return;  // wave-uniform
   const int y1 = min(y0 + rows_per_wave, h);
   img += (long)bz * img_stride;
@@ -759,21 +759,21 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
                                                           int max_pts, unsigned int *__restrict__ counters,
                                                           int rows_per_wave, LaplaceTapsPk T, FindParams P,
                                                           RowWindow rw, int cy_begin, int cy_end) {
-  __shared__ float s_cube[kWavesPerBlock][9 * kCubeCols];
+  extern __shared__ float s_cube[];  // [waves per workgroup][9 * kCubeCols]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   xcd_remap(bx, by, bz);
   // extremum centres are GLOBAL rows [cy_begin, cy_end) minus the global border rows; this wave takes a chunk
   // of them and works in band-local row indices (global - rw.row0).  Whole image: rw = {0, h}, [0, h).
-  const int gy0 = cy_begin + (by * kWavesPerBlock + wv) * rows_per_wave;
+  const int gy0 = cy_begin + (by * (int)(blockDim.x >> 6) + wv) * rows_per_wave;
   const int ya = max(max(gy0, 1), cy_begin) - rw.row0;
   const int yb = min(min(gy0 + rows_per_wave, rw.hg - 1), cy_end) - rw.row0;  // local centres [ya, yb)
   if (ya >= yb) return;                                                         // wave-uniform
   img += (long)bz * img_stride;
   points += (long)bz * max_pts;
   unsigned int *counter = counters + bz;
-  float *cube = s_cube[wv];
+  float *cube = s_cube + wv * (9 * kCubeCols);
 
   const int c0 = bx * kDetStrip - kDetHaloLanes * kBlurCols + lane * kBlurCols;
   const bool left = c0 < 0, right = c0 >= w;
