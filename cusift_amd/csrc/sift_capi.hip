@@ -33,7 +33,8 @@ __global__ void orientations_kernel(const float *, int, int, int, long, cusift_p
                                     const unsigned int *, float, float, RowWindow);
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                    const unsigned int *, float, float, float, RowWindow, int);
-__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int);
+__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int,
+                                    unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, int, MatchPartial *, int);
 __global__ void match_merge_kernel(cusift_point *, int, const cusift_point *, int, int, const MatchPartial *, int, int);
@@ -110,6 +111,7 @@ struct cusift_ctx {
   size_t u8_stage_bytes = 0;
   // small persistent device scratch for the blocking single-image entry points
   unsigned int *d_counter1 = nullptr;
+  unsigned int *d_queue = nullptr;  // kQueueShards work cursors of describe_all_kernel, 128 bytes apart
   int describe_grid = 0;  // resident blocks of describe_all_kernel on this device (occupancy query, cached)
   // timing
   bool timing = false;
@@ -399,7 +401,9 @@ static int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool 
     ctx->owns_stream = true;
   }
   hipError_t e = hipMalloc((void **)&ctx->d_counter1, 256);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, kQueueShards * 128);
   if (e != hipSuccess) {
+    if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return fail(CUSIFT_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -431,6 +435,7 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
   if (ctx->homo_scratch) (void)hipFree(ctx->homo_scratch);
   if (ctx->match_scratch) (void)hipFree(ctx->match_scratch);
   if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
+  if (ctx->d_queue) (void)hipFree(ctx->d_queue);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return CUSIFT_OK;
@@ -1132,10 +1137,14 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
       ctx->describe_grid = std::max(1, per_cu) * std::max(1, cus);
     }
     const long cap = (long)n_images * prm->max_pts;
-    dim3 grid((unsigned int)std::max(1L, std::min(cap, (long)ctx->describe_grid)));
+    // a multiple of the shard count (the kernel deals items to shards by workgroup index)
+    const long want = std::max(1L, std::min(cap, (long)ctx->describe_grid));
+    dim3 grid((unsigned int)std::max<long>(kQueueShards, want / kQueueShards * kQueueShards));
+    unsigned int *queue = ctx->d_queue;  // the kernel's work cursors
+    HIP_TRY(hipMemsetAsync(queue, 0, kQueueShards * 128, ctx->stream));
     StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
     hipLaunchKernelGGL(describe_all_kernel, grid, dim3(64), 0, ctx->stream, T, d_points, prm->max_pts, d_counters,
-                       n_images, q, inv_q, prm->root_sift);
+                       n_images, q, inv_q, prm->root_sift, queue);
     TRY(check_launch("describe_all"));
   }
   return CUSIFT_OK;
