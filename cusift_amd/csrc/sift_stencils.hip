@@ -815,15 +815,17 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
       // centre at all.  One wave-uniform test skips the whole neighbourhood analysis for them; skipping cannot
       // change the result, because a hit implies |v| > thr.  (Skipping per scale/plane as well was tried: the
       // conditionally live min/max arrays cost 258 VGPRs -> 1 wave per SIMD, slower.)
-      bool big = false;
+      // (one running maximum of |v| -- ten v_max3_f32 with |.| modifiers and one compare instead of twenty compares;
+      // a NaN never raises the maximum, just as it never passed `|v| > thr`)
+      float vmax = 0.0f;
 #pragma unroll
       for (int s = 0; s < kNumScales; ++s) {
         const f4 v = D1[s + 1];
-        big = big || fabsf(v.x) > P.thr_pos || fabsf(v.y) > P.thr_pos || fabsf(v.z) > P.thr_pos ||
-              fabsf(v.w) > P.thr_pos;
+        vmax = max3f(vmax, fabsf(v.x), fabsf(v.y));
+        vmax = max3f(vmax, fabsf(v.z), fabsf(v.w));
       }
       // halo lanes and lanes right of the image hold no centres (and their DoG values are not meaningful)
-      big = big && lane_valid && c0 < w;
+      const bool big = vmax > P.thr_pos && lane_valid && c0 < w;
       unsigned int cand = 0;  // bit (4*s + j)
       if (__builtin_amdgcn_ballot_w64(big) != 0) {  // wave-uniform
         // per plane: 3-row column min/max, then the 3x3 min/max (h*) and the left/right neighbours' columns
