@@ -159,13 +159,12 @@ def main():
                   lowest_scale=0.0, subsampling=1.0, max_pts=args.max_pts, tex_frac_bits=8)
     # One extractor (context + arena + output slots) per stream; step i runs on stream i % E.  A step is still one
     # whole pass of the hot path over one batch -- consecutive steps merely overlap on the device.
+    from cusift_amd.batch import PipelinedExtractor
+
     E = max(1, args.streams)
-    ex_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(E - 1)]
-    exs = []
-    for st in ex_streams:
-        with torch.cuda.stream(st):
-            exs.append(BatchExtractor(B, w, h, n_slots=2 if use_dist else 1, fused_detect=0 if args.two_stage else 1,
-                                      **prm_kw))
+    pipe = PipelinedExtractor(B, w, h, n_streams=E, n_slots=2 if use_dist else 1,
+                              fused_detect=0 if args.two_stage else 1, **prm_kw)
+    exs = pipe.extractors
     ex = exs[0]
 
     # ---- synthetic inputs, resident in HBM before anything is timed ----
@@ -183,7 +182,7 @@ def main():
     side_stream = torch.cuda.Stream() if use_dist else None
     packer = ex.make_packer(side_stream) if use_dist else None
     pending = []
-    state = {"i": 0, "gathered": None}
+    state = {"gathered": None}
 
     def finish_one():
         pts, cnt, ev = pending.pop(0)
@@ -192,14 +191,7 @@ def main():
             state["gathered"] = allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather, packer=packer)
 
     def step():
-        i = state["i"]
-        state["i"] += 1
-        e = i % E
-        with torch.cuda.stream(ex_streams[e]):
-            pts, cnt = exs[e].extract(d_imgs, slot=(i // E) % len(exs[e].slots))
-            if use_dist:
-                ev = torch.cuda.Event()
-                ev.record(ex_streams[e])
+        pts, cnt, ev = pipe.submit(d_imgs)
         if use_dist:
             pending.append((pts, cnt, ev))
             if len(pending) > 1:
@@ -210,7 +202,7 @@ def main():
             finish_one()
         if use_dist:
             main_stream.wait_stream(side_stream)
-        for st in ex_streams[1:]:
+        for st in pipe.streams[1:]:
             main_stream.wait_stream(st)
 
     def fence():

@@ -90,3 +90,62 @@ class BatchExtractor:
 
     def close(self):
         self.ctx.close()
+
+
+class PipelinedExtractor:
+    """Consecutive batches on `n_streams` HIP streams, one BatchExtractor (context, arena, output slots) each.
+
+    A single launch sequence leaves the chip part-idle at times: the ScaleDown chain is HBM-bound while everything
+    else is VALU-bound, and the last waves of every detection / description launch run on a nearly empty device.
+    With two batches in flight those gaps are filled by the other batch's kernels (64 x 1080p on MI355X: 1.96 ms per
+    batch on one stream, 1.72 ms on two; a third adds nothing).  Results are those of BatchExtractor.
+
+        pipe = PipelinedExtractor(64, 1920, 1080, n_streams=2, num_octaves=5, init_blur=1.0, peak_thresh=3.0)
+        for frames in source:                       # frames: float32 device tensor [n, h, pitch]
+            points, counts, done = pipe.submit(frames)
+            ...                                     # consume after `done` (an event) -- e.g. other_stream.wait_event(done)
+    The output tensors of a submit are reused by the submit `n_streams * n_slots` calls later.
+    """
+
+    def __init__(self, n_images, w, h, n_streams=2, n_slots=1, device=None, **kw):
+        if not torch.cuda.is_available():
+            raise capi.CusiftError("PipelinedExtractor needs a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(1, n_streams) - 1)]
+            self.extractors = []
+            for st in self.streams:
+                with torch.cuda.stream(st):
+                    self.extractors.append(BatchExtractor(n_images, w, h, n_slots=n_slots, device=self.device, **kw))
+        self.n_slots = n_slots
+        self.submitted = 0
+        first = self.extractors[0]
+        self.n, self.w, self.h, self.pitch, self.max_pts, self.params = (first.n, first.w, first.h, first.pitch,
+                                                                         first.max_pts, first.params)
+
+    def images_from_numpy(self, imgs):
+        return self.extractors[0].images_from_numpy(imgs)
+
+    def submit(self, d_imgs, ready=None):
+        """Enqueue one batch on the next stream.  `ready`: an event after which d_imgs may be read (None: the caller
+        has made sure already, e.g. by a device synchronisation after the upload).
+        Returns (points, counts, done_event)."""
+        k = self.submitted
+        self.submitted += 1
+        e = k % len(self.streams)
+        st = self.streams[e]
+        with torch.cuda.stream(st):
+            if ready is not None:
+                st.wait_event(ready)
+            pts, cnt = self.extractors[e].extract(d_imgs, slot=(k // len(self.streams)) % self.n_slots)
+            done = torch.cuda.Event()
+            done.record(st)
+        return pts, cnt, done
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def close(self):
+        for x in self.extractors:
+            x.close()

@@ -121,6 +121,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _prefer_torch_hip_runtime():
+    """A process can hold ONE libamdhip64.so.7.  libcusift_amd.so asks for it by soname and would pull in the system
+    ROCm's; a PyTorch-ROCm wheel ships its own copy (plus matching HSA / comgr libraries) and stops seeing the GPU if
+    it is imported after a different one was loaded (torch.cuda.is_available() == False).  So when torch is installed
+    but not imported yet, its copy is loaded first -- the combination every torch-first program (bench.py,
+    cusift_amd.batch) runs with anyway.  Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def lib():
     """The loaded libcusift_amd.so with typed entry points. Raises if the extension is not built."""
     global _lib
@@ -130,6 +155,7 @@ def lib():
                 "HIP extension %s is missing: run `python -m cusift_amd.build` (needs hipcc); "
                 "there is no CPU fallback for the extraction path" % LIB_PATH
             )
+        _prefer_torch_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the library does not export the symbol

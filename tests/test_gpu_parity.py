@@ -7,6 +7,7 @@ glibc vs OCML), so a handful of hard decisions (histogram bin, arg-max) may flip
 bounded as a fraction, never ignored silently.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,8 @@ from cusift_amd import synth
 from cusift_amd.capi import SIFT_POINT_DTYPE, DeviceBuffer
 from oracle_binding import pitched
 from parity_utils import ang_diff, canonical_order, match_nearest, xys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -674,3 +677,59 @@ def test_errors_are_reported_not_fatal(ctx):
     with pytest.raises(capi.CusiftError, match="max_pts"):
         ctx.extract_batch(d.ptr, 1, 8, 8, 8, 64, bad, d.ptr, d.ptr)
     assert C.c_char_p(capi.lib().cusift_last_error()).value
+
+
+def test_pipelined_extractor_equals_single_stream(ctx, gray1):
+    """PipelinedExtractor (consecutive batches alternating over two streams): every batch's SiftData equals what one
+    BatchExtractor gives for that batch, bit for bit (canonical order)."""
+    import torch
+
+    from cusift_amd.batch import BatchExtractor, PipelinedExtractor
+
+    kw = dict(num_octaves=4, peak_thresh=1.0, max_pts=4096)
+    batches = [np.stack([np.roll(gray1, (7 * b + 3 * i, 11 * b + 5 * i), axis=(0, 1)) for i in range(3)])
+               for b in range(5)]
+    single = BatchExtractor(3, 640, 480, **kw)
+    want = []
+    for imgs in batches:
+        single.extract(single.images_from_numpy(imgs))
+        want.append([canonical(p) for p in single.to_host()])
+    single.close()
+
+    pipe = PipelinedExtractor(3, 640, 480, n_streams=2, n_slots=1, **kw)
+    dev = [pipe.images_from_numpy(imgs) for imgs in batches]
+    torch.cuda.synchronize()
+    for b, d_imgs in enumerate(dev):
+        pts, cnt, done = pipe.submit(d_imgs)
+        done.synchronize()  # outputs of a stream are reused two submits later: read them back first
+        counts = torch.clamp(cnt, max=pipe.max_pts).cpu().numpy()
+        for i in range(3):
+            got = canonical(pts[i, : int(counts[i])].cpu().numpy().view(SIFT_POINT_DTYPE).reshape(-1))
+            assert len(got) == len(want[b][i]) > 100
+            for f in ("coords2D", "scale", "orientation", "data"):
+                assert np.array_equal(got[f], want[b][i][f]), (b, i, f)
+    # and without a wait in between (both streams busy): the last two batches are still intact
+    outs = [pipe.submit(d) for d in dev[-2:]]
+    pipe.synchronize()
+    for (pts, cnt, _), wb in zip(outs, want[-2:]):
+        counts = torch.clamp(cnt, max=pipe.max_pts).cpu().numpy()
+        for i in range(3):
+            got = canonical(pts[i, : int(counts[i])].cpu().numpy().view(SIFT_POINT_DTYPE).reshape(-1))
+            assert np.array_equal(got["data"], wb[i]["data"])
+    pipe.close()
+
+
+def test_torch_still_sees_the_gpu_when_imported_after_the_library():
+    """Load order: libcusift_amd.so first, torch second.  The process can hold one libamdhip64.so.7; capi.lib() loads
+    the copy a PyTorch-ROCm wheel ships (when there is one) so that a later `import torch` finds its own runtime."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cusift_amd import capi\n"
+            "c = capi.Context(0); b = capi.DeviceBuffer(c, 1 << 20)\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "print(float(torch.ones(8, device='cuda').sum()))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("8.0"), out.stdout[-500:] + out.stderr[-1500:]
