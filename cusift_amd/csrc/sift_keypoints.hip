@@ -79,11 +79,23 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, f
   const float *p0 = lds + e;
   const float *p1 = p0 + kStride;
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
-  const float ia = 1.0f - a, ib = 1.0f - b;
-  float t = (ia * ib) * s00;
-  t = fmaf(a * ib, s10, t);
-  t = fmaf(ia * b, s01, t);
-  t = fmaf(a * b, s11, t);
+  float w00, w10, w01, w11;
+  if (kQuant) {
+    // a and b are multiples of 2^-8 in [0, 1]: the four weight products are multiples of 2^-16 below 2 and therefore
+    // exact in fp32, so any exact route gives the bits of (1-a)(1-b), a(1-b), (1-a)b, ab -- one product, four
+    // subtractions instead of two subtractions and four products
+    w11 = a * b;
+    w10 = a - w11;
+    w01 = b - w11;
+    w00 = (1.0f - a) - w01;
+  } else {
+    const float ia = 1.0f - a, ib = 1.0f - b;
+    w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+  }
+  float t = w00 * s00;
+  t = fmaf(w10, s10, t);
+  t = fmaf(w01, s01, t);
+  t = fmaf(w11, s11, t);
   return t;
 }
 
@@ -186,8 +198,8 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
       const float yf = yp + yd;
       const float dx = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
       const float dy = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
-      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
-      if (bin > 31 || bin < 0) bin = 0;  // < 0 only for non-finite input
+      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
+      if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
       const float grad = sqrtf(dx * dx + dy * dy);
       S.sample[t] = make_float2(__int_as_float(bin), grad * S.gauss[xd] * S.gauss[yd]);
     }
@@ -246,7 +258,8 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
 //            angle weight) and accumulates them into a private 8-bin LDS histogram (plain read-add-write,
 //            lane-private rows, stride 9 -> conflict free).  The reference's column-14 spill into the
 //            next row's first cell (guard `tx<=14`, cuSIFT_D.cu:243) is gathered the same way; its
-//            angle-index-8 spill (atan2f == +pi) is rare and goes through one LDS atomic.
+//            angle-index-8 spill (atan2f == +pi) is collected in the row's 9th slot and folded into the
+//            next linear cell in phase 3.
 //   phase 3  the 4 partial histograms of each cell are summed in a fixed order; L2-normalise, clamp at
 //            0.2, L2-normalise with the reference's reduction tree.
 // The order of the sums is fixed, so results are reproducible run to run.  Lane l returns elements l, l+64.
@@ -270,20 +283,20 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
   return c;
 }
 
-__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float *__restrict__ fin, int next_cell_base,
-                                              float grad, float angraw, float wx, float wy) {
-  int angi = (int)angraw;
-  const float angf = angraw - angi;
-  if (angi < 0 || angi > 8) angi = 0;  // only for non-finite input
+__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float grad, float angraw, float wx,
+                                              float wy) {
+  // angraw = 4/pi*atan2 + 4 lies in [0, 8.0001] for every finite gradient and v_cvt_i32_f32 turns a NaN into 0; the
+  // unsigned min is for memory safety only (slots 0..8 exist: the histogram rows have stride 9)
+  const int angc = (int)angraw;
+  const float angf = angraw - angc;
+  const int angi = (int)min((unsigned int)angc, 8u);
   const float grad1 = wx * grad;
   const float grad2 = wy * grad1;
   const float v1 = (1.0f - angf) * grad2;
   const float v2 = angf * grad2;
-  if (angi < 8) {
-    myhist[angi] += v1;
-  } else if (next_cell_base < 128) {
-    atomicAdd(fin + next_cell_base, v1);  // index angi+hist+off = 8 + ...: bin 0 of the next linear cell
-  }
+  // angi == 8 (atan2f == +pi): the reference's index 8 + ... is bin 0 of the NEXT linear cell; it is collected in the
+  // lane's slot 8 and folded into that cell in phase 3 -- no branch and no atomic in the loop
+  myhist[angi] += v1;
   const int angp = (angi < 7 ? angi + 1 : 0);
   myhist[angp] += v2;
 }
@@ -294,8 +307,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
                                               float &out1) {
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
   float *myhist = S.hist8() + lane * 9;
-  float *fin = S.fin(), *sums = S.sums();
-  const int next_cell_base = 8 * (cell + 1);
+  float *sums = S.sums();
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
   float sina, cosa;
   sincosf(theta, &sina, &cosa);  // OCML: one argument reduction, the same polynomials as sinf() and cosf()
@@ -319,10 +331,8 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   }
   wave_sync();
   // the patch is dead from here on: its storage becomes the histogram buffers
-  fin[lane] = 0.0f;
-  fin[lane + 64] = 0.0f;
 #pragma unroll
-  for (int b = 0; b < 8; ++b) myhist[b] = 0.0f;
+  for (int b = 0; b < 9; ++b) myhist[b] = 0.0f;
   wave_sync();
 
   // ---- phase 2: gather into the lane-private histogram ----
@@ -341,7 +351,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
           const float horf = (tx - 1.5f) / 4.0f - hori;
           const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
           const int idx = y * 16 + tx;
-          gather_sample(myhist, fin, next_cell_base, S.grad[idx], S.angraw[idx], wx, wy);
+          gather_sample(myhist, S.grad[idx], S.angraw[idx], wx, wy);
         }
       }
     }
@@ -357,7 +367,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
         const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
         const float horf = (14 - 1.5f) / 4.0f - 3;
         const int idx = y * 16 + 14;
-        gather_sample(myhist, fin, next_cell_base, S.grad[idx], S.angraw[idx], horf, wy);
+        gather_sample(myhist, S.grad[idx], S.angraw[idx], horf, wy);
       }
     }
   }
@@ -370,8 +380,12 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     const int b = lane + 64 * r;
     const float *hc = S.hist8() + (b >> 3) * 4 * 9 + (b & 7);
     bsum[r] = ((hc[0] + hc[9]) + hc[18]) + hc[27];
+    if ((b & 7) == 0 && b >= 8) {  // bin 0 of cell b/8 also receives the angle-index-8 spill of the cell before it
+      const float *hp = S.hist8() + ((b >> 3) - 1) * 4 * 9 + 8;
+      bsum[r] = (((hp[0] + hp[9]) + hp[18]) + hp[27]) + bsum[r];
+    }
   }
-  float b0 = fin[lane] + bsum[0], b1 = fin[lane + 64] + bsum[1];
+  float b0 = bsum[0], b1 = bsum[1];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     sums[lane] = b0 * b0 + b1 * b1;
