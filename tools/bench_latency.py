@@ -69,6 +69,36 @@ def measure(w=1920, h=1080, iters=200, warmup=20):
         ctx.timing_enable(False)
         out["gpu_ms_per_frame_by_stage"] = {k: round(v[0] / 20, 4) for k, v in t.items() if v[1]}
         graph.close()
+        # PCIe-inclusive: SiftData::Extract(float *host, w, h) -- dense pageable host image in, SiftData back on the
+        # host (cusift_extract_host), and the 8-bit upload front-end (1 byte per pixel + conversion on the device)
+        h_pts = np.zeros(prm.max_pts, dtype=capi.SIFT_POINT_DTYPE)
+        dense = np.ascontiguousarray(img, dtype=np.float32)
+        for _ in range(5):
+            n = ctx.extract_host(dense, prm, d_pts.ptr, h_pts)
+        lat = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            n = ctx.extract_host(dense, prm, d_pts.ptr, h_pts)
+            lat.append(time.perf_counter() - t0)
+        out["host_float_in_host_siftdata_out"] = {"latency_ms_median": round(float(np.median(lat)) * 1e3, 4),
+                                                   "keypoints": int(n),
+                                                   "bytes_up": int(dense.nbytes), "bytes_down": int(n) * 588}
+        lat = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            n = ctx.extract_host(dense, prm, d_pts.ptr, None)
+            lat.append(time.perf_counter() - t0)
+        out["host_float_in_device_siftdata"] = {"latency_ms_median": round(float(np.median(lat)) * 1e3, 4)}
+        u8 = np.ascontiguousarray(img.astype(np.uint8))
+        if hasattr(ctx, "image_u8_h2d"):
+            lat = []
+            for _ in range(50):
+                t0 = time.perf_counter()
+                ctx.image_u8_h2d(d_img.ptr, p, u8)
+                ctx.extract_batch(*args)
+                ctx.synchronize()
+                lat.append(time.perf_counter() - t0)
+            out["host_u8_in_device_siftdata"] = {"latency_ms_median": round(float(np.median(lat)) * 1e3, 4)}
     return out
 
 
