@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps alternate over (one extractor each): the HBM-bound ScaleDown chain and "
                          "the launch tails of one batch overlap the VALU-bound kernels of the next")
+    ap.add_argument("--gather-depth", type=int, default=1,
+                    help="N > 1: the all-gatherv of step i is issued after step i + depth has been enqueued")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gatherv of SiftData even with one rank (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
@@ -162,7 +164,10 @@ def main():
     from cusift_amd.batch import PipelinedExtractor
 
     E = max(1, args.streams)
-    pipe = PipelinedExtractor(B, w, h, n_streams=E, n_slots=2 if use_dist else 1,
+    # output slots per extractor: a slot is overwritten E * n_slots steps later, and the gather of step i (which
+    # reads it) is issued -- and its packing waited for -- right after step i + gather_depth has been enqueued
+    n_slots = max(2, args.gather_depth // E + 2) if use_dist else 1
+    pipe = PipelinedExtractor(B, w, h, n_streams=E, n_slots=n_slots,
                               fused_detect=0 if args.two_stage else 1, **prm_kw)
     exs = pipe.extractors
     ex = exs[0]
@@ -194,7 +199,7 @@ def main():
         pts, cnt, ev = pipe.submit(d_imgs)
         if use_dist:
             pending.append((pts, cnt, ev))
-            if len(pending) > 1:
+            if len(pending) > args.gather_depth:
                 finish_one()
 
     def drain():

@@ -61,18 +61,29 @@ class BatchExtractor:
         ctx = self.ctx if stream == self.stream else capi.Context(self.device.index, stream=stream.cuda_stream)
         self._packer_ctxs = getattr(self, "_packer_ctxs", []) + [ctx]
 
-        def packer(points, counts, max_pts):
+        def packer(points, counts, max_pts, out=None):
+            """Valid records of all images back to back.  out=None: returns (packed, valid counts) like
+            cusift_amd.dist.pack_points (one host read-back for the size); out=<uint8 [total, 588] tensor of exactly
+            the valid total>: packs into it, no read-back, returns None."""
             n = points.shape[0]
             if n > 256 or not points.is_cuda:  # kMaxFlatImages
                 from .dist import pack_points
-                return pack_points(points, counts, max_pts)
+                packed, valid = pack_points(points, counts, max_pts)
+                if out is None:
+                    return packed, valid
+                out.copy_(packed)
+                return None
             with torch.cuda.stream(stream):
-                valid = torch.clamp(counts, max=max_pts)
-                total = int(valid.sum().item())  # the one host read-back of the packing
-                packed = torch.empty((total, capi.SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+                if out is None:
+                    valid = torch.clamp(counts, max=max_pts)
+                    total = int(valid.sum().item())  # the one host read-back of the packing
+                    out_t = torch.empty((total, capi.SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+                else:
+                    assert out.is_contiguous() and out.dtype == torch.uint8 and out.shape[1] == capi.SIFT_POINT_BYTES
+                    out_t, total = out, out.shape[0]
                 if total > 0:
-                    ctx.pack_points(points.data_ptr(), counts.data_ptr(), n, max_pts, packed.data_ptr(), total, None)
-            return packed, valid
+                    ctx.pack_points(points.data_ptr(), counts.data_ptr(), n, max_pts, out_t.data_ptr(), total, None)
+            return (out_t, valid) if out is None else None
 
         return packer
 

@@ -43,9 +43,9 @@ def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    # `packer(points, counts, max_pts) -> (packed [sum,588], valid counts)`: BatchExtractor.pack on the GPU (one
-    # HIP kernel); the torch expression below is the host/gloo form
-    packed, valid = (packer or pack_points)(points, counts, max_pts)
+    # counts first (cheap: a clamp), so that every rank knows all offsets before anything is packed: the local shard
+    # is then packed straight into its place in `gathered` and sent from there -- no staging copy of ~100 MB
+    valid = torch.clamp(counts.to(torch.int64), min=0, max=max_pts).to(torch.int32)
     n_local = torch.tensor([valid.numel()], dtype=torch.int32, device=points.device)
     n_all = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(n_all, n_local, group=group)
@@ -59,6 +59,14 @@ def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer
     offsets[1:] = torch.cumsum(per_rank, 0)
     total = int(offsets[-1])
     gathered = torch.empty((total, SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
+    mine = gathered[int(offsets[rank]): int(offsets[rank + 1])]
+    # `packer(points, counts, max_pts, out)`: BatchExtractor.make_packer runs one HIP kernel that writes the valid
+    # records of all images back to back into `out`; the torch expression below is the host/gloo form
+    if packer is not None:
+        packer(points, counts, max_pts, mine)
+    else:
+        mine.copy_(pack_points(points, counts, max_pts)[0])
+    packed = mine
 
     if method == "padded":
         biggest = int(per_rank.max()) if world else 0
@@ -69,8 +77,6 @@ def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer
         for r in range(world):
             gathered[int(offsets[r]): int(offsets[r + 1])] = recv[r, : int(per_rank[r])]
     elif method == "p2p":
-        packed = packed.contiguous()
-        gathered[int(offsets[rank]): int(offsets[rank + 1])] = packed
         ops = []
         for step in range(1, world):
             dst = (rank + step) % world
