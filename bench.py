@@ -129,7 +129,7 @@ def main():
 
     from cusift_amd import capi, synth
     from cusift_amd.batch import BatchExtractor
-    from cusift_amd.dist import allgather_siftdata
+    from cusift_amd.dist import begin_allgather, finish_allgather
 
     # Rank 0 prints exactly ONE line on stdout.  Libraries write there too (RCCL prints a version banner on
     # communicator creation), so from here on file descriptor 1 points at stderr and the JSON line goes to a
@@ -189,16 +189,26 @@ def main():
     pending = []
     state = {"gathered": None}
 
+    slot_free = {}  # (stream index, slot) -> event after which the slot's last gather no longer reads it
+
     def finish_one():
-        pts, cnt, ev = pending.pop(0)
+        ticket, key = pending.pop(0)
         with torch.cuda.stream(side_stream):
-            side_stream.wait_event(ev)
-            state["gathered"] = allgather_siftdata(pts, cnt, ex.max_pts, method=args.gather, packer=packer)
+            state["gathered"] = finish_allgather(ticket, method=args.gather, packer=packer)
+            done = torch.cuda.Event()
+            done.record(side_stream)
+        slot_free[key] = done
 
     def step():
-        pts, cnt, ev = pipe.submit(d_imgs)
+        key = (pipe.submitted % E, (pipe.submitted // E) % pipe.n_slots)
+        pts, cnt, ev = pipe.submit(d_imgs, ready=slot_free.pop(key, None))
         if use_dist:
-            pending.append((pts, cnt, ev))
+            # phase 1 of the all-gatherv right away (counts exchange + async copy to pinned memory, no host wait);
+            # phase 2 (pack + shard exchange) once `gather_depth` further steps have been enqueued, by which time
+            # the counts have long arrived
+            with torch.cuda.stream(side_stream):
+                side_stream.wait_event(ev)
+                pending.append((begin_allgather(pts, cnt, ex.max_pts, n_images_max=B), key))
             if len(pending) > args.gather_depth:
                 finish_one()
 
@@ -284,7 +294,7 @@ def main():
     kp = torch.tensor([local_kp], dtype=torch.int64, device=dev)
     if use_dist:
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
-        total_gathered = int(gathered[2][-1])
+        total_gathered = int(gathered[2][-1])  # noqa
         assert total_gathered == int(kp.item()), (total_gathered, int(kp.item()))
     total_kp = int(kp.item())
 

@@ -33,35 +33,56 @@ def pack_points(points, counts, max_pts):
     return points[mask], valid.to(torch.int32)
 
 
-def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer=None):
-    """All-gatherv of SiftData.
+class GatherTicket:
+    """First half of an all-gatherv of SiftData: the counts of every rank are on their way to pinned host memory."""
 
-    points : uint8 [n_local, max_pts, 588] on this rank; counts : int32 [n_local] raw counters.
-    Returns (all_counts int32 [world, n_max], gathered uint8 [total, 588], offsets int64 [world + 1]) where
-    rank r's records occupy gathered[offsets[r]:offsets[r+1]] in image order, and all_counts[r, i] is the
-    number of points of its i-th image (rows are padded with 0 when ranks hold different image counts).
-    """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    # counts first (cheap: a clamp), so that every rank knows all offsets before anything is packed: the local shard
-    # is then packed straight into its place in `gathered` and sent from there -- no staging copy of ~100 MB
+    __slots__ = ("points", "counts", "max_pts", "group", "all_counts", "host_counts", "ready", "world", "rank")
+
+
+def begin_allgather(points, counts, max_pts, group=None, n_images_max=None):
+    """Phase 1 (asynchronous, no host wait): exchange the per-image counts and start copying them to pinned host
+    memory.  `n_images_max`: the largest number of images any rank holds; None = find out with one more (blocking)
+    exchange.  Call on the stream the exchange should run on, after that stream has been made to wait for `points`."""
+    t = GatherTicket()
+    t.points, t.counts, t.max_pts, t.group = points, counts, max_pts, group
+    t.world, t.rank = dist.get_world_size(group), dist.get_rank(group)
     valid = torch.clamp(counts.to(torch.int64), min=0, max=max_pts).to(torch.int32)
-    n_local = torch.tensor([valid.numel()], dtype=torch.int32, device=points.device)
-    n_all = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(n_all, n_local, group=group)
-    n_max = int(max(int(t.item()) for t in n_all))
+    if n_images_max is None:
+        n_local = torch.tensor([valid.numel()], dtype=torch.int32, device=points.device)
+        n_all = [torch.zeros_like(n_local) for _ in range(t.world)]
+        dist.all_gather(n_all, n_local, group=group)
+        n_images_max = int(torch.stack(n_all).max().item())
+    n_max = max(int(n_images_max), valid.numel())
     padded_counts = torch.zeros(n_max, dtype=torch.int32, device=points.device)
     padded_counts[: valid.numel()] = valid
-    all_counts = torch.zeros((world, n_max), dtype=torch.int32, device=points.device)
-    dist.all_gather_into_tensor(all_counts.view(-1), padded_counts, group=group)
-    per_rank = all_counts.sum(dim=1).to(torch.int64).cpu()  # the one host read-back of the exchange
+    t.all_counts = torch.zeros((t.world, n_max), dtype=torch.int32, device=points.device)
+    dist.all_gather_into_tensor(t.all_counts.view(-1), padded_counts, group=group)
+    if points.is_cuda:
+        t.host_counts = torch.empty((t.world, n_max), dtype=torch.int32, pin_memory=True)
+        t.host_counts.copy_(t.all_counts, non_blocking=True)
+        t.ready = torch.cuda.Event()
+        t.ready.record()
+    else:
+        t.host_counts, t.ready = t.all_counts, None
+    return t
+
+
+def finish_allgather(t, method="p2p", packer=None):
+    """Phase 2: waits for the ticket's counts (an event that has long fired if a step of other work was enqueued in
+    between), allocates the result, packs the local shard straight into its place and exchanges the shards.
+    Returns (all_counts, gathered, offsets) as allgather_siftdata does."""
+    if t.ready is not None:
+        t.ready.synchronize()
+    points, counts, max_pts, group, world, rank = t.points, t.counts, t.max_pts, t.group, t.world, t.rank
+    per_rank = t.host_counts.to(torch.int64).sum(dim=1)
     offsets = torch.zeros(world + 1, dtype=torch.int64)
     offsets[1:] = torch.cumsum(per_rank, 0)
     total = int(offsets[-1])
     gathered = torch.empty((total, SIFT_POINT_BYTES), dtype=torch.uint8, device=points.device)
     mine = gathered[int(offsets[rank]): int(offsets[rank + 1])]
     # `packer(points, counts, max_pts, out)`: BatchExtractor.make_packer runs one HIP kernel that writes the valid
-    # records of all images back to back into `out`; the torch expression below is the host/gloo form
+    # records of all images back to back into `out` -- the local shard is packed straight into its place in
+    # `gathered` and sent from there (no staging copy); the torch expression below is the host/gloo form
     if packer is not None:
         packer(points, counts, max_pts, mine)
     else:
@@ -91,7 +112,19 @@ def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer
                 req.wait()
     else:
         raise ValueError("unknown method %r" % method)
-    return all_counts, gathered, offsets
+    return t.all_counts, gathered, offsets
+
+
+def allgather_siftdata(points, counts, max_pts, group=None, method="p2p", packer=None, n_images_max=None):
+    """All-gatherv of SiftData (both phases back to back; a pipelined caller uses begin_allgather /
+    finish_allgather with a step of other work in between, which removes every host wait from its critical path).
+
+    points : uint8 [n_local, max_pts, 588] on this rank; counts : int32 [n_local] raw counters.
+    Returns (all_counts int32 [world, n_max], gathered uint8 [total, 588], offsets int64 [world + 1]) where
+    rank r's records occupy gathered[offsets[r]:offsets[r+1]] in image order, and all_counts[r, i] is the
+    number of points of its i-th image (rows are padded with 0 when ranks hold different image counts).
+    """
+    return finish_allgather(begin_allgather(points, counts, max_pts, group, n_images_max), method, packer)
 
 
 def _global_rank(group_rank, group):
