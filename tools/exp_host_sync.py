@@ -26,6 +26,7 @@ packer = pipe.extractors[0].make_packer(side)
 torch.cuda.synchronize()
 dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
 scratch = torch.empty((200000, 588), dtype=torch.uint8, device=dev)
+scratch_i = torch.zeros((1, 64), dtype=torch.int32, device=dev)
 
 
 def run(mode, steps=24):
@@ -42,6 +43,17 @@ def run(mode, steps=24):
                 v = torch.clamp(cnt.to(torch.int64), min=0, max=32768).to(torch.int32)
                 z = torch.zeros((1, 64), dtype=torch.int32, device=dev)
                 z[0, :64] = v
+            elif mode == "op_clamp":
+                torch.clamp(cnt, min=0, max=32768)
+            elif mode == "op_to64":
+                cnt.to(torch.int64)
+            elif mode == "op_zeros":
+                torch.zeros((1, 64), dtype=torch.int32, device=dev)
+            elif mode == "op_slice_assign":
+                scratch_i[0, :64] = cnt
+            elif mode == "op_zeros_1d_assign":
+                z = torch.zeros(64, dtype=torch.int32, device=dev)
+                z[:64] = cnt
             elif mode == "allgather":
                 out = torch.zeros(64, dtype=torch.int32, device=dev)
                 dist.all_gather_into_tensor(out, cnt)
@@ -59,6 +71,6 @@ def run(mode, steps=24):
     print("%-12s %.4f ms/step" % (mode, (time.perf_counter() - t0) / steps * 1e3), flush=True)
 
 
-for m in ("none", "none", "smallops", "allgather", "begin", "empty99", "pack", "full", "none"):
+for m in ("none", "op_clamp", "op_to64", "op_zeros", "op_slice_assign", "op_zeros_1d_assign", "smallops", "begin", "none"):
     run(m)
 dist.destroy_process_group()
