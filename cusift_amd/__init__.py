@@ -7,9 +7,9 @@ Layout
     dist.py     one-process-per-GPU sharding of an image batch + all-gatherv of SiftData (RCCL)
     tiling.py   one large image strip-tiled over several GPUs with per-octave halo exchange
     synth.py    seeded synthetic inputs of the benchmark configurations
+    build.py    hipcc build of the shared object (in-tree)
 The host-side mirror of the reference's C++ surface (SiftData / cuImage / ExtractSift, MatchSiftData, FindHomography
 ...) is C++ like the reference: include/cuSIFT.h, matching.h, debug.h, homography.h over the same C ABI.
-    build.py    hipcc build of the shared object (in-tree)
 """
 from .capi import (SIFT_POINT_BYTES, SIFT_POINT_DTYPE, Context, CusiftError, DeviceBuffer, Params,  # noqa: F401
                    default_params, device_count, ialign_up)
