@@ -63,6 +63,23 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
   }
 }
 
+// (1-a)(1-b), a(1-b), (1-a)b, ab of the texture model.
+template <bool kQuant>
+__device__ __forceinline__ void bilinear_weights(float a, float b, float &w00, float &w10, float &w01, float &w11) {
+  if (kQuant) {
+    // a and b are multiples of 2^-8 in [0, 1]: the four weight products are multiples of 2^-16 below 2 and therefore
+    // exact in fp32, so any exact route gives the bits of (1-a)(1-b), a(1-b), (1-a)b, ab -- one product, four
+    // subtractions instead of two subtractions and four products
+    w11 = a * b;
+    w10 = a - w11;
+    w01 = b - w11;
+    w00 = (1.0f - a) - w01;
+  } else {
+    const float ia = 1.0f - a, ib = 1.0f - b;
+    w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+  }
+}
+
 template <int kStride, bool kQuant>
 __device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, float x, float y, float q, float inv_q) {
   const float xb = x - 0.5f, yb = y - 0.5f;
@@ -80,18 +97,7 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, f
   const float *p1 = p0 + kStride;
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
   float w00, w10, w01, w11;
-  if (kQuant) {
-    // a and b are multiples of 2^-8 in [0, 1]: the four weight products are multiples of 2^-16 below 2 and therefore
-    // exact in fp32, so any exact route gives the bits of (1-a)(1-b), a(1-b), (1-a)b, ab -- one product, four
-    // subtractions instead of two subtractions and four products
-    w11 = a * b;
-    w10 = a - w11;
-    w01 = b - w11;
-    w00 = (1.0f - a) - w01;
-  } else {
-    const float ia = 1.0f - a, ib = 1.0f - b;
-    w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
-  }
+  bilinear_weights<kQuant>(a, b, w00, w10, w01, w11);
   float t = w00 * s00;
   t = fmaf(w10, s10, t);
   t = fmaf(w01, s01, t);
@@ -113,6 +119,9 @@ __device__ __forceinline__ void wave_sync() {
 // run-time Sampler the compiler guarded each of the 24 taps per lane with two branches).
 template <int kStride, bool kQuant>
 struct PatchSampler {
+  static constexpr bool kIsPatch = true;
+  static constexpr int kPatchStride = kStride;
+  static constexpr bool kQuantised = kQuant;
   const float *patch;
   int x0, y0;  // image coordinate of patch element (0,0)
   float q, inv_q;
@@ -121,6 +130,9 @@ struct PatchSampler {
   }
 };
 struct GlobalSampler {
+  static constexpr bool kIsPatch = false;
+  static constexpr int kPatchStride = 1;
+  static constexpr bool kQuantised = false;
   const float *img;
   int w, h, pitch;
   RowWindow rw;
@@ -187,6 +199,34 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   if (tx < 11) S.gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
   const float xp = kx - 5.0f;
   const float yp = ky - 5.0f;
+  // Lattice shortcut.  The 484 taps of a keypoint sit at kx + n/2, ky + m/2 (n, m integers, |n|,|m| <= 13).  Let
+  // u = ulp(kx) (<= 1/2 for kx < 2^23).  Every intermediate of the reference's arithmetic ((kx - 5) + i) +- 1 - 0.5 is
+  // a multiple of u; it is exactly representable -- so no operation rounds -- as long as it does not climb into the
+  // binade ABOVE kx's, where the spacing doubles (below kx's binade the spacing only gets finer).  If kx + 8 is still
+  // in kx's binade, all taps therefore share ONE pair of bilinear fractions (frac(kx - 0.5), frac(ky - 0.5)) and
+  // their footprints are integer shifts of each other: the weights are formed once per keypoint and a tap costs one
+  // product and three fused multiply-adds -- the same operations on the same operands as the general path, so the
+  // same bits.  Keypoints within 8 px below a power of two (or with a coordinate < 16) take the general path.
+  bool lattice = false;
+  float w00 = 0.f, w10 = 0.f, w01 = 0.f, w11 = 0.f;
+  int e_c = 0;  // patch element of the pixel that holds floor(k - 0.5) of the window's centre sample
+  if constexpr (TEX::kIsPatch) {
+    const float xhi = kx + 8.0f, yhi = ky + 8.0f;
+    lattice = kx >= 1.0f && ky >= 1.0f && xhi < 4.0e6f && yhi < 4.0e6f &&
+              (__float_as_int(kx) >> 23) == (__float_as_int(xhi) >> 23) &&
+              (__float_as_int(ky) >> 23) == (__float_as_int(yhi) >> 23);
+    if (lattice) {  // wave-uniform
+      const float xb = kx - 0.5f, yb = ky - 0.5f;  // the centre sample's T(x, y) coordinate: (xp + 5) == kx exactly
+      const float fx = floorf(xb), fy = floorf(yb);
+      float a = xb - fx, b = yb - fy;
+      if (TEX::kQuantised) {
+        a = floorf(fmaf(a, tex.q, 0.5f)) * tex.inv_q;
+        b = floorf(fmaf(b, tex.q, 0.5f)) * tex.inv_q;
+      }
+      bilinear_weights<TEX::kQuantised>(a, b, w00, w10, w01, w11);
+      e_c = ((int)fy - tex.y0) * TEX::kPatchStride + ((int)fx - tex.x0);
+    }
+  }
   wave_sync();
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
@@ -194,10 +234,31 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     if (t < 121) {
       const int yd = t / 11;
       const int xd = t - yd * 11;
-      const float xf = xp + xd;
-      const float yf = yp + yd;
-      const float dx = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
-      const float dy = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
+      float dx = 0.0f, dy = 0.0f;
+      bool done = false;
+      if constexpr (TEX::kIsPatch) {
+        if (lattice) {
+          constexpr int RS = TEX::kPatchStride;
+          // P(r, c): pixel (floor(yb) + r, floor(xb) + c) of this sample's own T(x, y) footprint origin
+          const float *P = tex.patch + e_c + (yd - 5) * RS + (xd - 5);
+          auto T = [&](int r, int c) {  // T(x + c, y + r): footprint rows r, r+1 x columns c, c+1
+            float v = w00 * P[r * RS + c];
+            v = fmaf(w10, P[r * RS + c + 1], v);
+            v = fmaf(w01, P[(r + 1) * RS + c], v);
+            v = fmaf(w11, P[(r + 1) * RS + c + 1], v);
+            return v;
+          };
+          dx = T(0, 1) - T(0, -1);
+          dy = T(1, 0) - T(-1, 0);
+          done = true;
+        }
+      }
+      if (!done) {
+        const float xf = xp + xd;
+        const float yf = yp + yd;
+        dx = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
+        dy = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
+      }
       int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
       if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
       const float grad = sqrtf(dx * dx + dy * dy);
