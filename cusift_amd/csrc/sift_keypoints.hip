@@ -270,11 +270,19 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     // bins are lanes (lane & 31); the lower half-wave sums samples 0..60 in index order, the upper half-wave
     // samples 61..120, then hist = lower + upper -- the oracle accumulates in exactly this order
     const int b = tx & 31;
-    const int t0 = tx < 32 ? 0 : 61, t1 = tx < 32 ? 61 : 121;
+    // 60 samples per half-wave from a per-lane base, fully unrolled (immediate LDS offsets, loads in flight in
+    // batches: the rolled loop waited out one LDS round trip per sample and spent as many instructions on loop
+    // control as on the sum), then sample 60 for the lower half; adding 0.0f to a non-negative sum is exact
+    const float2 *sp = S.sample + (tx < 32 ? 0 : 61);
     float acc = 0.0f;
-    for (int t = t0; t < t1; ++t) {
-      const float2 sv = S.sample[t];
-      if (__float_as_int(sv.x) == b) acc += sv.y;
+#pragma unroll
+    for (int k = 0; k < 60; ++k) {
+      const float2 sv = sp[k];
+      acc = (__float_as_int(sv.x) == b) ? acc + sv.y : acc;
+    }
+    if (tx < 32) {
+      const float2 sv = S.sample[60];
+      acc = (__float_as_int(sv.x) == b) ? acc + sv.y : acc;
     }
     if (tx >= 32) S.hist[tx] = acc;  // hist[32 + b]: scratch until the smoothing pass overwrites it
     wave_sync();
@@ -357,9 +365,12 @@ __device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float 
   const float v2 = angf * grad2;
   // angi == 8 (atan2f == +pi): the reference's index 8 + ... is bin 0 of the NEXT linear cell; it is collected in the
   // lane's slot 8 and folded into that cell in phase 3 -- no branch and no atomic in the loop
-  myhist[angi] += v1;
   const int angp = (angi < 7 ? angi + 1 : 0);
-  myhist[angp] += v2;
+  // angp != angi always, so the two read-modify-writes are independent: both reads first (one LDS round trip per
+  // sample instead of two)
+  const float h1 = myhist[angi], h2 = myhist[angp];
+  myhist[angi] = h1 + v1;
+  myhist[angp] = h2 + v2;
 }
 
 template <typename TEX>
