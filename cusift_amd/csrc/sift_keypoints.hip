@@ -57,9 +57,22 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
   const int rows_per_iter = 64 / cols;
   const int c = lane & (cols - 1), rsub = lane / cols;
   const int col = clampi(g.x0 + c, 0, w - 1);
-  for (int r = rsub; r < ph; r += rows_per_iter) {
-    const int row = local_row(g.y0 + r, h, rw);
-    if (c < pw) lds[r * g.stride + c] = img[(long)row * pitch + col];
+  // eight row loads in flight, then eight LDS writes (left to itself the compiler issued one load, waited for it,
+  // wrote it, and only then issued the next: one full memory round trip per patch row)
+  constexpr int kBatch = 8;
+  for (int r0 = rsub; r0 < ph; r0 += rows_per_iter * kBatch) {
+    float v[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int r = min(r0 + k * rows_per_iter, ph - 1);  // rows past the patch re-read its last row (not stored)
+      const int row = local_row(g.y0 + r, h, rw);
+      v[k] = img[(long)row * pitch + col];
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int r = r0 + k * rows_per_iter;
+      if (r < ph && c < pw) lds[r * g.stride + c] = v[k];
+    }
   }
 }
 
