@@ -206,6 +206,30 @@ __device__ __forceinline__ float max_over_32(float v) {
   return fmaxf(v, __shfl_xor(v, 16));
 }
 
+// The reference's 64-element reduction tree (cuSIFT_D.cu:262-280: s[l] += s[l+32], += s[l+16], += s[l+8],
+// += s[l+4], then s[0]+s[1]+s[2]+s[3] left to right) without LDS round trips: the two cross-row steps are gfx950
+// lane-swap instructions, the two in-row steps DPP shifts, the last four terms are read by lane.  Same pairs added in
+// the same order, so the same bits; every lane returns the total.
+__device__ __forceinline__ float tree_sum64(float x) {
+  // The swap instructions exchange halves / rows BETWEEN two registers and modify both.  Inline assembly: this
+  // compiler's __builtin_amdgcn_permlane{32,16}_swap returns the first register for both results.  The s_nops cover
+  // the VALU -> permlane-swap -> VALU wait states, which the hazard recogniser does not see inside an asm block.
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));  // a = (lo, lo), b = (hi, hi)
+  const float y = a + b;  // x[l] + x[l+32]
+  float c = y, d = y;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));  // c = (r0,r0,r2,r2), d = (r1,r1,r3,r3)
+  const float z = c + d;  // y[l] + y[l+16]
+  const float w = z + dpp_perm<0x108>(z);  // row_shl:8: lane l receives lane l+8
+  const float u = w + dpp_perm<0x104>(w);  // row_shl:4
+  const int ui = __builtin_bit_cast(int, u);
+  const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 0));
+  const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 1));
+  const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 2));
+  const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 3));
+  return s0 + s1 + s2 + s3;
+}
+
 template <typename SH, typename TEX>
 __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
@@ -392,7 +416,6 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
                                               float &out1) {
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
   float *myhist = S.hist8() + lane * 9;
-  float *sums = S.sums();
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
   float sina, cosa;
   sincosf(theta, &sina, &cosa);  // OCML: one argument reduction, the same polynomials as sinf() and cosf()
@@ -473,17 +496,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   float b0 = bsum[0], b1 = bsum[1];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    sums[lane] = b0 * b0 + b1 * b1;
-    wave_sync();
-    if (lane < 32) sums[lane] = sums[lane] + sums[lane + 32];
-    wave_sync();
-    if (lane < 16) sums[lane] = sums[lane] + sums[lane + 16];
-    wave_sync();
-    if (lane < 8) sums[lane] = sums[lane] + sums[lane + 8];
-    wave_sync();
-    if (lane < 4) sums[lane] = sums[lane] + sums[lane + 4];
-    wave_sync();
-    const float tsum = sums[0] + sums[1] + sums[2] + sums[3];
+    const float tsum = tree_sum64(b0 * b0 + b1 * b1);
     const float r = 1.0f / sqrtf(tsum);
     b0 = b0 * r;
     b1 = b1 * r;
@@ -491,7 +504,6 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       if (b0 > 0.2f) b0 = 0.2f;
       if (b1 > 0.2f) b1 = 0.2f;
     }
-    wave_sync();
   }
   out0 = b0;
   out1 = b1;
