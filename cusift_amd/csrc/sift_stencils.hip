@@ -782,10 +782,14 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
       __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((unsigned int)h * (unsigned int)pitch * 4u), kBufFlags);
   const bool lane_valid = lane >= kDetHaloLanes && lane < 64 - kDetHaloLanes;
 
-  auto load_row = [&](int y) -> f4 {
+  // The load and its border fix-up are separate: the fix-up is the first USE of the loaded registers, and it is
+  // written where the row enters the window -- two row steps after the load was issued -- so that the wait for the
+  // load sits there too (as one function the compiler fixed the row up, and waited, one row step after the issue).
+  auto load_raw = [&](int y) -> f4 {
     const int yc = clampi(y, 0, h - 1);
-    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, yc * pitch * 4, 0);
-    f4 v = __builtin_bit_cast(f4, raw);
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, yc * pitch * 4, 0));
+  };
+  auto fix = [&](f4 v) -> f4 {
     if (left) v = f4{v.x, v.x, v.x, v.x};
     if (right) v = f4{v.w, v.w, v.w, v.w};
     return v;
@@ -793,7 +797,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
 
   f4 win[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) win[i] = load_row(ya - 1 - 4 + i);
+  for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 1 - 4 + i));
 
   // DoG rows yy-2, yy-1, yy live in three register sets whose roles rotate; the row loop is unrolled by
   // three so the rotation costs no moves.
@@ -801,10 +805,10 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
 #pragma unroll
   for (int p = 0; p < kNumDog; ++p) DA[p] = DB[p] = DC[p] = f4{0.f, 0.f, 0.f, 0.f};
 
-  f4 ahead = load_row(ya - 1 + 5);  // row yy+5 of the first iteration; the loop keeps two rows in flight
+  f4 ahead = load_raw(ya - 1 + 5);  // row yy+5 of the first iteration; the loop keeps two rows in flight
   auto row_step = [&](int yy, f4 (&D0)[kNumDog], f4 (&D1)[kNumDog], f4 (&D2)[kNumDog]) {
-    const f4 nxt = ahead;        // requested one iteration ago
-    ahead = load_row(yy + 6);    // needed two iterations from now
+    const f4 nxt = ahead;        // requested one iteration ago (raw)
+    ahead = load_raw(yy + 6);    // needed two iterations from now
     blur_dog_row<kIdent0>(win, T, D2);
 
     if (yy >= ya + 1) {
@@ -910,7 +914,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
-    win[8] = nxt;
+    win[8] = fix(nxt);
   };
 
   for (int yy = ya - 1; yy <= yb; yy += 3) {
