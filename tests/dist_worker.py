@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 from cusift_amd import synth  # noqa: E402
-from cusift_amd.dist import allgather_siftdata, shard_range, split_gathered  # noqa: E402
+from cusift_amd.dist import (allgather_siftdata, begin_allgather, finish_allgather, shard_range,  # noqa: E402
+                             split_gathered)
 from oracle_binding import SIFT_POINT_DTYPE, Oracle  # noqa: E402
 
 
@@ -35,6 +36,24 @@ def main():
             result[method] = dict(counts=ac.numpy(), gathered=ga.numpy(), offsets=off.numpy())
         result["local_pts"] = pts.numpy()
         result["local_cnt"] = cnt.numpy()
+    elif mode == "pipelined":
+        # the order bench.py uses: phase 1 of step i+1 is issued before phase 2 of step i (two tickets in flight),
+        # with the image-count hint that skips the first exchange; every step must equal the one-shot form
+        max_pts, n_local = 12, 4
+        steps = []
+        for k in range(3):
+            g = torch.Generator().manual_seed(1000 * k + rank)
+            pts = torch.randint(0, 255, (n_local, max_pts, 588), dtype=torch.uint8, generator=g)
+            cnt = torch.tensor([(7 * i + 5 * rank + 3 * k) % 16 for i in range(n_local)], dtype=torch.int32)
+            steps.append((pts, cnt))
+        tickets = [begin_allgather(p, c, max_pts, n_images_max=n_local) for p, c in steps[:2]]
+        outs = [finish_allgather(tickets[0])]
+        tickets.append(begin_allgather(steps[2][0], steps[2][1], max_pts, n_images_max=n_local))
+        outs += [finish_allgather(tickets[1]), finish_allgather(tickets[2])]
+        for k, ((pts, cnt), (ac, ga, off)) in enumerate(zip(steps, outs)):
+            ac1, ga1, off1 = allgather_siftdata(pts, cnt, max_pts)
+            result["step%d" % k] = dict(counts=ac.numpy(), gathered=ga.numpy(), offsets=off.numpy(),
+                                        counts1=ac1.numpy(), gathered1=ga1.numpy(), offsets1=off1.numpy())
     else:
         # the real thing at small scale: a batch of 5 images sharded over the ranks, oracle extraction,
         # all-gatherv, every rank ends up with the same merged SiftData in global image order

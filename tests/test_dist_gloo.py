@@ -127,3 +127,16 @@ def test_strip_tiling_halo_exchange_and_merge(world, tmp_path, oracle):
         np.testing.assert_array_equal(got["coords2D"][:, 0], want["coords2D"][:, 0])
         np.testing.assert_allclose(got["coords2D"][:, 1], want["coords2D"][:, 1], atol=1e-3, rtol=0)
         np.testing.assert_array_equal(got["sharpness"], want["sharpness"])
+
+
+def test_two_phase_allgatherv_with_tickets_in_flight(tmp_path):
+    """begin_allgather / finish_allgather in the pipelined order of bench.py (phase 1 of the next step before phase 2
+    of the current one) give, step by step, what the one-shot allgather_siftdata gives -- on every rank."""
+    res = run_world(2, "pipelined", tmp_path)
+    for r in res:
+        for k in range(3):
+            for name in ("counts", "gathered", "offsets"):
+                assert np.array_equal(r["step%d.%s" % (k, name)], r["step%d.%s1" % (k, name)]), (k, name)
+        assert r["step0.gathered"].shape[0] > 0
+    for k in range(3):  # and both ranks hold the same gathered SiftData
+        assert np.array_equal(res[0]["step%d.gathered" % k], res[1]["step%d.gathered" % k])
