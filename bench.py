@@ -27,6 +27,11 @@ import time
 
 import numpy as np
 
+# ROCr reads its flags once, at hsa_init -- i.e. at the first HIP call of the process -- so this has to be in the
+# environment before torch (or libcusift_amd.so) touches the GPU: the host driver only supports dmabuf IPC, and
+# without it RCCL's cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -162,7 +167,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_gather
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)

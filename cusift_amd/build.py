@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcusift_amd.so")
 SOURCES = ["sift_capi.hip", "sift_stencils.hip", "sift_keypoints.hip", "sift_match.hip",
            "sift_frontend.hip", "sift_homography.hip"]
-HEADERS = [os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"),
+HEADERS = [os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"),
            os.path.join(HERE, "..", "include", "cusift_amd.h")]
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).
@@ -50,10 +50,18 @@ def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 if missing or older than its sources. Returns the path."""
     if not force and not is_stale():
         return LIB
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    # build into a temporary file and rename it onto LIB: a concurrent rank that loads the library (or builds it too)
+    # never sees a half-written shared object
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

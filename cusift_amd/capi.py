@@ -102,6 +102,7 @@ SIGNATURES = {
     "cusift_compute_orientations": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _i, _i]),
     "cusift_extract_descriptors": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _f, _i, _i]),
     "cusift_rootsift": (_i, [_vp, _vp, _i]),
+    "cusift_math_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
     "cusift_scale_down_band": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f]),
     "cusift_detect_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i, _vp]),
     "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i]),
@@ -342,6 +343,10 @@ class Context:
                       tex_frac_bits=8):
         check(lib().cusift_describe_band(self.handle, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first,
                                          d_counter, subsampling, tex_frac_bits))
+
+    def math_eval(self, op, d_a, d_b, d_out, d_out2, n):
+        """cusift_math_eval: op 0 expf, 1 exp2f, 2 atan2f(a, b), 3 sincosf -> (out, out2); device pointers."""
+        check(lib().cusift_math_eval(self.handle, op, d_a, d_b, d_out, d_out2, n))
 
     def rootsift(self, d_points, num_pts):
         check(lib().cusift_rootsift(self.handle, d_points, num_pts))

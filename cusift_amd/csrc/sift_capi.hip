@@ -43,6 +43,7 @@ __global__ void homography_solve_kernel(const float *, int, const int *, int, fl
 __global__ void homography_test_kernel(const float *, int, const float *, int, float, int *);
 __global__ void u8_to_f32_kernel(float *, int, long, const unsigned char *, int, int, int, long, int);
 __global__ void gaussian3x3_kernel(float *, int, long, const float *, int, int, int, long, float, float);
+__global__ void math_eval_kernel(int, const float *, const float *, float *, float *, long);
 __global__ void pack_points_kernel(const cusift_point *, const unsigned int *, int, int, cusift_point *, unsigned int,
                                    unsigned int *);
 }  // namespace cusift
@@ -113,6 +114,7 @@ struct cusift_ctx {
   unsigned int *d_counter1 = nullptr;
   unsigned int *d_queue = nullptr;  // kQueueShards work cursors of describe_all_kernel, 128 bytes apart
   int describe_grid = 0;  // resident blocks of describe_all_kernel on this device (occupancy query, cached)
+  unsigned long scratch_gen = 0;  // bumped whenever arena / DoG / matcher scratch is re-allocated (recorded graphs check it)
   // timing
   bool timing = false;
   std::vector<TimedSpan> spans;       // recorded, not yet folded
@@ -219,6 +221,7 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
 int ensure_dog(cusift_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->dog_bytes) return CUSIFT_OK;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->scratch_gen++;
   if (ctx->dog) HIP_TRY(hipFree(ctx->dog));
   ctx->dog = nullptr;
   ctx->dog_bytes = 0;
@@ -231,6 +234,7 @@ int ensure_dog(cusift_ctx *ctx, size_t bytes) {
 int ensure_arena(cusift_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->arena_bytes) return CUSIFT_OK;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->scratch_gen++;
   if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
   ctx->arena = nullptr;
   ctx->arena_bytes = 0;
@@ -328,6 +332,15 @@ void frac_consts(int frac_bits, float &q, float &inv_q) {
     q = 0.0f;
     inv_q = 0.0f;
   }
+}
+
+// Every ctx-taking entry point starts here: a NULL check and the selection of the context's device BEFORE any
+// allocation or launch (a process may hold contexts on several GPUs; the current device is per thread).
+int enter(cusift_ctx *ctx) {
+  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) HIP_TRY(hipSetDevice(ctx->device));
+  return CUSIFT_OK;
 }
 
 int check_launch(const char *what) {
@@ -442,7 +455,7 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
 }
 
 extern "C" int cusift_ctx_synchronize(cusift_ctx *ctx) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSIFT_OK;
 }
@@ -450,7 +463,7 @@ extern "C" int cusift_ctx_synchronize(cusift_ctx *ctx) {
 extern "C" void *cusift_ctx_stream(cusift_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   Plan pl;
   TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p));
   // + one pitched upload image for cusift_extract_host
@@ -460,14 +473,14 @@ extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, c
 extern "C" size_t cusift_ctx_arena_bytes(cusift_ctx *ctx) { return ctx ? ctx->arena_bytes + ctx->dog_bytes : 0; }
 
 extern "C" int cusift_ctx_timing_enable(cusift_ctx *ctx, int on) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!on && ctx->timing) TRY(fold_spans(ctx));
   ctx->timing = on != 0;
   return CUSIFT_OK;
 }
 
 extern "C" int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGES], int launches[CUSIFT_NUM_STAGES]) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   TRY(fold_spans(ctx));
   for (int i = 0; i < CUSIFT_NUM_STAGES; ++i) {
     if (ms) ms[i] = ctx->ms[i];
@@ -477,7 +490,7 @@ extern "C" int cusift_ctx_timing_read(cusift_ctx *ctx, float ms[CUSIFT_NUM_STAGE
 }
 
 extern "C" int cusift_ctx_timing_reset(cusift_ctx *ctx) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   TRY(fold_spans(ctx));
   for (int i = 0; i < CUSIFT_NUM_STAGES; ++i) {
     ctx->ms[i] = 0.f;
@@ -537,12 +550,14 @@ extern "C" int cusift_free_host(void *h_ptr) {
 
 extern "C" int cusift_memset(cusift_ctx *ctx, void *d_ptr, int value, size_t bytes) {
   if (!ctx || !d_ptr) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  TRY(enter(ctx));
   HIP_TRY(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
   return CUSIFT_OK;
 }
 
 extern "C" int cusift_memcpy_h2d(cusift_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
   if (!ctx || !d_dst || !h_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  TRY(enter(ctx));
   HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSIFT_OK;
@@ -550,6 +565,7 @@ extern "C" int cusift_memcpy_h2d(cusift_ctx *ctx, void *d_dst, const void *h_src
 
 extern "C" int cusift_memcpy_d2h(cusift_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
   if (!ctx || !h_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  TRY(enter(ctx));
   HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return CUSIFT_OK;
@@ -557,6 +573,7 @@ extern "C" int cusift_memcpy_d2h(cusift_ctx *ctx, void *h_dst, const void *d_src
 
 extern "C" int cusift_memcpy_d2d(cusift_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
   if (!ctx || !d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  TRY(enter(ctx));
   if (bytes == 0) return CUSIFT_OK;
   HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -565,6 +582,7 @@ extern "C" int cusift_memcpy_d2d(cusift_ctx *ctx, void *d_dst, const void *d_src
 
 extern "C" int cusift_image_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const float *h_src, int w, int h) {
   if (!ctx || !d_dst || !h_src || w < 1 || h < 1 || dst_pitch < w) return fail(CUSIFT_ERR_INVALID, "bad argument");
+  TRY(enter(ctx));
   // cuImage::HostToDevice, cuImage.cu:83-92: dense host rows -> pitched device rows
   HIP_TRY(hipMemcpy2DAsync(d_dst, sizeof(float) * dst_pitch, h_src, sizeof(float) * w, sizeof(float) * w, h,
                            hipMemcpyHostToDevice, ctx->stream));
@@ -574,6 +592,7 @@ extern "C" int cusift_image_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, co
 
 extern "C" int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_src, int src_pitch, int w, int h) {
   if (!ctx || !h_dst || !d_src || w < 1 || h < 1 || src_pitch < w) return fail(CUSIFT_ERR_INVALID, "bad argument");
+  TRY(enter(ctx));
   HIP_TRY(hipMemcpy2DAsync(h_dst, sizeof(float) * w, d_src, sizeof(float) * src_pitch, sizeof(float) * w, h,
                            hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -586,7 +605,7 @@ extern "C" int cusift_image_d2h(cusift_ctx *ctx, float *h_dst, const float *d_sr
 extern "C" int cusift_u8_to_f32(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride,
                                 const unsigned char *d_src, int w, int h, int src_pitch_bytes,
                                 size_t src_stride_bytes, int n_images) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "u8_to_f32: missing data");
   if (n_images < 1 || n_images > 65535 || w < 1 || h < 1 || h > 65535 || dst_pitch < w || src_pitch_bytes < w)
     return fail(CUSIFT_ERR_INVALID, "u8_to_f32: bad geometry");
@@ -601,6 +620,7 @@ extern "C" int cusift_u8_to_f32(cusift_ctx *ctx, float *d_dst, int dst_pitch, si
 extern "C" int cusift_image_u8_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch, const unsigned char *h_src, int w,
                                    int h) {
   if (!ctx || !d_dst || !h_src || w < 1 || h < 1 || dst_pitch < w) return fail(CUSIFT_ERR_INVALID, "bad argument");
+  TRY(enter(ctx));
   const size_t spitch = align_up_sz((size_t)w, 4);
   const size_t bytes = spitch * h;
   if (bytes > ctx->u8_stage_bytes) {
@@ -620,7 +640,7 @@ extern "C" int cusift_image_u8_h2d(cusift_ctx *ctx, float *d_dst, int dst_pitch,
 
 extern "C" int cusift_gaussian3x3(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
                                   int w, int h, int src_pitch, size_t src_stride, int n_images, float sigma) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_dst || !d_src || d_dst == d_src) return fail(CUSIFT_ERR_INVALID, "gaussian3x3: need distinct src and dst");
   if (n_images < 1 || n_images > 65535 || w < 1 || h < 1 || h > 65535 || dst_pitch < w || src_pitch < w ||
       !(sigma > 0.0f))
@@ -641,7 +661,7 @@ extern "C" int cusift_gaussian3x3(cusift_ctx *ctx, float *d_dst, int dst_pitch, 
 static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w,
                            int h, int src_pitch, size_t src_stride, int n_images, float variance, RowWindow src_rw,
                            int dst_row0, int r_begin, int r_end, bool band) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "ScaleDown: missing data");  // cuSIFT.cu:315-318
   if (!(variance > 0.0f)) return fail(CUSIFT_ERR_INVALID, "ScaleDown: variance must be > 0");
   const int ow = w / 2, oh = r_end - r_begin;
@@ -701,7 +721,7 @@ extern "C" int cusift_laplace_taps(float init_blur, float taps[8 * 16]) {
 
 extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
                                     float init_blur, float *d_dog, size_t dog_stride, int n_images) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_img || !d_dog) return fail(CUSIFT_ERR_INVALID, "LaplaceMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w) return fail(CUSIFT_ERR_INVALID, "LaplaceMulti: bad geometry");
   if (n_images > 1 && dog_stride < (size_t)kNumDog * h * pitch)
@@ -746,7 +766,7 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
 extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int w, int h, int pitch,
                                         size_t dog_stride, float peak_thresh, float edge_thresh, float subsampling,
                                         cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_dog || !d_points || !d_counters)
     return fail(CUSIFT_ERR_INVALID, "FindPointsMulti: missing data");  // cuSIFT.cu:425-428
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -782,7 +802,7 @@ static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t 
 static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
                        float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
                        unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
     return fail(CUSIFT_ERR_INVALID, "DetectMulti: bad geometry");
@@ -856,7 +876,7 @@ static int keypoint_grid_x(int max_pts, int n_images) {
 static int orientations_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
                              cusift_point *d_points, int max_pts, const unsigned int *d_first,
                              const unsigned int *d_counters, int tex_frac_bits, int n_images, RowWindow rw) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ComputeOrientations: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
     return fail(CUSIFT_ERR_INVALID, "ComputeOrientations: bad geometry");
@@ -873,7 +893,7 @@ static int descriptors_impl(cusift_ctx *ctx, const float *d_img, int w, int h, i
                             cusift_point *d_points, int max_pts, const unsigned int *d_first,
                             const unsigned int *d_counters, float subsampling, int tex_frac_bits, int n_images,
                             RowWindow rw, int root_sift = 0) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
     return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: bad geometry");
@@ -914,7 +934,7 @@ extern "C" int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, 
 }
 
 extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_points) return fail(CUSIFT_ERR_INVALID, "ConvertSiftToRootSift: missing data");
   if (num_pts <= 0) return CUSIFT_OK;
   dim3 grid(std::min(num_pts, 256 * 32));
@@ -922,12 +942,23 @@ extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_
   return check_launch("rootsift");
 }
 
+extern "C" int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b, float *d_out,
+                                float *d_out2, size_t n) {
+  TRY(enter(ctx));
+  if (op < 0 || op > 3 || !d_a || !d_out || (op == 2 && !d_b) || (op == 3 && !d_out2))
+    return fail(CUSIFT_ERR_INVALID, "math_eval: bad argument");
+  if (n == 0) return CUSIFT_OK;
+  const unsigned int blocks = (unsigned int)std::min<size_t>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(math_eval_kernel, dim3(blocks), dim3(256), 0, ctx->stream, op, d_a, d_b, d_out, d_out2, (long)n);
+  return check_launch("math_eval");
+}
+
 // ------------------------------------------------------------------------------------------------
 // matcher
 // ------------------------------------------------------------------------------------------------
 extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1, const cusift_point *d_sift2,
                             int num_pts2, int distance) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (num_pts1 <= 0 || num_pts2 <= 0) return CUSIFT_OK;  // extras/matching.cu:241-242: nothing to match
   if (!d_sift1 || !d_sift2) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: missing data");
   if (distance != 0 && distance != 1) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: distance must be 0 or 1");
@@ -944,6 +975,7 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
     const size_t bytes = sizeof(MatchPartial) * (size_t)splits * n1_pad;
     if (bytes > ctx->match_scratch_bytes) {
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      ctx->scratch_gen++;
       if (ctx->match_scratch) HIP_TRY(hipFree(ctx->match_scratch));
       ctx->match_scratch = nullptr;
       ctx->match_scratch_bytes = 0;
@@ -967,7 +999,7 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
 extern "C" int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sift, int num_pts, const int *h_rand_pts,
                                       int num_loops, float thresh, float h_homography[9], int *num_matches,
                                       float *h_all_homo, int *h_all_counts) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!h_homography || !num_matches) return fail(CUSIFT_ERR_INVALID, "FindHomography: NULL output");
   static const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // extras/homography.cu:184-187
   memcpy(h_homography, ident, sizeof(ident));
@@ -982,7 +1014,6 @@ extern "C" int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sif
   const size_t homo_b = align_up_sz(sizeof(float) * 8 * (size_t)num_loops, 256);
   const size_t cnt_b = align_up_sz(sizeof(int) * (size_t)num_loops, 256);
   const size_t bytes = coord_b + rand_b + homo_b + cnt_b;
-  HIP_TRY(hipSetDevice(ctx->device));
   if (bytes > ctx->homo_scratch_bytes) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->homo_scratch) HIP_TRY(hipFree(ctx->homo_scratch));
@@ -1026,6 +1057,7 @@ extern "C" int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sif
 extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitch, const void *d_src,
                                    size_t src_pitch, size_t width_bytes, size_t rows) {
   if (!ctx || !h_dst || !d_src) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  TRY(enter(ctx));
   if (rows == 0 || width_bytes == 0) return CUSIFT_OK;
   HIP_TRY(hipMemcpy2DAsync(h_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1035,7 +1067,7 @@ extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitc
 extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
                                   int n_images, int max_pts, cusift_point *d_packed, size_t capacity,
                                   unsigned int *d_offsets) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_points || !d_counters || !d_packed) return fail(CUSIFT_ERR_INVALID, "pack: missing data");
   if (n_images < 1 || n_images > kMaxFlatImages || max_pts < 1)
     return fail(CUSIFT_ERR_INVALID, "pack: n_images must be in [1, %d]", kMaxFlatImages);
@@ -1052,13 +1084,12 @@ extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points,
 extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_images, int w, int h, int pitch,
                                     size_t image_stride, const cusift_params *prm, cusift_point *d_points,
                                     unsigned int *d_counters) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!d_imgs || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "extract: missing data");
   if (n_images > 1 && image_stride < (size_t)h * pitch) return fail(CUSIFT_ERR_INVALID, "image_stride too small");
   Plan pl;
   TRY(make_plan(pl, n_images, w, h, pitch, prm));
   TRY(ensure_arena(ctx, pl.total));
-  HIP_TRY(hipSetDevice(ctx->device));
 
   StageTimer total(ctx, CUSIFT_STAGE_TOTAL);
   // cuSIFT.cu:69: point counter = 0
@@ -1157,8 +1188,8 @@ struct cusift_graph {
   cusift_ctx *ctx = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  size_t arena_bytes = 0;  // the recording refers to the arena as it was: a later growth invalidates it
-  char *arena = nullptr;
+  unsigned long scratch_gen = 0;  // the recording refers to the context's scratch (arena, DoG planes of the
+                                  // two-stage path) as it was: any later re-allocation invalidates it
   int nodes = 0;
 };
 
@@ -1166,6 +1197,7 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
                                    int pitch, size_t image_stride, const cusift_params *prm, cusift_point *d_points,
                                    unsigned int *d_counters) {
   if (!ctx || !out) return fail(CUSIFT_ERR_INVALID, "NULL argument");
+  TRY(enter(ctx));
   *out = nullptr;
   if (!ctx->stream) return fail(CUSIFT_ERR_INVALID, "graph capture needs a real stream (the context borrows the null stream)");
   Plan pl;
@@ -1185,7 +1217,6 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
     ctx->describe_grid = std::max(1, per_cu) * std::max(1, cus);
   }
-  HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const bool timing = ctx->timing;
   ctx->timing = false;  // event records are not part of the recording
@@ -1215,16 +1246,17 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
   size_t n_nodes = 0;
   (void)hipGraphGetNodes(g->graph, nullptr, &n_nodes);
   g->nodes = (int)n_nodes;
-  g->arena = ctx->arena;
-  g->arena_bytes = ctx->arena_bytes;
+  g->scratch_gen = ctx->scratch_gen;
   *out = g;
   return CUSIFT_OK;
 }
 
 extern "C" int cusift_graph_launch(cusift_graph *g) {
   if (!g || !g->exec) return fail(CUSIFT_ERR_INVALID, "graph is NULL");
-  if (g->ctx->arena != g->arena || g->ctx->arena_bytes != g->arena_bytes)
-    return fail(CUSIFT_ERR_INVALID, "the context's arena was re-allocated after this graph was recorded; record it again");
+  if (g->ctx->scratch_gen != g->scratch_gen)
+    return fail(CUSIFT_ERR_INVALID,
+                "the context's scratch (arena / DoG planes) was re-allocated after this graph was recorded; record it again");
+  HIP_TRY(hipSetDevice(g->ctx->device));
   HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
   return CUSIFT_OK;
 }
@@ -1241,7 +1273,7 @@ extern "C" int cusift_graph_destroy(cusift_graph *g) {
 
 extern "C" int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, const cusift_params *prm,
                               cusift_point *d_points, cusift_point *h_points, int *num_pts) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!num_pts) return fail(CUSIFT_ERR_INVALID, "num_pts is NULL");
   *num_pts = 0;
   TRY(cusift_extract_batch(ctx, d_img, 1, w, h, pitch, (size_t)h * pitch, prm, d_points, ctx->d_counter1));
@@ -1260,7 +1292,7 @@ extern "C" int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h,
 
 extern "C" int cusift_extract_host(cusift_ctx *ctx, const float *h_img, int w, int h, const cusift_params *prm,
                                    cusift_point *d_points, cusift_point *h_points, int *num_pts) {
-  if (!ctx) return fail(CUSIFT_ERR_INVALID, "ctx is NULL");
+  TRY(enter(ctx));
   if (!h_img) return fail(CUSIFT_ERR_INVALID, "image is NULL");
   if (w < 1 || h < 1) return fail(CUSIFT_ERR_INVALID, "bad image size %dx%d", w, h);
   const int pitch = ialign_up(w, 128);  // cuImage::AllocateWithHostMemory, cuImage.cu:11-13

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "sift_math.h"  // expf / exp2f / atan2f / sincosf written out: the same bits as the CPU oracle
 #include "sift_types.h"
 
 namespace cusift {

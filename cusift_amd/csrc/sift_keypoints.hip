@@ -2,7 +2,9 @@
 // octaves of a batch, RootSIFT.  One 64-lane wave per keypoint; the pixels a keypoint samples are staged in LDS
 // and the reference's texture fetches are modelled in software (gfx950 has no image unit).
 //
-// Arithmetic follows oracle/sift_oracle.c operation by operation (nothing fused: -ffp-contract=off).
+// Arithmetic follows oracle/sift_oracle.c operation by operation (nothing fused: -ffp-contract=off); expf, atan2f,
+// sincosf are the written-out functions of sift_math.h, which the oracle compiles too -- orientations are therefore
+// bit-identical to the oracle's, descriptors differ only by the summation order of the histogram (~1e-7).
 #include "sift_device.h"
 
 namespace cusift {
@@ -233,7 +235,7 @@ __device__ __forceinline__ float tree_sum64(float x) {
 template <typename SH, typename TEX>
 __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
-  if (tx < 11) S.gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
+  if (tx < 11) S.gauss[tx] = sm_expf(i2sigma2 * (tx - 5) * (tx - 5));
   const float xp = kx - 5.0f;
   const float yp = ky - 5.0f;
   // Lattice shortcut.  The 484 taps of a keypoint sit at kx + n/2, ky + m/2 (n, m integers, |n|,|m| <= 13).  Let
@@ -296,7 +298,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
         dx = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
         dy = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
       }
-      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
+      int bin = (int)(16.0f * sm_atan2f(dy, dx) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
       if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
       const float grad = sqrtf(dx * dx + dy * dy);
       S.sample[t] = make_float2(__int_as_float(bin), grad * S.gauss[xd] * S.gauss[yd]);
@@ -380,11 +382,11 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
   // sample idx = lane + 64*step -> column tx = lane%16, row y = lane/16 + 4*step
   DescLaneConsts c;
   c.tx1 = lane & 15;
-  c.gx1 = expf(-(c.tx1 - 7.5f) * (c.tx1 - 7.5f) / 128.0f);
+  c.gx1 = sm_expf(-(c.tx1 - 7.5f) * (c.tx1 - 7.5f) / 128.0f);
 #pragma unroll
   for (int step = 0; step < 4; ++step) {
     const int y = (lane >> 4) + 4 * step;
-    c.gy1[step] = expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
+    c.gy1[step] = sm_expf(-(y - 7.5f) * (y - 7.5f) / 128.0f);
   }
   return c;
 }
@@ -418,7 +420,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   float *myhist = S.hist8() + lane * 9;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
   float sina, cosa;
-  sincosf(theta, &sina, &cosa);  // OCML: one argument reduction, the same polynomials as sinf() and cosf()
+  sm_sincosf(theta, &sina, &cosa);  // sift_math.h
   const float scale = 12.0f / 16.0f * kp_scale;
   const float ssina = scale * sina;
   const float scosa = scale * cosa;
@@ -435,7 +437,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     const float dy = tex(xpos - sina, ypos + cosa) - tex(xpos + sina, ypos - cosa);
     const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
     S.grad[idx] = grad;
-    S.angraw[idx] = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;
+    S.angraw[idx] = 4.0f / 3.1415f * sm_atan2f(dy, dx) + 4.0f;
   }
   wave_sync();
   // the patch is dead from here on: its storage becomes the histogram buffers
@@ -617,8 +619,7 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
     const float px = uniform(pt->coords2D[0]), py = uniform(pt->coords2D[1]);
     const float kscale = uniform(pt->scale), ori = uniform(pt->orientation);
     // every tap is within `reach` of the keypoint: 7.5*spacing*(|cos|+|sin|) for the grid + 1 for the tap
-    const float theta = 2.0f * 3.1415f / 360.0f * ori;
-    const float reach = 7.5f * (12.0f / 16.0f * kscale) * (fabsf(cosf(theta)) + fabsf(sinf(theta))) + 1.0f + 0.01f;
+    const float reach = 7.5f * (12.0f / 16.0f * kscale) * 1.41422f + 1.0f + 0.01f;  // |cos| + |sin| <= sqrt 2
     PatchGeom g;
     int pw, ph;
     const bool use_patch = patch_for_reach(px, py, reach, g, pw, ph);
@@ -789,6 +790,27 @@ __global__ void __launch_bounds__(64) pack_points_kernel(const cusift_point *__r
     for (int k = 0; k < (kDwords + 63) / 64; ++k) {
       const int e = lane + 64 * k;
       if (e < kDwords) dst[e] = src[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The written-out transcendental functions of sift_math.h evaluated on the device, array form (cusift_math_eval):
+// lets a test compare the device's results with the host's bit for bit.  op 0 expf(a), 1 exp2f(a), 2 atan2f(a, b),
+// 3 sincosf(a) -> (out, out2).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) math_eval_kernel(int op, const float *__restrict__ a,
+                                                       const float *__restrict__ b, float *__restrict__ out,
+                                                       float *__restrict__ out2, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (op == 0) out[i] = sm_expf(a[i]);
+    else if (op == 1) out[i] = sm_exp2f(a[i]);
+    else if (op == 2) out[i] = sm_atan2f(a[i], b[i]);
+    else {
+      float s, c;
+      sm_sincosf(a[i], &s, &c);
+      out[i] = s;
+      out2[i] = c;
     }
   }
 }

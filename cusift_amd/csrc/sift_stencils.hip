@@ -10,7 +10,8 @@
 //  * Keypoint kernels (orientation, descriptor) run one wave per keypoint on a persistent grid that
 //    reads the point count from device memory -- no host read-back between stages.
 //  * Arithmetic follows oracle/sift_oracle.c operation by operation (explicit fmaf chains in the
-//    filters, nothing else fused: this file is built with -ffp-contract=off).
+//    filters, nothing else fused: this file is built with -ffp-contract=off); transcendental functions are
+//    the written-out ones of sift_math.h, which the oracle compiles too.
 #include "sift_device.h"
 
 namespace cusift {
@@ -413,7 +414,7 @@ __device__ __forceinline__ void refine_and_append(const float *__restrict__ dog,
   cusift_point *pt = pts + idx;
   pt->coords2D[0] = (float)x + pdx;
   pt->coords2D[1] = (float)y + pdy;
-  pt->scale = P.scales[s] * exp2f(pds * P.factor);
+  pt->scale = P.scales[s] * sm_exp2f(pds * P.factor);
   pt->sharpness = val + dval;
   pt->edgeness = edge;
   pt->subsampling = P.subsampling;
@@ -747,7 +748,7 @@ __device__ __forceinline__ void refine_from_cube(const float *cube, int col, int
   cusift_point *pt = pts + idx;
   pt->coords2D[0] = (float)x + pdx;
   pt->coords2D[1] = (float)y + pdy;
-  pt->scale = P.scales[s] * exp2f(pds * P.factor);
+  pt->scale = P.scales[s] * sm_exp2f(pds * P.factor);
   pt->sharpness = val + dval;
   pt->edgeness = edge;
   pt->subsampling = P.subsampling;

@@ -184,6 +184,14 @@ int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h
 /* SiftData::ConvertSiftToRootSift, cuSIFT.cu:383-395 + cuSIFT_D.cu:299-317. */
 int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts);
 
+/* The device build of the five transcendental functions the kernels use in place of CUDA's libm (expf, exp2f,
+ * atan2f, sinf/cosf: cuSIFT_D.cu:209-210,233,330,349,507), array form: op 0 expf(a), 1 exp2f(a), 2 atan2f(a, b),
+ * 3 sincosf(a) -> (out, out2).  They are written out in IEEE operations (cusift_amd/csrc/sift_math.h) so that a host
+ * build of the same header gives the same bits; this entry point exists so that callers and tests can verify that
+ * on their device.  Asynchronous. */
+int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b, float *d_out, float *d_out2,
+                     size_t n);
+
 /* ---- band ("tile") forms: one large image strip-tiled over several GPUs (BASELINE configs[4]) -- */
 /* A band is `h` rows of device memory whose local row 0 is row `row0` of a global image with `h_global` rows
  * (same width).  Row addressing is "clamp to the global image, then translate", so a band that carries enough

@@ -8,8 +8,8 @@
  * sums (ScaleDown, LaplaceMulti) are therefore restated as "first product, then a left-to-right
  * fmaf chain"; everything else is evaluated operation by operation with no contraction
  * (compile with -ffp-contract=off).  The same convention is used by the HIP kernels so that
- * the filter stages are bit-identical between oracle and device; the remaining differences
- * come from libm (expf/atan2f/sinf/cosf/exp2f: glibc here, OCML on the device).
+ * the filter stages are bit-identical between oracle and device; the device code's transcendental
+ * functions are shared with the kernels as well (sift_math.h, below).
  *
  * Build-time switch ORACLE_NO_FMA evaluates the filter sums without fusion (used once to
  * check the convention against the golden file).
@@ -19,6 +19,46 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* The transcendental functions of the DEVICE code (expf, exp2f, atan2f, sinf, cosf in cuSIFT_D.cu).  CUDA's libm is
+ * not available; glibc's and the GPU's (OCML) differ from it and from each other in the last bits, and a last bit
+ * occasionally decides a texture-fraction step or a histogram bin.  So one written-out evaluation of each function
+ * (cusift_amd/csrc/sift_math.h: IEEE operations in a fixed order) is compiled into this oracle AND into the HIP
+ * kernels; what remains between the two is then only the descriptor's summation order.  -DORACLE_LIBM builds the
+ * same restatement on glibc's functions instead (libsift_oracle_libm.so): tests/test_oracle_golden.py pins BOTH
+ * builds to the reference's golden file with the same gates, and tests/test_math.py bounds the written-out functions
+ * against float64 -- that is what keeps this oracle tied to the reference rather than to the product.
+ * The HOST-side tap tables (cuSIFT.cu:331,406: expf/powf in host code) use the host libm, as the reference did. */
+#include "../cusift_amd/csrc/sift_math.h"
+#ifdef ORACLE_LIBM
+#define dev_expf expf
+#define dev_exp2f exp2f
+#define dev_atan2f atan2f
+static inline void dev_sincosf(float x, float *s, float *c) {
+  *s = sinf(x);
+  *c = cosf(x);
+}
+#else
+#define dev_expf sm_expf
+#define dev_exp2f sm_exp2f
+#define dev_atan2f sm_atan2f
+#define dev_sincosf sm_sincosf
+#endif
+
+/* the written-out functions, exported for tests/test_math.py (accuracy) and the device bit-identity test */
+float oracle_math_expf(float x) { return sm_expf(x); }
+float oracle_math_exp2f(float x) { return sm_exp2f(x); }
+float oracle_math_atan2f(float y, float x) { return sm_atan2f(y, x); }
+void oracle_math_sincosf(float x, float *s, float *c) { sm_sincosf(x, s, c); }
+/* array form: op 0 expf(a), 1 exp2f(a), 2 atan2f(a, b), 3 sincosf(a) -> (out, out2) */
+void oracle_math_eval(int op, const float *a, const float *b, float *out, float *out2, int n) {
+  for (int i = 0; i < n; i++) {
+    if (op == 0) out[i] = sm_expf(a[i]);
+    else if (op == 1) out[i] = sm_exp2f(a[i]);
+    else if (op == 2) out[i] = sm_atan2f(a[i], b[i]);
+    else sm_sincosf(a[i], out + i, out2 + i);
+  }
+}
 
 #define NUM_SCALES 5 /* cuSIFT_D.h:8  */
 #define LAPLACE_S 8  /* cuSIFT_D.h:23 (NUM_SCALES + 3) */
@@ -255,7 +295,7 @@ void oracle_find_points_multi(const float *dog, int w, int h, int pitch, float p
         oracle_sift_point *pt = points + idx;
         pt->coords2D[0] = x + pdx;
         pt->coords2D[1] = y + pdy;
-        pt->scale = scales[s] * exp2f(pds * factor);
+        pt->scale = scales[s] * dev_exp2f(pds * factor);
         pt->sharpness = val + dval;
         pt->edgeness = edge;
         pt->subsampling = subsampling;
@@ -309,7 +349,7 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
     float hist_hi[32];
     float gauss[11];
     float i2sigma2 = -1.0f / (4.5f * pt->scale * pt->scale);
-    for (int tx = 0; tx < 11; tx++) gauss[tx] = expf(i2sigma2 * (tx - 5) * (tx - 5));
+    for (int tx = 0; tx < 11; tx++) gauss[tx] = dev_expf(i2sigma2 * (tx - 5) * (tx - 5));
     for (int i = 0; i < 64; i++) hist[i] = 0.0f;
     for (int i = 0; i < 32; i++) hist_hi[i] = 0.0f;
     float xp = pt->coords2D[0] - 5.0f;
@@ -323,7 +363,7 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
                  oracle_tex2d(img, w, h, pitch, xf - 1.0f, yf, frac_bits);
       float dy = oracle_tex2d(img, w, h, pitch, xf, yf + 1.0f, frac_bits) -
                  oracle_tex2d(img, w, h, pitch, xf, yf - 1.0f, frac_bits);
-      int bin = (int)(16.0f * atan2f(dy, dx) / 3.1416f + 16.5f);
+      int bin = (int)(16.0f * dev_atan2f(dy, dx) / 3.1416f + 16.5f);
       if (bin > 31 || bin < 0) bin = 0; /* < 0 only for non-finite input (memory safety) */
       float grad = sqrtf(dx * dx + dy * dy);
       /* reference: LDS float atomicAdd in arbitrary order.  This restatement (and the HIP kernel) fixes one:
@@ -381,14 +421,14 @@ static inline void desc_add(float *buffer, int idx, float v) {
 void oracle_extract_descriptors(const float *img, int w, int h, int pitch, oracle_sift_point *points, int first,
                                 int last, float subsampling, int frac_bits) {
   float gauss[16];
-  for (int tx = 0; tx < 16; tx++) gauss[tx] = expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
+  for (int tx = 0; tx < 16; tx++) gauss[tx] = dev_expf(-(tx - 7.5f) * (tx - 7.5f) / 128.0f);
   for (int bx = first; bx < last; bx++) {
     oracle_sift_point *pt = points + bx;
     float buffer[128];
     for (int i = 0; i < 128; i++) buffer[i] = 0.0f;
     float theta = 2.0f * 3.1415f / 360.0f * pt->orientation;
-    float sina = sinf(theta);
-    float cosa = cosf(theta);
+    float sina, cosa;
+    dev_sincosf(theta, &sina, &cosa);
     float scale = 12.0f / 16.0f * pt->scale;
     float ssina = scale * sina;
     float scosa = scale * cosa;
@@ -401,7 +441,7 @@ void oracle_extract_descriptors(const float *img, int w, int h, int pitch, oracl
         float dy = oracle_tex2d(img, w, h, pitch, xpos - sina, ypos + cosa, frac_bits) -
                    oracle_tex2d(img, w, h, pitch, xpos + sina, ypos - cosa, frac_bits);
         float grad = gauss[y] * gauss[tx] * sqrtf(dx * dx + dy * dy);
-        float angf = 4.0f / 3.1415f * atan2f(dy, dx) + 4.0f;
+        float angf = 4.0f / 3.1415f * dev_atan2f(dy, dx) + 4.0f;
 
         int hori = (tx + 2) / 4 - 1;
         float horf = (tx - 1.5f) / 4.0f - hori;

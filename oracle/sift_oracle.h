@@ -110,6 +110,14 @@ void oracle_gaussian3x3(const float *src, int w, int h, int src_pitch, float *ds
 /* Software model of tex2D<float>(x, y) with cudaFilterModeLinear / clamp / unnormalised coords. */
 float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, int frac_bits);
 
+/* The written-out transcendental functions shared with the HIP kernels (cusift_amd/csrc/sift_math.h), exported so
+ * that tests can bound them against float64 (tests/test_math.py) and compare the device's results bit for bit. */
+float oracle_math_expf(float x);
+float oracle_math_exp2f(float x);
+float oracle_math_atan2f(float y, float x);
+void oracle_math_sincosf(float x, float *s, float *c);
+void oracle_math_eval(int op, const float *a, const float *b, float *out, float *out2, int n);
+
 #ifdef __cplusplus
 }
 #endif

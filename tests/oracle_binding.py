@@ -49,9 +49,13 @@ class OracleParams(C.Structure):
 
 def build_oracle():
     """Compile the oracle if the shared objects are missing or stale (needs gcc)."""
-    src = os.path.join(ORACLE_DIR, "sift_oracle.c")
     so = os.path.join(ORACLE_DIR, "libsift_oracle.so")
-    if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    deps = [os.path.join(ORACLE_DIR, "sift_oracle.c"), os.path.join(ORACLE_DIR, "sift_oracle.h"),
+            os.path.join(ROOT, "cusift_amd", "csrc", "sift_math.h")]
+    sos = [so, os.path.join(ORACLE_DIR, "libsift_oracle_libm.so"), os.path.join(ORACLE_DIR, "libsift_oracle_nofma.so")]
+    stale = any(not os.path.exists(x) for x in sos) or any(
+        os.path.exists(d) and os.path.getmtime(d) > min(os.path.getmtime(x) for x in sos) for d in deps)
+    if stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
     return so
 
@@ -190,6 +194,18 @@ class Oracle:
         best = self.lib.oracle_find_homography(points.ctypes.data, len(points), rand_pts.ctypes.data, loops, thresh,
                                                hom.ctypes.data, C.byref(n), all_h.ctypes.data, all_c.ctypes.data)
         return hom, n.value, best, all_h, all_c
+
+    def math_eval(self, op, a, b=None):
+        """The written-out transcendental functions shared with the kernels (cusift_amd/csrc/sift_math.h), array form:
+        op 'exp' | 'exp2' | 'atan2' (a = y, b = x) | 'sincos' (returns (sin, cos))."""
+        code = {"exp": 0, "exp2": 1, "atan2": 2, "sincos": 3}[op]
+        a = _f32(a).ravel()
+        b = _f32(b).ravel() if b is not None else a
+        out, out2 = np.zeros_like(a), np.zeros_like(a)
+        self.lib.oracle_math_eval.argtypes = [C.c_int, _vp, _vp, _vp, _vp, C.c_int]
+        self.lib.oracle_math_eval.restype = None
+        self.lib.oracle_math_eval(code, a.ctypes.data, b.ctypes.data, out.ctypes.data, out2.ctypes.data, a.size)
+        return (out, out2) if op == "sincos" else out
 
     def tex2d(self, img, w, h, x, y, frac_bits=8):
         img = _f32(img)

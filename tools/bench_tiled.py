@@ -13,6 +13,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the first HIP call: ROCr reads it at hsa_init
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -37,7 +39,6 @@ def main():
     out = {"workload": "single %dx%d image, 5 octaves, initBlur=1.0, thresh=3.0" % (W, H)}
 
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
         rows = H // world
         strip = torch.from_numpy(img[rank * rows:(rank + 1) * rows]).to(dev)
