@@ -175,8 +175,6 @@ struct Plan {
   // arena offsets in bytes
   size_t base_off[kMaxOctaves];  // octave >= 1 base images (n * h*p floats each); [0] unused
   size_t first_off = 0, total = 0;
-  size_t dog_bytes = 0;   // size of the separate DoG buffer if the two-stage path is taken
-  size_t dog_stride = 0;  // floats per image
 };
 
 int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm) {
@@ -210,8 +208,6 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
     pl.base_off[o] = off;
     off = align_up_sz(off + (size_t)n_images * pl.h[o] * pl.p[o] * sizeof(float), 256);
   }
-  pl.dog_stride = (size_t)kNumDog * pl.h[0] * pl.p[0];
-  pl.dog_bytes = (size_t)n_images * pl.dog_stride * sizeof(float);
   pl.first_off = off;
   off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
   pl.total = off;
@@ -669,12 +665,12 @@ static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t 
     return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
   ScaleDownTaps T;
   scale_down_taps(T, variance);
-  const bool fast = (w % 4 == 0) && w >= 4 && (src_pitch % 4 == 0) && (((uintptr_t)d_src % 16) == 0) &&
+  const bool fast = w >= 4 && (src_pitch % 4 == 0) && (((uintptr_t)d_src % 16) == 0) &&
                     (src_stride % 4 == 0) && (dst_pitch % 2 == 0) && (((uintptr_t)d_dst % 8) == 0) &&
                     (dst_stride % 2 == 0) && ((size_t)h * src_pitch * sizeof(float) < (1ull << 31)) &&
                     (band || !getenv("CUSIFT_FORCE_GENERIC"));
   if (band && !fast)
-    return fail(CUSIFT_ERR_INVALID, "ScaleDown (band): needs w %% 4 == 0, 16-byte aligned source rows, band < 2 GiB");
+    return fail(CUSIFT_ERR_INVALID, "ScaleDown (band): needs w >= 4, 16-byte aligned source rows, band < 2 GiB");
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
   if (fast) {
     const int strips = idiv_up(ow, 124);  // kDownStrip
@@ -740,8 +736,8 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
   rows_bounds("LAPLACE", rlo, rhi);
   const int rows = pick_rows(h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
-  // fast path: aligned float4 rows, whole lanes inside/outside the image, 32-bit buffer offsets
-  const bool fast = vec_ok && (w % 4 == 0) && w >= 4 && ((size_t)h * pitch * sizeof(float) < (1ull << 31)) &&
+  // fast path: 16-byte aligned rows (any width >= 4), 32-bit buffer offsets
+  const bool fast = vec_ok && w >= 4 && ((size_t)h * pitch * sizeof(float) < (1ull << 31)) &&
                     !getenv("CUSIFT_FORCE_GENERIC");
   StageTimer t(ctx, CUSIFT_STAGE_LAPLACE);
   if (fast) {
@@ -780,7 +776,7 @@ extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int
   rows_bounds("FINDPOINTS", rlo, rhi);
   const int rows = pick_rows(h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
-  const bool fast = vec_ok && (w % 2 == 0) && w >= 2 &&
+  const bool fast = vec_ok && w >= 2 &&
                     ((size_t)kNumDog * h * pitch * sizeof(float) < (1ull << 31)) && !getenv("CUSIFT_FORCE_GENERIC");
   StageTimer t(ctx, CUSIFT_STAGE_FINDPOINTS);
   if (fast) {
@@ -795,8 +791,8 @@ extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int
 }
 
 static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t img_stride) {
-  return (pitch % 4 == 0) && (((uintptr_t)d_img % 16) == 0) && (img_stride % 4 == 0) && (w % 4 == 0) && w >= 4 &&
-         h >= 3 && ((size_t)h * pitch * sizeof(float) < (1ull << 31));
+  return (pitch % 4 == 0) && (((uintptr_t)d_img % 16) == 0) && (img_stride % 4 == 0) && w >= 4 && h >= 3 &&
+         ((size_t)h * pitch * sizeof(float) < (1ull << 31));
 }
 
 static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
@@ -807,7 +803,7 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
     return fail(CUSIFT_ERR_INVALID, "DetectMulti: bad geometry");
   if (!detect_fused_ok(d_img, w, h, pitch, img_stride))
-    return fail(CUSIFT_ERR_INVALID, "DetectMulti: needs 16-byte aligned rows, w %% 4 == 0, h >= 3, image < 2 GiB");
+    return fail(CUSIFT_ERR_INVALID, "DetectMulti: needs 16-byte aligned rows (pitch %% 4 == 0), w >= 4, h >= 3, image < 2 GiB");
   float taps[8 * 16];
   laplace_taps_table(init_blur, taps);
   LaplaceTapsPk TP;
@@ -1081,6 +1077,22 @@ extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points,
 // ------------------------------------------------------------------------------------------------
 // drivers
 // ------------------------------------------------------------------------------------------------
+// Bytes of DoG planes the two-stage path needs: the largest searched octave that does not take the fused detection
+// (0 when every octave does).  `arena_base`: where octaves >= 1 live (their alignment is what matters).
+static size_t two_stage_dog_bytes(const Plan &pl, const cusift_params *prm, const float *d_imgs, size_t image_stride,
+                                  const char *arena_base, int n_images) {
+  size_t need = 0;
+  const bool generic = getenv("CUSIFT_FORCE_GENERIC") != nullptr;
+  for (int o = 0; o < pl.n_oct; ++o) {
+    if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;
+    const float *b = o == 0 ? d_imgs : (const float *)(arena_base + pl.base_off[o]);
+    const size_t st = o == 0 ? image_stride : (size_t)pl.h[o] * pl.p[o];
+    if (!prm->fused_detect || generic || !detect_fused_ok(b, pl.w[o], pl.h[o], pl.p[o], st))
+      need = std::max(need, (size_t)n_images * kNumDog * pl.h[o] * pl.p[o] * sizeof(float));
+  }
+  return need;
+}
+
 extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_images, int w, int h, int pitch,
                                     size_t image_stride, const cusift_params *prm, cusift_point *d_points,
                                     unsigned int *d_counters) {
@@ -1090,6 +1102,8 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   Plan pl;
   TRY(make_plan(pl, n_images, w, h, pitch, prm));
   TRY(ensure_arena(ctx, pl.total));
+  if (const size_t dog_need = two_stage_dog_bytes(pl, prm, d_imgs, image_stride, ctx->arena, n_images))
+    TRY(ensure_dog(ctx, dog_need));  // sized once for the largest two-stage octave, before anything is enqueued
 
   StageTimer total(ctx, CUSIFT_STAGE_TOTAL);
   // cuSIFT.cu:69: point counter = 0
@@ -1109,43 +1123,38 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   }
   unsigned int *first = (unsigned int *)(ctx->arena + pl.first_off);
   // With fused_detect the keypoint stages run once, after the last octave's detection, over the flattened list
-  // of all keypoints of the batch (describe_all_kernel); otherwise per octave like the reference.
-  bool all_fused = prm->fused_detect && n_images <= kMaxFlatImages && !getenv("CUSIFT_FORCE_GENERIC");
-  for (int o = 0; o < pl.n_oct && all_fused; ++o)
-    if ((prm->lowest_scale < pl.sub[o] * 2.0f) && !detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o]))
-      all_fused = false;
+  // of all keypoints of the batch (describe_all_kernel); otherwise per octave like the reference.  The DETECTION
+  // kernel is chosen per octave: the fused one wherever it applies (16-byte aligned rows, w >= 4, h >= 3), the
+  // two-stage pair for an octave where it does not (a 2x1 coarsest octave, a caller's odd pitch) -- one such octave
+  // no longer demotes the others.
+  const bool generic = getenv("CUSIFT_FORCE_GENERIC") != nullptr;
+  const bool flat = prm->fused_detect && n_images <= kMaxFlatImages && !generic;
   // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
   for (int o = pl.n_oct - 1; o >= 0; --o) {
     if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
     // ExtractSiftOctave, cuSIFT.cu:204-270
-    if (all_fused) {
-      TRY(cusift_detect_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o],
-                              prm->peak_thresh, prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters,
-                              n_images));
-      continue;
-    }
-    const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
     unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
-    HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
-    if (prm->fused_detect && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o]) &&
-        !getenv("CUSIFT_FORCE_GENERIC")) {
+    if (!flat)
+      HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
+    if (prm->fused_detect && !generic && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o])) {
       TRY(cusift_detect_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o],
                               prm->peak_thresh, prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters,
                               n_images));
     } else {
-      TRY(ensure_dog(ctx, pl.dog_bytes));
+      const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
       float *dog = ctx->dog;
       TRY(cusift_laplace_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], dog, dstride,
                                n_images));
       TRY(cusift_find_points_multi(ctx, dog, pl.w[o], pl.h[o], pl.p[o], dstride, prm->peak_thresh, prm->edge_thresh,
                                    pl.sub[o], d_points, prm->max_pts, d_counters, n_images));
     }
+    if (flat) continue;
     TRY(cusift_compute_orientations(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
                                     d_counters, prm->tex_frac_bits, n_images));
     TRY(descriptors_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst, d_counters,
                          pl.sub[o], prm->tex_frac_bits, n_images, RowWindow{0, pl.h[o]}, prm->root_sift));
   }
-  if (all_fused) {
+  if (flat) {
     OctaveTable T;
     memset(&T, 0, sizeof(T));
     T.n_oct = pl.n_oct;
@@ -1204,13 +1213,9 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
   TRY(make_plan(pl, n_images, w, h, pitch, prm));
   // everything that allocates or synchronises happens before the capture starts
   TRY(ensure_arena(ctx, pl.total));
-  bool need_dog = !prm->fused_detect || getenv("CUSIFT_FORCE_GENERIC");
-  for (int o = 0; o < pl.n_oct && !need_dog; ++o) {
-    const float *b = o == 0 ? d_imgs : (const float *)(ctx->arena + pl.base_off[o]);
-    const size_t st = o == 0 ? image_stride : (size_t)pl.h[o] * pl.p[o];
-    if (!detect_fused_ok(b, pl.w[o], pl.h[o], pl.p[o], st)) need_dog = true;
-  }
-  if (need_dog) TRY(ensure_dog(ctx, pl.dog_bytes));  // the two-stage path's DoG planes
+  // the DoG planes of every octave that takes the two-stage path (see cusift_extract_batch), sized up front
+  const size_t dog_need = two_stage_dog_bytes(pl, prm, d_imgs, image_stride, ctx->arena, n_images);
+  if (dog_need) TRY(ensure_dog(ctx, dog_need));
   if (ctx->describe_grid == 0) {
     int per_cu = 0, cus = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, describe_all_kernel, 64, 0));

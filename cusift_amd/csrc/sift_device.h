@@ -37,6 +37,49 @@ __device__ __forceinline__ float from_next_lane(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
+// Right/left image border for lanes that own GROUPS of 4 (or 2) adjacent columns of a 16-byte (8-byte) aligned row,
+// for ANY width w >= 4 (>= 2): the lane's vector load is clamped to the last column group that starts inside the
+// image -- always aligned and inside the pitch, because pitch % 4 == 0 (% 2) -- and the components that lie outside
+// the image are overwritten with the border column: clamp addressing, exactly what the reference's texture unit and
+// the generic kernels' per-column clampi() do (cuSIFT_D.cu:534-548).  Lanes whose group lies inside the image are
+// untouched; the masks are loop-invariant per lane.
+struct EdgeFix4 {
+  int voff;    // byte offset of the lane's float4 inside a row, clamped into the image
+  int src;     // component that holds the border column for this lane
+  bool m0, m1, m2, m3;  // component j is replaced by the border column
+  __device__ __forceinline__ EdgeFix4(int c0, int w) {
+    const int cA = (w - 1) & ~3;  // first column of the last, possibly partial, group
+    const bool left = c0 < 0;
+    voff = clampi(c0, 0, cA) * 4;
+    src = left ? 0 : ((w - 1) & 3);
+    m0 = left || c0 + 0 > w - 1;
+    m1 = left || c0 + 1 > w - 1;
+    m2 = left || c0 + 2 > w - 1;
+    m3 = left || c0 + 3 > w - 1;
+  }
+  __device__ __forceinline__ f4 operator()(f4 v) const {
+    const float s = src == 0 ? v.x : (src == 1 ? v.y : (src == 2 ? v.z : v.w));
+    return f4{m0 ? s : v.x, m1 ? s : v.y, m2 ? s : v.z, m3 ? s : v.w};
+  }
+};
+struct EdgeFix2 {
+  int voff;
+  int src;
+  bool m0, m1;
+  __device__ __forceinline__ EdgeFix2(int c0, int w) {
+    const int cA = (w - 1) & ~1;
+    const bool left = c0 < 0;
+    voff = clampi(c0, 0, cA) * 4;
+    src = left ? 0 : ((w - 1) & 1);
+    m0 = left || c0 + 0 > w - 1;
+    m1 = left || c0 + 1 > w - 1;
+  }
+  __device__ __forceinline__ f2 operator()(f2 v) const {
+    const float s = src == 0 ? v.x : v.y;
+    return f2{m0 ? s : v.x, m1 ? s : v.y};
+  }
+};
+
 // XCD-aware work mapping.  Hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each
 // with its own L2), so spatially adjacent tiles would land on different L2s and fetch their shared
 // halo lines twice.  Remapping id -> (id % 8) * (total / 8) + id / 8 gives every XCD a contiguous

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// LaplaceMulti, fast path (16-byte aligned buffers, w % 4 == 0, image and DoG block < 4 GiB).
+// LaplaceMulti, fast path (16-byte aligned rows: pitch % 4 == 0, any w >= 4, image and DoG plane < 2 GiB).
 // Same strip geometry and the same arithmetic as laplace_multi_kernel above, restructured for the
 // CDNA4 VALU and memory pipes:
 //  * packed fp32 (v_pk_fma_f32 / v_pk_add_f32) across SCALE PAIRS: a register pair holds levels
@@ -199,20 +199,18 @@ __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__
   dog += (long)bz * dog_stride;
 
   const int c0 = bx * kBlurStrip - kBlurHaloLanes * kBlurCols + lane * kBlurCols;
-  const bool left = c0 < 0, right = c0 >= w;  // w % 4 == 0: a lane is entirely inside or entirely outside
-  const int voff_in = clampi(c0, 0, w - 4) * 4;
+  const EdgeFix4 edge(c0, w);  // any w >= 4: border groups are clamped + replicated (sift_device.h)
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((unsigned int)h * (unsigned int)pitch * 4u), kBufFlags);
-  const int voff_out = (lane >= kBlurHaloLanes && lane < 64 - kBlurHaloLanes) ? c0 * 4 : kOobOffset;  // c0 >= w is dropped by num_records
+  // columns >= w are dropped by num_records = w*4: dwordx4 stores are range-checked per component, so the last
+  // group of a ragged width (w % 4 != 0) stores exactly its valid columns and the pad columns stay untouched
+  const int voff_out = (lane >= kBlurHaloLanes && lane < 64 - kBlurHaloLanes) ? c0 * 4 : kOobOffset;
   const long plane = (long)h * pitch;
 
   auto load_row = [&](int y) -> f4 {
     const int yc = clampi(y, 0, h - 1);
-    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, yc * pitch * 4, 0);
-    f4 v = __builtin_bit_cast(f4, raw);
-    if (left) v = f4{v.x, v.x, v.x, v.x};
-    if (right) v = f4{v.w, v.w, v.w, v.w};
-    return v;
+    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, edge.voff, yc * pitch * 4, 0);
+    return edge(__builtin_bit_cast(f4, raw));
   };
 
   f4 win[9];
@@ -281,7 +279,7 @@ __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__
 }
 
 // ------------------------------------------------------------------------------------------------
-// ScaleDown, fast path (16-byte aligned source rows, w % 4 == 0, 8-byte aligned destination rows).
+// ScaleDown, fast path (16-byte aligned source rows, any w >= 4, 8-byte aligned destination rows).
 // Same arithmetic as scale_down_kernel.  A lane loads source columns 4l..4l+3 as one float4 (1 KiB per wave
 // row), takes columns 4l-2, 4l-1 and 4l+4 from its neighbours by DPP and produces two output columns
 // (one float2 store); the five horizontally filtered rows 2r-1..2r+3 slide through registers.
@@ -310,20 +308,17 @@ __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict_
   dst += (long)bz * dst_stride;
 
   const int cs = strip * (2 * kDownStrip) - 4 + lane * 4;  // first source column of this lane's float4
-  const bool left = cs < 0, right = cs >= w;
-  const int voff_in = clampi(cs, 0, w - 4) * 4;
+  const EdgeFix4 edge(cs, w);  // any w >= 4: source columns beyond the image replicate column w-1 (clamp addressing)
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
       (void *)src, 0, (int)((unsigned int)h * (unsigned int)src_pitch * 4u), kBufFlags);
   const int o0 = cs >> 1;  // first output column (even)
-  const int voff_out = (lane >= 1 && lane <= 62 && cs >= 0) ? o0 * 4 : kOobOffset;  // o0 >= ow dropped by num_records
+  // output columns >= ow are dropped by num_records = ow*4, per component (odd ow: the pair's first column only)
+  const int voff_out = (lane >= 1 && lane <= 62 && cs >= 0) ? o0 * 4 : kOobOffset;
   const float k0 = T.k[0], k1 = T.k[1], k2 = T.k[2];
 
   auto load_row = [&](int y) -> f4 {
-    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, local_row(y, h, src_rw) * src_pitch * 4, 0);
-    f4 v = __builtin_bit_cast(f4, raw);
-    if (left) v = f4{v.x, v.x, v.x, v.x};
-    if (right) v = f4{v.w, v.w, v.w, v.w};
-    return v;
+    const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rin, edge.voff, local_row(y, h, src_rw) * src_pitch * 4, 0);
+    return edge(__builtin_bit_cast(f4, raw));
   };
   // horizontal 5-tap of one source row for output columns o0 (centre 4l) and o0+1 (centre 4l+2)
   auto hrow = [&](const f4 v) -> f2 {
@@ -523,7 +518,7 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // ------------------------------------------------------------------------------------------------
-// FindPointsMulti, fast path (8-byte aligned DoG block < 4 GiB, w % 2 == 0): the same test and the
+// FindPointsMulti, fast path (8-byte aligned DoG rows: pitch % 2 == 0, any w >= 2, block < 2 GiB): the same test and the
 // same refinement as find_points_kernel, with buffer_load_dwordx2 on a wave-uniform row base, the next
 // row of all 7 planes requested one iteration ahead, and v_min3/v_max3 trees.
 // ------------------------------------------------------------------------------------------------
@@ -546,8 +541,7 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
   unsigned int *counter = counters + bz;
 
   const int c0 = strip * kFindStrip - kFindCols + lane * kFindCols;
-  const bool left = c0 < 0, right = c0 >= w;
-  const int voff = clampi(c0, 0, w - 2) * 4;
+  const EdgeFix2 edge(c0, w);  // any w >= 2
   const long plane = (long)h * pitch;
   const int plane_bytes = (int)((unsigned int)h * (unsigned int)pitch * 4u);
   const __amdgpu_buffer_rsrc_t rin =
@@ -557,11 +551,8 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
     const int row_off = clampi(y, 0, h - 1) * pitch * 4;
 #pragma unroll
     for (int p = 0; p < kNumDog; ++p) {
-      const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(rin, voff, p * plane_bytes + row_off, 0);
-      f2 v = __builtin_bit_cast(f2, raw);
-      if (left) v = f2{v.x, v.x};
-      if (right) v = f2{v.y, v.y};
-      o[p] = v;
+      const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(rin, edge.voff, p * plane_bytes + row_off, 0);
+      o[p] = edge(__builtin_bit_cast(f2, raw));
     }
   };
 
@@ -777,8 +768,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
   float *cube = s_cube + wv * (9 * kCubeCols);
 
   const int c0 = bx * kDetStrip - kDetHaloLanes * kBlurCols + lane * kBlurCols;
-  const bool left = c0 < 0, right = c0 >= w;
-  const int voff_in = clampi(c0, 0, w - 4) * 4;
+  const EdgeFix4 edge(c0, w);  // any w >= 4
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((unsigned int)h * (unsigned int)pitch * 4u), kBufFlags);
   const bool lane_valid = lane >= kDetHaloLanes && lane < 64 - kDetHaloLanes;
@@ -788,13 +778,9 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
   // load sits there too (as one function the compiler fixed the row up, and waited, one row step after the issue).
   auto load_raw = [&](int y) -> f4 {
     const int yc = clampi(y, 0, h - 1);
-    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, voff_in, yc * pitch * 4, 0));
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, edge.voff, yc * pitch * 4, 0));
   };
-  auto fix = [&](f4 v) -> f4 {
-    if (left) v = f4{v.x, v.x, v.x, v.x};
-    if (right) v = f4{v.w, v.w, v.w, v.w};
-    return v;
-  };
+  auto fix = [&](f4 v) -> f4 { return edge(v); };
 
   f4 win[9];
 #pragma unroll

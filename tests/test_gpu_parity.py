@@ -249,7 +249,11 @@ def test_find_points_overflow_is_dropped_not_written(ctx, oracle, gray1):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("w,h,blur,thresh", [(640, 480, 0.0, 0.1), (320, 240, 0.559017, 0.1), (244, 37, 0.0, 0.5),
                                              (1920, 1080, 1.0, 3.0), (8, 5, 0.0, 0.01), (4, 3, 0.0, 0.01),
-                                             (480, 9, 0.3, 0.2)])
+                                             (480, 9, 0.3, 0.2),
+                                             # ragged widths (w % 4 != 0): the last column group is partial
+                                             (1366, 768, 0.0, 1.0), (249, 37, 0.0, 0.5), (30, 16, 0.0, 0.2),
+                                             (15, 8, 0.0, 0.05), (6, 5, 0.0, 0.01), (5, 3, 0.0, 0.01),
+                                             (1001, 75, 0.5, 0.5), (243, 9, 0.0, 0.2), (241, 12, 0.0, 0.2)])
 def test_detect_multi_same_set_as_oracle(ctx, oracle, gray1, w, h, blur, thresh):
     if (w, h) == (640, 480):
         img = gray1
@@ -277,6 +281,47 @@ def test_detect_multi_same_set_as_oracle(ctx, oracle, gray1, w, h, blur, thresh)
     np.testing.assert_array_equal(a["sharpness"], b["sharpness"])
     np.testing.assert_array_equal(a["edgeness"], b["edgeness"])
     np.testing.assert_array_equal(a["scale"], b["scale"])
+
+
+def test_generic_kernels_on_unaligned_pitch(ctx, oracle):
+    """A caller-owned cuImage may have any pitch (cuImage.cu:16).  Rows that are not 16-byte aligned take the generic
+    kernels (per-column clamps, scalar loads): ScaleDown, LaplaceMulti, FindPointsMulti bit-exact there too."""
+    w, h, p = 77, 45, 79
+    img = rand_image(h, w, 23)
+    src = np.zeros((h, p), dtype=np.float32)
+    src[:, :w] = img
+    d_src = DeviceBuffer.from_numpy(ctx, src)
+    # ScaleDown into an odd-pitched destination
+    ow, oh, op = w // 2, h // 2, 39
+    d_dst = DeviceBuffer(ctx, oh * op * 4)
+    d_dst.zero()
+    ctx.scale_down(d_dst.ptr, op, d_src.ptr, w, h, p)
+    np.testing.assert_array_equal(d_dst.to_numpy(np.float32, (oh, op))[:, :ow], oracle.scale_down(src, w, h)[:oh, :ow])
+    # LaplaceMulti + FindPointsMulti on the odd pitch
+    want_dog = oracle.laplace_multi(src, w, h, 0.0)
+    d_dog = DeviceBuffer(ctx, 7 * h * p * 4)
+    d_dog.zero()
+    ctx.laplace_multi(d_src.ptr, w, h, p, 0.0, d_dog.ptr)
+    np.testing.assert_array_equal(d_dog.to_numpy(np.float32, (7, h, p))[:, :, :w], want_dog[:, :, :w])
+    want, n_want = oracle.find_points_multi(want_dog, w, h, 0.5, 10.0, 1.0, 4096)
+    got, n_got = run_find_points(ctx, want_dog, w, h, 0.5, 10.0, 1.0, 4096)
+    assert n_got == n_want > 20
+    a, b = canonical_order(want[:n_want]), canonical_order(got[:n_got])
+    for f in ("coords2D", "scale", "sharpness", "edgeness"):
+        np.testing.assert_array_equal(a[f], b[f])
+    # the driver on such an image: every octave >= 1 lives in the arena (aligned) and takes the fused kernel, octave 0
+    # (odd pitch) the two-stage pair -- one ragged octave does not demote the others
+    kw = dict(num_octaves=3, init_blur=0.0, peak_thresh=1.0, max_pts=4096)
+    prm = capi.default_params(**kw)
+    d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
+    h_pts = np.zeros(prm.max_pts, dtype=SIFT_POINT_DTYPE)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    n = ctx.extract(d_src.ptr, w, h, p, prm, d_pts.ptr, h_pts)
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    assert t["detect_multi"][1] == 2 and t["laplace_multi"][1] == 1 and t["describe_all"][1] == 1
+    compare_sets(oracle.extract(img, **kw), h_pts[:n])
 
 
 def test_detect_multi_rejects_what_it_cannot_do(ctx):
@@ -540,6 +585,30 @@ def test_extract_large_image_matches_oracle(ctx, oracle):
     got = gpu_extract(ctx, img, **kw)
     assert len(want) > 10000
     compare_sets(want, got)
+
+
+@pytest.mark.parametrize("w,h,n_oct,blur,thresh", [(1366, 768, 5, 0.0, 2.0), (1000, 750, 5, 1.0, 3.0),
+                                                    (1920, 1080, 7, 1.0, 3.0), (1027, 301, 6, 0.5, 2.0)])
+def test_extract_ragged_widths_match_oracle(ctx, oracle, w, h, n_oct, blur, thresh):
+    """Widths whose octaves are not multiples of 4 (1366 -> 683 -> 341 ...; 1000 -> 250 -> 125; 1080p x 7 octaves ->
+    w = 30, 15) run the same fast kernels -- the partial last column group is clamped and replicated in registers --
+    and every octave takes the fused detection (no demotion of the batch to the generic path)."""
+    img = synth.tile(300 + w, w, h, preblur=blur)
+    kw = dict(num_octaves=n_oct, init_blur=blur, peak_thresh=thresh, edge_thresh=10.0, max_pts=65536)
+    want = oracle.extract(img, **kw)
+    assert len(want) > 500
+    prm = capi.default_params(**kw)
+    d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
+    h_pts = np.zeros(prm.max_pts, dtype=SIFT_POINT_DTYPE)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    n = ctx.extract_host(img, prm, d_pts.ptr, h_pts)
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    if not os.environ.get("CUSIFT_FORCE_GENERIC"):
+        assert t["detect_multi"][1] == n_oct and t["laplace_multi"][1] == 0 and t["describe_all"][1] == 1, t
+    compare_sets(want, h_pts[:n])
+    d_pts.free()
 
 
 def test_extract_device_image_and_odd_size(ctx, oracle):
