@@ -9,15 +9,25 @@ Workload (BASELINE.json configs[2]/[3]): a batch of 64 synthetic 1920x1080 8-bit
 (seeded `tile` images pre-blurred to sigma 1.0), 5 octaves, initBlur=1.0, thresh=3.0, edge=10.
 One "step" = one pass of the whole hot path over that batch: ScaleDown pyramid, 8 blurs + 7 DoG per
 octave, extrema + refinement, orientation, 128-D descriptors -- SiftData left in HBM; with N>1 ranks the
-step ends with the RCCL all-gatherv of SiftData so every rank holds all N*64 images' keypoints.
+step ends with the RCCL all-gatherv of SiftData (C ABI: cusift_allgatherv_*, ncclAllGather of the counts + one
+ncclGroup of ncclSend/ncclRecv) so every rank holds all N*64 images' keypoints.
 Inputs are resident in HBM before the timed region.  Weak scaling: 64 images per GPU at every N.
 Consecutive steps alternate over --streams HIP streams (default 2, one extractor each), so that the HBM-bound
 ScaleDown chain and the launch tails of one batch overlap the VALU-bound kernels of the next; every step is still
 one complete pass over one batch, and the timed region is bracketed by device-wide synchronisation.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description), with two extra
-objects: `roofline` (blur+DoG kernel: algorithmic bytes / HIP-event duration vs 8 TB/s) and
-`cpu_baseline` (the CPU oracle timed on this box's host cores over a bounded sample).
+Prints ONE JSON line on rank 0 (see the driver contract in the task description).  `value` comes from the timed
+region only.  Everything else on the line is measured in separate, labelled legs after it (same inputs unless the
+leg says otherwise), `--legs` selects them:
+  single     the same steps on ONE stream with HIP events per launch: per-stage ms (kernel spans do not overlap)
+  two_stage  the reference's LaplaceMulti -> DoG in HBM -> FindPointsMulti pipeline: `roofline` (blur+DoG kernel,
+             algorithmic bytes / HIP-event time vs 8 TB/s, the north-star gate)
+  host       SiftData made host-visible: packed records copied to pinned memory on a copy stream, overlapped with
+             the next step (`keypoints_per_s_host_visible`; SURVEY.md section 8d's end-to-end definition)
+  content    the same pipeline on other image content (`blobs`, un-pre-blurred `tile`): keypoints/step and the
+             fraction of octave-0 wave-rows the threshold pre-test skips -- how much of the rate is the images
+  ragged     64 x 1366x768 (no octave width is a multiple of 4): per-pixel rate next to 1080p's
+  cpu        `cpu_baseline`: the CPU oracle on this box's host cores over a bounded sample; OpenCV if importable
 """
 import argparse
 import json
@@ -35,7 +45,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+FP32_VALU_PEAK_TF = 157.3  # ibid. "Peak FP32 (vector)": 256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz
+ALL_LEGS = ("single", "two_stage", "host", "content", "ragged", "cpu")
 
 
 def octave_dims(w, h, n_oct):
@@ -57,15 +69,7 @@ def algorithmic_bytes(w, h, n_oct, n_img):
     return blur, down, find
 
 
-def cpu_baseline(w, h, params_kw, preblur, budget_s):
-    """The CPU oracle (a restatement of the cuSIFT algorithm -- NOT OpenCV, which this image lacks) timed on
-    the host cores: one image per thread (the C code releases the GIL), bounded to ~budget_s of wall time."""
-    import threading
-
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from cusift_amd import synth
-    from oracle_binding import Oracle  # checker / baseline only
-
+def usable_cpus():
     cores = os.cpu_count() or 1
     # the CPUs this process may actually use: the cgroup quota if there is one (a GPU box hands a 16-CPU share of its
     # 256 hardware threads to a job), else the affinity mask
@@ -76,6 +80,19 @@ def cpu_baseline(w, h, params_kw, preblur, budget_s):
             usable = max(1, min(usable, int(round(int(quota) / int(period)))))
     except (OSError, ValueError):
         pass
+    return cores, usable
+
+
+def cpu_baseline(w, h, params_kw, preblur, budget_s):
+    """The CPU oracle (a restatement of the cuSIFT algorithm -- NOT OpenCV) timed on the host cores: one image per
+    thread (the C code releases the GIL), bounded to ~budget_s of wall time."""
+    import threading
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cusift_amd import synth
+    from oracle_binding import Oracle  # checker / baseline only
+
+    cores, usable = usable_cpus()
     # measured on the box (16-CPU quota): 8 / 16 / 24 / 32 / 64 threads -> 102 / 184 / 197 / 189 / 163 Mpix/s
     threads = int(os.environ.get("CUSIFT_CPU_THREADS", "0")) or max(1, min(cores, usable + usable // 2, 48))
     oracle = Oracle()
@@ -100,7 +117,7 @@ def cpu_baseline(w, h, params_kw, preblur, budget_s):
         t.join()
     dt = time.perf_counter() - t0
     n_img = sum(done)
-    return {
+    out = {
         "value": round(n_img * w * h / dt / 1e6, 3),
         "unit": "Mpix/s",
         "cores": threads,
@@ -111,6 +128,41 @@ def cpu_baseline(w, h, params_kw, preblur, budget_s):
         "host_cores": cores,
         "usable_cpus": usable,
     }
+    out["opencv"] = opencv_baseline(imgs[: min(len(imgs), 8)], usable, min(budget_s, 8.0))
+    return out
+
+
+def opencv_baseline(imgs, threads, budget_s):
+    """north_star asks for OpenCV's CPU SIFT beside the number (the reference's callers decode with OpenCV,
+    test/detector.cpp:19-20).  It is not in this image; if a box has it, it is timed on the same images."""
+    try:
+        import cv2  # noqa: F401
+    except Exception as e:  # ImportError, or a broken binary wheel
+        return {"available": False, "note": "opencv: absent (import cv2: %s)" % type(e).__name__}
+    try:
+        cv2.setNumThreads(int(threads))
+        sift = cv2.SIFT_create(0, 3, 0.04, 10, 1.6)
+        u8 = [np.clip(i, 0, 255).astype(np.uint8) for i in imgs]
+        sift.detectAndCompute(u8[0], None)
+        n, kp, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            k, _ = sift.detectAndCompute(u8[n % len(u8)], None)
+            kp += len(k)
+            n += 1
+        dt = time.perf_counter() - t0
+        h, w = u8[0].shape
+        return {"available": True, "version": cv2.__version__, "threads": int(threads),
+                "Mpix_per_s": round(n * w * h / dt / 1e6, 3), "keypoints_per_s": round(kp / dt, 1),
+                "note": "cv2.SIFT_create(0,3,0.04,10,1.6).detectAndCompute on the same images (8-bit)"}
+    except Exception as e:
+        return {"available": False, "note": "opencv: present but SIFT failed (%s)" % e}
+
+
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
 
 
 def main():
@@ -126,26 +178,33 @@ def main():
     ap.add_argument("--thresh", type=float, default=3.0)
     ap.add_argument("--max-pts", type=int, default=32768)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-stage-timers", action="store_true", help="do not bracket stages with HIP events")
-    ap.add_argument("--gather", choices=["p2p", "padded"], default="p2p")
+    ap.add_argument("--legs", default=",".join(ALL_LEGS),
+                    help="comma-separated extra legs after the timed region (%s); 'none' = only the timed region"
+                         % ", ".join(ALL_LEGS))
     ap.add_argument("--two-stage", action="store_true",
                     help="time the reference's two-stage pipeline (DoG planes in HBM) instead of the fused detection")
-    ap.add_argument("--no-two-stage", action="store_true", help="skip the roofline exhibit leg")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps alternate over (one extractor each): the HBM-bound ScaleDown chain and "
                          "the launch tails of one batch overlap the VALU-bound kernels of the next")
-    ap.add_argument("--gather-depth", type=int, default=1,
-                    help="N > 1: the all-gatherv of step i is issued after step i + depth has been enqueued")
+    ap.add_argument("--gather-capacity", type=int, default=8192,
+                    help="N > 1: records per image the gathered SiftData buffer is sized for")
     ap.add_argument("--force-gather", action="store_true",
-                    help="run the all-gatherv of SiftData even with one rank (exercises the RCCL path on one GPU)")
+                    help="run the all-gatherv of SiftData even with one rank (self send/recv: exercises the RCCL path "
+                         "on one GPU)")
     args = ap.parse_args()
+    legs = set() if args.legs in ("none", "") else set(x for x in args.legs.split(",") if x)
+    unknown = legs - set(ALL_LEGS)
+    if unknown:
+        raise SystemExit("unknown legs: %s" % sorted(unknown))
+    if args.cpu_seconds <= 0:
+        legs.discard("cpu")
 
     import torch
     import torch.distributed as dist
 
     from cusift_amd import capi, synth
-    from cusift_amd.batch import BatchExtractor
-    from cusift_amd.dist import begin_allgather, finish_allgather
+    from cusift_amd.batch import BatchExtractor, PipelinedExtractor
+    from cusift_amd.dist import SiftGatherer, make_comm
 
     # Rank 0 prints exactly ONE line on stdout.  Libraries write there too (RCCL prints a version banner on
     # communicator creation), so from here on file descriptor 1 points at stderr and the JSON line goes to a
@@ -166,9 +225,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_gather
-    if use_dist:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # torch.distributed carries the communicator's 128-byte id, the barrier and the max-over-ranks of the time;
+        # the SiftData exchange itself is the C ABI's (RCCL called from libcusift_amd.so)
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     w, h, B = args.width, args.height, args.batch
@@ -176,12 +237,8 @@ def main():
                   lowest_scale=0.0, subsampling=1.0, max_pts=args.max_pts, tex_frac_bits=8)
     # One extractor (context + arena + output slots) per stream; step i runs on stream i % E.  A step is still one
     # whole pass of the hot path over one batch -- consecutive steps merely overlap on the device.
-    from cusift_amd.batch import PipelinedExtractor
-
     E = max(1, args.streams)
-    # output slots per extractor: a slot is overwritten E * n_slots steps later, and the gather of step i (which
-    # reads it) is issued -- and its packing waited for -- right after step i + gather_depth has been enqueued
-    n_slots = max(2, args.gather_depth // E + 2) if use_dist else 1
+    n_slots = 2 if use_dist else 1  # a slot is read by the gather of its step while the next steps are extracted
     pipe = PipelinedExtractor(B, w, h, n_streams=E, n_slots=n_slots,
                               fused_detect=0 if args.two_stage else 1, **prm_kw)
     exs = pipe.extractors
@@ -190,26 +247,30 @@ def main():
     # ---- synthetic inputs, resident in HBM before anything is timed ----
     from concurrent.futures import ThreadPoolExecutor
 
-    seeds = [1000 + rank * B + i for i in range(B)]
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        host = list(pool.map(lambda s: synth.tile(s, w, h, args.init_blur), seeds))
-    d_imgs = ex.images_from_numpy(np.stack(host))
-    del host
+    def make_images(fn, seeds):
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            return np.stack(list(pool.map(fn, seeds)))
 
-    # N > 1: the all-gatherv of step i runs on a side stream while step i+1 is extracted on the main stream
-    # (two output slots); its one host read-back (the counts) then waits only for the side stream.
+    seeds = [1000 + rank * B + i for i in range(B)]
+    d_imgs = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, args.init_blur), seeds))
+
+    # N > 1: the all-gatherv of step i runs on a side stream (its own context + communicator) while step i+1 is
+    # extracted; its one host read (the counts) happens one step later, when they have long arrived
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream() if use_dist else None
-    packer = ex.make_packer(side_stream) if use_dist else None
+    gatherer = None
+    if use_dist:
+        side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
+        comm = make_comm(side_ctx, self_p2p=(world == 1))
+        gatherer = SiftGatherer(comm, B, args.max_pts, capacity=world * B * args.gather_capacity, device=dev, n_out=2)
     pending = []
     state = {"gathered": None}
-
     slot_free = {}  # (stream index, slot) -> event after which the slot's last gather no longer reads it
 
     def finish_one():
-        ticket, key = pending.pop(0)
+        key = pending.pop(0)
         with torch.cuda.stream(side_stream):
-            state["gathered"] = finish_allgather(ticket, method=args.gather, packer=packer)
+            state["gathered"] = gatherer.finish()
             done = torch.cuda.Event()
             done.record(side_stream)
         slot_free[key] = done
@@ -218,14 +279,14 @@ def main():
         key = (pipe.submitted % E, (pipe.submitted // E) % pipe.n_slots)
         pts, cnt, ev = pipe.submit(d_imgs, ready=slot_free.pop(key, None))
         if use_dist:
-            # phase 1 of the all-gatherv right away (counts exchange + async copy to pinned memory, no host wait);
-            # phase 2 (pack + shard exchange) once `gather_depth` further steps have been enqueued, by which time
-            # the counts have long arrived
+            # the previous step's exchange is completed first (its counts arrived while this step was being enqueued),
+            # then this step's counts exchange is started
+            if pending:
+                finish_one()
             with torch.cuda.stream(side_stream):
                 side_stream.wait_event(ev)
-                pending.append((begin_allgather(pts, cnt, ex.max_pts, n_images_max=B), key))
-            if len(pending) > args.gather_depth:
-                finish_one()
+                gatherer.begin(pts, cnt)
+            pending.append(key)
 
     def drain():
         while pending:
@@ -237,15 +298,16 @@ def main():
 
     def fence():
         drain()
-        if use_dist:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    timers = bool(legs)
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
-    if not args.no_stage_timers:
+    if timers:
         for x in exs:
             x.ctx.timing_enable(True)
             x.ctx.timing_reset()
@@ -255,66 +317,32 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     gathered = state["gathered"]
-    stage = None
-    if not args.no_stage_timers:
+    stage_overlapped = None
+    if timers:
         for x in exs:  # kernel spans of all streams (with E > 1 they overlap in time: their sum exceeds the wall time)
             t = x.ctx.timing_read()
-            stage = t if stage is None else {k: (stage[k][0] + t[k][0], stage[k][1] + t[k][1]) for k in t}
+            stage_overlapped = t if stage_overlapped is None else {
+                k: (stage_overlapped[k][0] + t[k][0], stage_overlapped[k][1] + t[k][1]) for k in t}
             x.ctx.timing_enable(False)
-
-    # ---- single-stream leg (not part of `value`): with E > 1 the kernel spans of the timed region overlap in time,
-    # so the per-stage table and the pyramid rate come from the same steps run on ONE stream
-    stage_overlapped = None
-    single_stream_ms = None
-    if E > 1 and not args.no_stage_timers:
-        stage_overlapped = stage
-        ex.ctx.timing_enable(True)
-        ex.ctx.timing_reset()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ex.extract(d_imgs)
-        torch.cuda.synchronize()
-        single_stream_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        stage = ex.ctx.timing_read()
-        ex.ctx.timing_enable(False)
-
-    # ---- roofline exhibit leg (not part of `value`): the same steps through the reference's two-stage pipeline
-    # (LaplaceMulti -> DoG planes in HBM -> FindPointsMulti), to time the blur+DoG kernel the north star names.
-    stage2 = None
-    if not args.no_stage_timers and not args.no_two_stage and ex.params.fused_detect:
-        ex.params.fused_detect = 0
-        for _ in range(2):
-            ex.extract(d_imgs)
-        fence()
-        ex.ctx.timing_enable(True)
-        ex.ctx.timing_reset()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            ex.extract(d_imgs)
-        torch.cuda.synchronize()
-        two_stage_elapsed = time.perf_counter() - t2
-        stage2 = ex.ctx.timing_read()
-        ex.ctx.timing_enable(False)
-        ex.params.fused_detect = 1
-        fence()
 
     # max over ranks
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
+    if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-
     counts = ex.valid_counts()
     local_kp = int(counts.sum().item())
     kp = torch.tensor([local_kp], dtype=torch.int64, device=dev)
-    if use_dist:
+    if world > 1:
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
-        total_gathered = int(gathered[2][-1])  # noqa
-        assert total_gathered == int(kp.item()), (total_gathered, int(kp.item()))
     total_kp = int(kp.item())
+    if use_dist:
+        total_gathered = int(gathered[2][-1])
+        assert total_gathered == total_kp, (total_gathered, total_kp)
 
+    K = args.steps
+    out = None
     if rank == 0:
-        K = args.steps
         ms_per_step = elapsed / K * 1e3
         total_pix = world * B * w * h
         out = {
@@ -333,102 +361,296 @@ def main():
             "config": {
                 "workload": "batch of %d x %dx%d images per GPU (BASELINE configs[2]; x%d GPUs = configs[3] shape), "
                             "%d octaves, initBlur=%.1f, thresh=%.1f, edge=10, maxPts=%d; full SIFT extraction "
-                            "(pyramid+DoG, extrema, orientation, 128-D descriptor)%s"
+                            "(pyramid+DoG, extrema, orientation, 128-D descriptor), SiftData left in HBM%s"
                             % (B, w, h, world, args.octaves, args.init_blur, args.thresh, args.max_pts,
-                               "; + all-gatherv of SiftData (%s)" % args.gather if use_dist else ""),
+                               "; + all-gatherv of SiftData (C ABI over RCCL: counts all-gather + grouped send/recv)"
+                               if use_dist else ""),
                 "images_per_gpu": B,
                 "parallelism": "image-sharded x%d" % world,
                 "streams_per_gpu": E,
+                "pipeline": "two-stage (DoG in HBM)" if args.two_stage else "fused detection (DoG on chip)",
             },
-            "keypoints_per_s": round(total_kp / (elapsed / K), 1),
+            "keypoints_per_s_in_hbm": round(total_kp / (elapsed / K), 1),
             "keypoints_per_step": total_kp,
         }
-        blur_b, down_b, find_b = algorithmic_bytes(w, h, args.octaves, B)
-        out["config"]["pipeline"] = "two-stage (DoG in HBM)" if args.two_stage else "fused detection (DoG on chip)"
+        if use_dist:
+            out["config"]["rccl_library"] = capi.Comm.library()
 
-        def traffic_of(kernel):
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            try:
-                return json.load(open(tpath))[kernel]["hbm_bytes_per_launch"]
-            except Exception:
-                return None
+    # ================================================================================================================
+    # Extra legs (rank 0's GPU only; not part of `value`).  With N > 1 the other ranks wait at the final barrier.
+    # ================================================================================================================
+    blur_b, down_b, find_b = algorithmic_bytes(w, h, args.octaves, B)
+    traffic = load_profile_json("traffic.json")
+    valu = load_profile_json("valu.json")
 
-        def blur_roofline(st, note):
-            lap_ms, lap_n = st["laplace_multi"]
-            if lap_n == 0 or lap_ms <= 0:
-                return None
-            # per launch: mean algorithmic bytes / mean HIP-event duration over the launches (5 octaves x K steps)
-            achieved = (blur_b * K / lap_n) / (lap_ms * 1e-3 / lap_n) / 1e9
-            return {
-                "kernel": "laplace_multi_fast_kernel (8 blurs + 7 DoG planes, 32 B/px algorithmic)",
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic_of("laplace_multi_fast_kernel"),
-                "algorithmic_bytes_per_launch": int(blur_b * K / lap_n),
-                "avg_launch_ms": round(lap_ms / lap_n, 5),
-                "launches": lap_n,
-                "note": note,
-            }
-
-        def stage_table(st):
-            return {k: round(st[k][0] / K, 4) for k in ("scale_down", "detect_multi", "describe_all", "laplace_multi",
+    def stage_table(st, steps):
+        return {k: round(st[k][0] / steps, 4) for k in ("scale_down", "detect_multi", "describe_all", "laplace_multi",
                                                          "find_points_multi", "compute_orientations",
                                                          "extract_descriptors", "total")}
 
-        if stage is not None:
-            out["stage_ms_per_step"] = stage_table(stage)
-            if stage_overlapped is not None:
-                out["single_stream_leg"] = {
-                    "ms_per_step": round(single_stream_ms, 4),
-                    "note": "the timed region alternates steps over %d streams; stage_ms_per_step, fused_detect and "
-                            "pyramid_mpix_per_s are measured on the same steps run on one stream (HIP events per "
-                            "launch), where kernel spans do not overlap" % E,
-                    "timed_region_kernel_spans_ms_per_step": stage_table(stage_overlapped)}
+    def run_single_stream(extractor, imgs, steps, warm=2):
+        """`steps` extractions on one stream with per-launch HIP events; returns (ms per step, stage dict)."""
+        for _ in range(warm):
+            extractor.extract(imgs)
+        torch.cuda.synchronize()
+        extractor.ctx.timing_enable(True)
+        extractor.ctx.timing_reset()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            extractor.extract(imgs)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / steps * 1e3
+        st = extractor.ctx.timing_read()
+        extractor.ctx.timing_enable(False)
+        return ms, st
+
+    if rank == 0 and legs:
+        torch.cuda.synchronize()
+        if stage_overlapped is not None and E > 1:
+            out["timed_region_kernel_spans_ms_per_step"] = stage_table(stage_overlapped, K)
+
+        # ---- single-stream leg: per-stage table, VALU rooflines of the two kernels that own the step ----
+        stage = None
+        if "single" in legs:
+            single_ms, stage = run_single_stream(ex, d_imgs, K)
+            out["stage_ms_per_step"] = stage_table(stage, K)
+            out["single_stream_leg"] = {
+                "ms_per_step": round(single_ms, 4),
+                "note": "the timed region alternates steps over %d streams; stage_ms_per_step, the VALU rooflines and "
+                        "pyramid_mpix_per_s are measured on the same steps run on one stream (HIP events per launch), "
+                        "where kernel spans do not overlap" % E}
             sd_ms = stage["scale_down"][0]
-            if stage["detect_multi"][1] > 0:
-                det_ms, det_n = stage["detect_multi"]
-                model_b = blur_b + find_b  # what the two reference stages move: 32 + 28 B/px
-                ach = (model_b * K / det_n) / (det_ms * 1e-3 / det_n) / 1e9
-                out["fused_detect"] = {
-                    "kernel": "detect_fused_kernel (LaplaceMulti+FindPointsMulti, DoG planes kept in registers)",
-                    "avg_launch_ms": round(det_ms / det_n, 5), "launches": det_n,
-                    "model_bytes_per_launch": int(model_b * K / det_n),
-                    "model_GBps": round(ach, 1), "model_frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic_of("detect_fused_kernel"),
-                    "note": "VALU-bound: the 60 B/px of the two-stage model are not moved (source image only); "
-                            "model_GBps can exceed the HBM peak by construction",
-                }
+            det_ms, det_n = stage["detect_multi"]
+            if det_n > 0:
                 out["pyramid_mpix_per_s"] = round(B * w * h / ((sd_ms + det_ms) / K * 1e-3) / 1e6, 1)
-                rl = blur_roofline(stage2, "measured in the two-stage leg of this run (same inputs, HIP events on the "
-                                           "launching stream); the timed region itself uses the fused kernel") if stage2 else None
-                if rl:
-                    out["roofline"] = rl
-                    out["two_stage_leg"] = {"ms_per_step": round(two_stage_elapsed / K * 1e3, 4),
-                                            "stage_ms_per_step": stage_table(stage2),
-                                            "find_points_GBps": round(find_b / (stage2["find_points_multi"][0] / K * 1e-3) / 1e9, 1)}
-            else:
-                rl = blur_roofline(stage, "measured over the timed region")
-                if rl:
-                    out["roofline"] = rl
-                lap_ms, fp_ms = stage["laplace_multi"][0], stage["find_points_multi"][0]
-                out["pyramid_mpix_per_s"] = round(B * w * h / ((sd_ms + lap_ms) / K * 1e-3) / 1e6, 1)
-                out["find_points_GBps"] = round(find_b / (fp_ms / K * 1e-3) / 1e9, 1) if fp_ms > 0 else None
             out["scale_down_GBps"] = round(down_b / (sd_ms / K * 1e-3) / 1e9, 1) if sd_ms > 0 else None
-        if world == 1 and args.cpu_seconds > 0:
-            cpu_kw = dict(prm_kw)
-            out["cpu_baseline"] = cpu_baseline(w, h, cpu_kw, args.init_blur, args.cpu_seconds)
+
+            def valu_roofline(kernel, stage_key, note):
+                ms, n = stage[stage_key]
+                info = valu.get(kernel)
+                if n == 0 or ms <= 0 or not info:
+                    return None
+                # FMA-equivalent flop: every VALU lane-operation priced as one FMA (2 flop) -- the pricing of the
+                # 157.3 TFLOP/s peak (32 lanes x 2 flop per SIMD-clock), so frac = vector issue slots used
+                insts_per_step = info["valu_wave_insts_per_launch"] * (n / K)
+                ach = insts_per_step * 64 * 2 / (ms / K * 1e-3) / 1e12
+                return {"kernel": kernel, "bound": "valu", "achieved": round(ach, 2), "peak": FP32_VALU_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_VALU_PEAK_TF, 4),
+                        "valu_wave_insts_per_step": int(insts_per_step), "launches_per_step": n // K,
+                        "ms_per_step": round(ms / K, 4),
+                        "valu_busy_pmc": info.get("valu_busy"),
+                        "hbm_traffic_bytes_per_launch": traffic.get(kernel, {}).get("hbm_bytes_per_launch"),
+                        "note": note}
+
+            rk = []
+            r = valu_roofline("detect_fused_kernel", "detect_multi",
+                              "achieved = PMC SQ_INSTS_VALU (profiles/valu.json, same command) x 64 lanes x 2 flop / "
+                              "HIP-event time of this run; valu_busy_pmc = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x "
+                              "GRBM_GUI_ACTIVE / 8)")
+            if r:
+                rk.append(r)
+            r = valu_roofline("describe_all_kernel", "describe_all", "as above; %d keypoints per step"
+                              % local_kp)
+            if r:
+                r["valu_wave_insts_per_keypoint"] = round(r["valu_wave_insts_per_step"] / max(1, local_kp), 1)
+                rk.append(r)
+            if rk:
+                out["roofline_kernels"] = rk
+
+        # ---- two-stage leg: the blur+DoG kernel the north star names ----
+        if "two_stage" in legs and ex.params.fused_detect:
+            ex.params.fused_detect = 0
+            two_ms, stage2 = run_single_stream(ex, d_imgs, K)
+            ex.params.fused_detect = 1
+            lap_ms, lap_n = stage2["laplace_multi"]
+            if lap_n > 0 and lap_ms > 0:
+                # per launch: mean algorithmic bytes / mean HIP-event duration over the launches (5 octaves x K steps)
+                achieved = (blur_b * K / lap_n) / (lap_ms * 1e-3 / lap_n) / 1e9
+                out["roofline"] = {
+                    "kernel": "laplace_multi_fast_kernel (8 blurs + 7 DoG planes, 32 B/px algorithmic)",
+                    "bound": "hbm",
+                    "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get("laplace_multi_fast_kernel", {}).get("hbm_bytes_per_launch"),
+                    "algorithmic_bytes_per_launch": int(blur_b * K / lap_n),
+                    "avg_launch_ms": round(lap_ms / lap_n, 5),
+                    "launches": lap_n,
+                    "note": "measured in the two-stage leg of this run (same inputs, HIP events on the launching "
+                            "stream); the timed region itself uses the fused kernel, whose roofline is VALU "
+                            "(roofline_kernels)",
+                }
+            fp_ms = stage2["find_points_multi"][0]
+            out["two_stage_leg"] = {"ms_per_step": round(two_ms, 4), "stage_ms_per_step": stage_table(stage2, K),
+                                    "find_points_GBps": round(find_b / (fp_ms / K * 1e-3) / 1e9, 1) if fp_ms > 0 else None,
+                                    "find_points_traffic_bytes_per_launch":
+                                        traffic.get("find_points_fast_kernel", {}).get("hbm_bytes_per_launch")}
+        elif "two_stage" in legs and stage_overlapped is not None:  # --two-stage: the timed region itself
+            lap_ms, lap_n = stage_overlapped["laplace_multi"]
+            if lap_n:
+                achieved = (blur_b * K / lap_n) / (lap_ms * 1e-3 / lap_n) / 1e9
+                out["roofline"] = {"kernel": "laplace_multi_fast_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                   "traffic": traffic.get("laplace_multi_fast_kernel", {}).get("hbm_bytes_per_launch"),
+                                   "note": "measured over the timed region (kernel spans of %d streams)" % E}
+
+        # ---- host-visible leg: SiftData in pinned host memory, copies overlapped with the next step ----
+        if "host" in legs:
+            out["host_visible_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank, dev,
+                                                       total_local_kp=local_kp)
+            out["keypoints_per_s_host_visible"] = out["host_visible_leg"]["keypoints_per_s"]
+
+        # ---- content legs ----
+        if "content" in legs:
+            cl = {}
+            cl["tile_preblurred (the timed workload)"] = content_stats(torch, capi, ex, d_imgs, None, w, h, B, args, K)
+            raw = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, 0.0), seeds))
+            cl["tile_raw (no pre-blur; initBlur=%.1f still declared)" % args.init_blur] = content_stats(
+                torch, capi, ex, raw, run_single_stream, w, h, B, args, max(4, K // 2))
+            del raw
+            blob = ex.images_from_numpy(make_images(lambda s: synth.blobs(s, w, h), seeds))
+            cl["blobs (SURVEY 8d secondary generator)"] = content_stats(torch, capi, ex, blob, run_single_stream, w, h,
+                                                                        B, args, max(4, K // 2))
+            del blob
+            if stage is not None:
+                cl["tile_preblurred (the timed workload)"].update(
+                    {"ms_per_step_single_stream": out["single_stream_leg"]["ms_per_step"],
+                     "keypoints_per_step": local_kp})
+            out["content_legs"] = cl
+
+        # ---- ragged-width leg ----
+        if "ragged" in legs:
+            rw, rh = 1366, 768
+            rex = BatchExtractor(B, rw, rh, **prm_kw)
+            rimgs = rex.images_from_numpy(make_images(lambda s: synth.tile(s, rw, rh, args.init_blur), seeds))
+            r_ms, r_st = run_single_stream(rex, rimgs, max(4, K // 2))
+            rate = B * rw * rh / (r_ms * 1e-3) / 1e6
+            leg = {"workload": "%d x %dx%d (octave widths 1366, 683, 341, 170, 85: none a multiple of 4)" % (B, rw, rh),
+                   "ms_per_step_single_stream": round(r_ms, 4), "Mpix_per_s_single_stream": round(rate, 1),
+                   "detect_launches_fused": r_st["detect_multi"][1], "laplace_launches": r_st["laplace_multi"][1],
+                   "keypoints_per_step": int(rex.valid_counts().sum().item())}
+            if "single_stream_leg" in out:
+                base = B * w * h / (out["single_stream_leg"]["ms_per_step"] * 1e-3) / 1e6
+                leg["per_pixel_rate_vs_1080p"] = round(rate / base, 3)
+            out["ragged_width_leg"] = leg
+            rex.close()
+            del rimgs
+
+        if "cpu" in legs:
+            out["cpu_baseline"] = cpu_baseline(w, h, dict(prm_kw), args.init_blur, args.cpu_seconds)
+            if world > 1:
+                out["cpu_baseline"]["note"] = "timed on rank 0's host share after the timed region (other ranks idle)"
+
     for x in exs:
         x.close()
     if use_dist:
+        comm.close()
+        side_ctx.close()
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+
+
+def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp):
+    """Steps as in the timed region, but each step's SiftData is packed on the device and copied to pinned host memory
+    on a copy stream while the next steps are extracted; the region ends when the last record is on the host.
+    The copy size is a host argument, so a step's counts travel first (4 bytes x images) and its records one step
+    later, exactly sized -- no host wait on the extraction streams."""
+    copy_stream = torch.cuda.Stream()
+    cctx = capi.Context(device_index, stream=copy_stream.cuda_stream)
+    cap = int(max(1.5 * total_local_kp, 4096))  # records per step the staging buffers hold
+    depth = 3
+    packed = [torch.empty((cap, capi.SIFT_POINT_BYTES), dtype=torch.uint8, device=dev) for _ in range(depth)]
+    offs = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
+    h_offs = [torch.zeros(B + 1, dtype=torch.int32).pin_memory() for _ in range(depth)]
+    h_rec = [torch.empty((cap, capi.SIFT_POINT_BYTES), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    ev_counts = [torch.cuda.Event() for _ in range(depth)]
+    ev_slot = {}
+    inflight = []
+    got = {"records": 0, "bytes": 0}
+    E = len(pipe.streams)
+
+    def complete(j):
+        ev_counts[j].synchronize()  # fired long ago: the next step has been enqueued since
+        total = int(h_offs[j][B])
+        assert total <= cap, (total, cap)
+        with torch.cuda.stream(copy_stream):
+            h_rec[j][:total].copy_(packed[j][:total], non_blocking=True)
+        got["records"] += total
+        got["bytes"] += total * capi.SIFT_POINT_BYTES + 4 * (B + 1)
+
+    def one(i):
+        j = i % depth
+        key = (pipe.submitted % E, (pipe.submitted // E) % pipe.n_slots)
+        pts, cnt, ev = pipe.submit(d_imgs, ready=ev_slot.pop(key, None))
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev)
+            cctx.pack_points(pts.data_ptr(), cnt.data_ptr(), B, max_pts, packed[j].data_ptr(), cap, offs[j].data_ptr())
+            done = torch.cuda.Event()
+            done.record(copy_stream)  # the slot's records have been packed: the slot may be overwritten
+            h_offs[j].copy_(offs[j], non_blocking=True)
+            ev_counts[j].record(copy_stream)
+        ev_slot[key] = done
+        inflight.append(j)
+        if len(inflight) > 1:
+            complete(inflight.pop(0))
+
+    for i in range(3):
+        one(i)
+    while inflight:
+        complete(inflight.pop(0))
+    torch.cuda.synchronize()
+    got["records"] = got["bytes"] = 0
+    t0 = time.perf_counter()
+    for i in range(K):
+        one(i)
+    while inflight:
+        complete(inflight.pop(0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # spot check: the last step's host records are real (first record of image 0 has a finite, in-range location)
+    rec = h_rec[(K - 1) % depth][:1].numpy().view(capi.SIFT_POINT_DTYPE)
+    assert np.isfinite(rec["coords2D"]).all() and rec["subsampling"][0] >= 1.0
+    cctx.close()
+    return {"ms_per_step": round(dt / K * 1e3, 4), "keypoints_per_s": round(got["records"] / dt, 1),
+            "d2h_GBps": round(got["bytes"] / dt / 1e9, 2), "d2h_bytes_per_step": int(got["bytes"] / K),
+            "note": "device-resident input -> SiftData records in pinned host memory (packed on the device, copied on "
+                    "a copy stream, overlapped with the following steps); bounded by the D2H copy when d2h_bytes_per_step "
+                    "/ PCIe rate exceeds the extraction time"}
+
+
+def content_stats(torch, capi, ex, d_imgs, run_single_stream, w, h, B, args, steps):
+    """Keypoints per step and the fraction of octave-0 wave-rows (240 columns x 1 row, the fused kernel's unit) in
+    which no DoG centre of the 5 searchable scales exceeds the threshold -- the rows the pre-test skips (measured from
+    the DoG planes of image 0 through the two-stage entry point); plus the single-stream rate on this content."""
+    out = {}
+    p = ex.pitch
+    dog = torch.empty((7, h, p), dtype=torch.float32, device=d_imgs.device)
+    ex.ctx.laplace_multi(d_imgs.data_ptr(), w, h, p, args.init_blur, dog.data_ptr())
+    torch.cuda.synchronize()
+    big = (dog[1:6, 1:h - 1, :w].abs() > args.thresh).any(dim=0)   # [h-2, w]: any scale above threshold, centre rows
+    big[:, 0] = False  # border columns are never centres
+    big[:, w - 1] = False
+    strips = -(-w // 240)  # the kernel's strips: columns [240 s, 240 s + 240)
+    pad = torch.zeros((big.shape[0], strips * 240), dtype=torch.bool, device=big.device)
+    pad[:, :w] = big
+    rows_with = pad.view(big.shape[0], strips, 240).any(dim=2)
+    out["pretest_skip_frac_octave0"] = round(1.0 - float(rows_with.float().mean().item()), 4)
+    out["pixels_above_thresh_frac_octave0"] = round(float(big.float().mean().item()), 5)
+    if run_single_stream is not None:
+        ms, st = run_single_stream(ex, d_imgs, steps)
+        out["ms_per_step_single_stream"] = round(ms, 4)
+        out["Mpix_per_s_single_stream"] = round(B * w * h / (ms * 1e-3) / 1e6, 1)
+        out["keypoints_per_step"] = int(ex.valid_counts().sum().item())
+        out["stage_ms_per_step"] = {k: round(st[k][0] / steps, 4) for k in ("scale_down", "detect_multi", "describe_all")}
+        raw = torch.clamp(ex.counts, min=0)
+        out["images_saturating_max_pts"] = int((raw >= ex.max_pts).sum().item())
+    return out
 
 
 if __name__ == "__main__":

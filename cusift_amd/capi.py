@@ -75,6 +75,19 @@ SIGNATURES = {
     "cusift_ctx_destroy": (_i, [_vp]),
     "cusift_ctx_synchronize": (_i, [_vp]),
     "cusift_ctx_stream": (_vp, [_vp]),
+    "cusift_ctx_device": (_i, [_vp]),
+    "cusift_ctx_wait": (_i, [_vp, _vp]),
+    "cusift_comm_get_unique_id": (_i, [_vp]),
+    "cusift_comm_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i]),
+    "cusift_comm_destroy": (_i, [_vp]),
+    "cusift_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "cusift_comm_library": (C.c_char_p, []),
+    "cusift_comm_set_self_p2p": (_i, [_vp, _i]),
+    "cusift_allgatherv_begin": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "cusift_allgatherv_finish": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "cusift_allgatherv": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "cusift_exchange_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cusift_exchange_halos": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
     "cusift_ctx_arena_bytes": (_sz, [_vp]),
     "cusift_ctx_timing_enable": (_i, [_vp, _i]),
@@ -231,6 +244,10 @@ class Context:
 
     def synchronize(self):
         check(lib().cusift_ctx_synchronize(self.handle))
+
+    def wait(self, other):
+        """cusift_ctx_wait: work enqueued on this context from now on waits for what `other` has enqueued so far."""
+        check(lib().cusift_ctx_wait(self.handle, other.handle))
 
     def reserve(self, n_images, w, h, params):
         check(lib().cusift_ctx_reserve(self.handle, n_images, w, h, C.byref(params)))
@@ -398,6 +415,71 @@ class Context:
         check(lib().cusift_extract_host(self.handle, img.ctypes.data, w, h, C.byref(params), d_points, hp,
                                         C.byref(n)))
         return n.value
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """cusift_comm_get_unique_id: 128 opaque bytes; rank 0 makes them, every rank passes them to Comm()."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(lib().cusift_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """cusift_comm: an RCCL communicator bound to a Context (its device and stream); one process per GPU.
+    The all-gatherv of SiftData and the row / halo exchange of the strip tiling (include/cusift_amd.h)."""
+
+    def __init__(self, ctx, unique_id, rank, world, self_p2p=False):
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        self._h = C.c_void_p()
+        self.ctx = ctx  # keeps the context alive
+        self.rank, self.world = rank, world
+        check(lib().cusift_comm_create(C.byref(self._h), ctx.handle, unique_id, rank, world))
+        if self_p2p:
+            check(lib().cusift_comm_set_self_p2p(self._h, 1))
+
+    def close(self):
+        if self._h:
+            lib().cusift_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def library():
+        p = lib().cusift_comm_library()
+        return p.decode() if p else ""
+
+    def allgatherv_begin(self, d_points, d_counters, n_images, max_pts, n_images_max):
+        check(lib().cusift_allgatherv_begin(self._h, d_points, d_counters, n_images, max_pts, n_images_max))
+        self._slots = n_images_max
+
+    def allgatherv_finish(self, d_gathered, capacity):
+        """Returns (counts uint32 [world, n_images_max], offsets uint64 [world + 1]) -- host arrays."""
+        counts = np.zeros((self.world, self._slots), dtype=np.uint32)
+        offsets = np.zeros(self.world + 1, dtype=np.uint64)
+        check(lib().cusift_allgatherv_finish(self._h, d_gathered, capacity, counts.ctypes.data, offsets.ctypes.data))
+        return counts, offsets
+
+    def allgatherv(self, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, capacity):
+        self.allgatherv_begin(d_points, d_counters, n_images, max_pts, n_images_max)
+        return self.allgatherv_finish(d_gathered, capacity)
+
+    def exchange_rows(self, d_band, pitch, ops):
+        """ops: list of (peer, send_row, send_rows, recv_row, recv_rows)."""
+        a = np.ascontiguousarray(np.array(ops, dtype=np.int32).reshape(-1, 5).T)
+        n = a.shape[1]
+        check(lib().cusift_exchange_rows(self._h, d_band, pitch, n, a[0].ctypes.data, a[1].ctypes.data,
+                                         a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data))
+
+    def exchange_halos(self, d_band, pitch, top_halo, own_rows, bottom_halo, send_rows):
+        check(lib().cusift_exchange_halos(self._h, d_band, pitch, top_halo, own_rows, bottom_halo, send_rows))
 
 
 class ExtractGraph:

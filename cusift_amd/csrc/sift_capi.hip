@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "sift_internal.h"
 #include "sift_types.h"
 
 namespace cusift {
@@ -56,6 +57,16 @@ using namespace cusift;
 static thread_local std::string g_err;
 
 static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int cusift_fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -457,6 +468,21 @@ extern "C" int cusift_ctx_synchronize(cusift_ctx *ctx) {
 }
 
 extern "C" void *cusift_ctx_stream(cusift_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int cusift_ctx_device(cusift_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+extern "C" int cusift_ctx_wait(cusift_ctx *ctx, cusift_ctx *other) {
+  TRY(enter(ctx));
+  if (!other) return fail(CUSIFT_ERR_INVALID, "other is NULL");
+  if (other == ctx || other->stream == ctx->stream) return CUSIFT_OK;  // same stream: already ordered
+  if (other->device != ctx->device) return fail(CUSIFT_ERR_INVALID, "contexts live on different devices");
+  hipEvent_t ev = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, other->stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+  (void)hipEventDestroy(ev);  // destruction is deferred until the event has completed
+  if (e != hipSuccess) return fail(CUSIFT_ERR_HIP, "cusift_ctx_wait: %s", hipGetErrorString(e));
+  return CUSIFT_OK;
+}
 
 extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p) {
   TRY(enter(ctx));

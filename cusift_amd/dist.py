@@ -10,13 +10,68 @@ final all-gatherv of the variable-length SiftPoint lists:
      (RCCL grouped p2p), so every shard travels over its own link instead of hopping round a ring.
      `method="padded"` is the fallback: pad to the largest shard and use one all_gather_into_tensor.
 
-Works on the `nccl` (= RCCL) backend with device tensors and on `gloo` with CPU tensors (tests).
+On GPUs the exchange is the C ABI's (cusift_comm_* / cusift_allgatherv_*, csrc/sift_comm.hip: RCCL called directly
+from C++) and this module is a thin caller: `make_comm` hands the communicator's unique id to every rank through
+torch.distributed, `SiftGatherer` owns the preallocated output buffers.  The torch.distributed implementation below
+(`begin_allgather` / `finish_allgather` / `allgather_siftdata`) is the host-logic twin used with CPU tensors over
+`gloo` (tests/test_dist_gloo.py); both produce the same layout.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import capi
 from .capi import SIFT_POINT_BYTES
+
+
+def make_comm(ctx, group=None, self_p2p=False):
+    """A capi.Comm (RCCL communicator behind the C ABI) over the ranks of `group`, bound to `ctx` (its device and
+    stream).  Rank 0 creates the unique id; torch.distributed only carries those 128 bytes."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ids = [capi.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=_global_rank(0, group), group=group)
+    else:
+        rank, world, ids = 0, 1, [capi.comm_unique_id()]
+    return capi.Comm(ctx, ids[0], rank, world, self_p2p=self_p2p)
+
+
+class SiftGatherer:
+    """All-gatherv of SiftData on GPUs through the C ABI, with everything allocated once.
+
+        g = SiftGatherer(comm, n_images_max=64, max_pts=32768, capacity=world * 64 * 8192)
+        g.begin(points, counts)                 # asynchronous: counts exchange (enqueued on the comm's stream)
+        ...                                     # enqueue the next extraction meanwhile
+        counts, gathered, offsets = g.finish()  # packs + posts the grouped ncclSend/ncclRecv; `gathered` is a view of
+                                                # an internal ring buffer (n_out deep), valid until n_out finishes later
+    `capacity` = records the gathered buffer holds (default: the worst case world * n_images_max * max_pts)."""
+
+    def __init__(self, comm, n_images_max, max_pts, capacity=None, device=None, n_out=2):
+        self.comm, self.n_max, self.max_pts = comm, int(n_images_max), int(max_pts)
+        self.capacity = int(capacity) if capacity else comm.world * self.n_max * self.max_pts
+        self.device = torch.device("cuda", comm.ctx.device) if device is None else torch.device(device)
+        self.out = [torch.empty((self.capacity, SIFT_POINT_BYTES), dtype=torch.uint8, device=self.device)
+                    for _ in range(max(1, n_out))]
+        self.k = 0
+        self._held = None
+
+    def begin(self, points, counts):
+        assert points.is_cuda and points.is_contiguous() and counts.is_cuda and counts.dtype == torch.int32
+        n = int(points.shape[0])
+        self._held = (points, counts)  # keep the tensors alive until finish()
+        self.comm.allgatherv_begin(points.data_ptr(), counts.data_ptr(), n, self.max_pts, self.n_max)
+
+    def finish(self):
+        buf = self.out[self.k % len(self.out)]
+        self.k += 1
+        counts, offsets = self.comm.allgatherv_finish(buf.data_ptr(), self.capacity)
+        self._held = None
+        return counts, buf[: int(offsets[-1])], offsets
+
+    def gather(self, points, counts):
+        self.begin(points, counts)
+        return self.finish()
 
 
 def shard_range(n_total, rank, world):

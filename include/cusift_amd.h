@@ -96,6 +96,11 @@ int cusift_ctx_create_borrowed(cusift_ctx **out, int device, void *hip_stream);
 int cusift_ctx_destroy(cusift_ctx *ctx);
 int cusift_ctx_synchronize(cusift_ctx *ctx); /* blocking */
 void *cusift_ctx_stream(cusift_ctx *ctx);
+int cusift_ctx_device(cusift_ctx *ctx);
+/* Stream ordering between two contexts of one device without HIP headers: everything enqueued on `ctx` after this
+ * call waits for everything enqueued on `other` so far (event record + stream wait; no host wait).  Lets a caller run
+ * the all-gatherv of batch i on a second context while batch i+1 is extracted on the first. */
+int cusift_ctx_wait(cusift_ctx *ctx, cusift_ctx *other);
 /* Pre-size the scratch arena for batches of n_images w x h images (otherwise grown on demand). */
 int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p);
 /* Bytes of HBM currently held by the arena. */
@@ -243,6 +248,60 @@ int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sift, int num_
  * of the valid counts into d_offsets[0 .. n_images] (may be NULL).  n_images <= 256.  Asynchronous. */
 int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters, int n_images,
                        int max_pts, cusift_point *d_packed, size_t capacity, unsigned int *d_offsets);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (BASELINE configs[3], [4]) --------------------------------
+ * New functionality: the reference is single-GPU, single-image (no collective call sites).
+ * A communicator wraps one ncclComm_t bound to a context: every exchange is enqueued on that context's stream.
+ * RCCL is loaded at run time from the directory of the process's HIP runtime (or $CUSIFT_RCCL_LIB); a program that
+ * never creates a communicator never needs it.
+ *   rank 0:  cusift_comm_get_unique_id(id)  -> hand the 128 bytes to every rank (MPI_Bcast, a TCP store, a file ...)
+ *   all:     cusift_comm_create(&comm, ctx, id, rank, world)      (collective: ncclCommInitRank)
+ */
+#define CUSIFT_UNIQUE_ID_BYTES 128
+typedef struct cusift_comm cusift_comm;
+int cusift_comm_get_unique_id(char id[CUSIFT_UNIQUE_ID_BYTES]);
+int cusift_comm_create(cusift_comm **out, cusift_ctx *ctx, const char id[CUSIFT_UNIQUE_ID_BYTES], int rank, int world);
+int cusift_comm_destroy(cusift_comm *comm);
+int cusift_comm_rank(cusift_comm *comm, int *rank, int *world);
+/* Path of the RCCL library in use ("" before the first communicator call). */
+const char *cusift_comm_library(void);
+/* Tests / world == 1: route the local shard (and rows addressed to this rank) through ncclSend/ncclRecv to self too,
+ * so that one GPU exercises the grouped p2p path.  Also settable with CUSIFT_COMM_SELF_P2P=1. */
+int cusift_comm_set_self_p2p(cusift_comm *comm, int on);
+
+/* All-gatherv of SiftData: every rank ends up with the valid records of ALL ranks' images, packed back to back in
+ * (rank, image) order.  Two phases so that no host wait sits on a pipelined caller's critical path:
+ *   begin  (asynchronous): clamps the per-image counters on the device, ncclAllGather of the counts
+ *          (n_images_max slots per rank: the largest image count of any rank, the same value on every rank),
+ *          asynchronous copy of the gathered counts to pinned host memory.
+ *   finish: waits for that copy (the sizes of ncclSend/ncclRecv are host arguments -- with a step of other work
+ *          enqueued in between, the wait has long been satisfied), writes h_counts[world][n_images_max] and
+ *          h_offsets[world + 1] (records before each rank's shard; either may be NULL), packs the local shard on the
+ *          device straight into d_gathered + h_offsets[rank] and posts ONE ncclGroup of ncclSend/ncclRecv: each shard
+ *          travels directly to each peer over its xGMI link.  Asynchronous after the wait.  d_gathered holds
+ *          `capacity` records; CUSIFT_ERR_NOMEM (and nothing sent) if the total exceeds it -- size it for the worst
+ *          case once (world * n_images_max * max_pts) or for what the scene can yield; no allocation happens here.
+ * d_points / d_counters are the outputs of cusift_extract_batch and must stay untouched until finish() has been
+ * enqueued and completed.  n_images <= 256.  cusift_allgatherv() = begin + finish. */
+int cusift_allgatherv_begin(cusift_comm *comm, const cusift_point *d_points, const unsigned int *d_counters,
+                            int n_images, int max_pts, int n_images_max);
+int cusift_allgatherv_finish(cusift_comm *comm, cusift_point *d_gathered, size_t capacity, unsigned int *h_counts,
+                             size_t *h_offsets);
+int cusift_allgatherv(cusift_comm *comm, const cusift_point *d_points, const unsigned int *d_counters, int n_images,
+                      int max_pts, int n_images_max, cusift_point *d_gathered, size_t capacity,
+                      unsigned int *h_counts, size_t *h_offsets);
+
+/* Rows of a pitched float image between ranks, as one ncclGroup: op i sends send_rows[i] rows starting at local row
+ * send_row[i] of d_band to peers[i] and receives recv_rows[i] rows from it into local row recv_row[i] (`pitch` floats
+ * per row; the peer must post the mirror image).  Asynchronous.
+ * cusift_exchange_halos is the strip tiling's per-octave step (cusift_*_band entry points, BASELINE configs[4]): a band
+ * is [top_halo rows of the neighbour above][own_rows][bottom_halo rows of the neighbour below]; the first / last
+ * `send_rows` owned rows go to rank-1 / rank+1 and their counterparts arrive in the halo rows (every interior rank
+ * uses the same send_rows == its neighbours' halo depth; rank 0 has top_halo = 0, the last rank bottom_halo = 0). */
+int cusift_exchange_rows(cusift_comm *comm, float *d_band, int pitch, int n_ops, const int *peers, const int *send_row,
+                         const int *send_rows, const int *recv_row, const int *recv_rows);
+int cusift_exchange_halos(cusift_comm *comm, float *d_band, int pitch, int top_halo, int own_rows, int bottom_halo,
+                          int send_rows);
 
 /* ---- drivers ------------------------------------------------------------------------------ */
 /* Batch form of ExtractSiftLoop/ExtractSiftOctave (cuSIFT.cu:175-270) on device-resident images.

@@ -1,0 +1,108 @@
+"""The multi-GPU step behind the C ABI (cusift_comm_*, cusift_allgatherv_*, cusift_exchange_*: csrc/sift_comm.hip) on ONE
+GPU: a world-1 communicator with self send/recv drives exactly the code an 8-rank job runs per peer -- ncclAllGather
+of the counts, the device-side pack, ONE ncclGroup of ncclSend/ncclRecv -- and must reproduce the torch expression
+cusift_amd.dist.pack_points.  (Two ranks cannot share a GPU under RCCL; the world > 1 host logic is covered by the
+gloo tests, the hardware run by the driver's scaling bench.)"""
+import numpy as np
+import pytest
+import torch
+
+from cusift_amd import capi
+from cusift_amd.batch import BatchExtractor
+from cusift_amd.dist import SiftGatherer, make_comm, pack_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def extracted(gray1):
+    imgs = np.stack([gray1, np.roll(gray1, (9, 31), axis=(0, 1)), np.full_like(gray1, 50.0), gray1[::-1].copy(),
+                     np.roll(gray1, (100, 200), axis=(0, 1))])
+    ex = BatchExtractor(5, 640, 480, num_octaves=3, peak_thresh=1.0, max_pts=2048)
+    pts, cnt = ex.extract(ex.images_from_numpy(imgs))
+    torch.cuda.synchronize()
+    assert int(cnt[2]) == 0 and int(cnt[0]) > 100
+    yield ex, pts, cnt
+    ex.close()
+
+
+@pytest.mark.parametrize("self_p2p", [True, False])
+def test_allgatherv_world1_equals_pack_points(extracted, self_p2p):
+    ex, pts, cnt = extracted
+    want, valid = pack_points(pts, cnt, ex.max_pts)
+    side = torch.cuda.Stream()
+    ctx = capi.Context(0, stream=side.cuda_stream)
+    comm = make_comm(ctx, self_p2p=self_p2p)
+    assert comm.world == 1 and comm.rank == 0
+    assert "rccl" in capi.Comm.library().lower()
+    n_max = 8  # more count slots than images: padding slots must come back as zero
+    g = SiftGatherer(comm, n_max, ex.max_pts, capacity=int(valid.sum()) + 10, n_out=2)
+    for rep in range(3):  # the output ring and the count buffers are reused
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            g.begin(pts, cnt)
+            counts, gathered, offsets = g.finish()
+        side.synchronize()
+        assert counts.shape == (1, n_max)
+        np.testing.assert_array_equal(counts[0, :5], valid.cpu().numpy())
+        assert not counts[0, 5:].any()
+        assert offsets[0] == 0 and offsets[1] == int(valid.sum())
+        assert torch.equal(gathered.cpu(), want.cpu()), rep
+    # saturated counters are clamped on the device
+    cnt2 = cnt.clone()
+    cnt2[1] = 10 ** 6
+    g2 = SiftGatherer(comm, 5, ex.max_pts, capacity=5 * ex.max_pts)
+    with torch.cuda.stream(side):
+        side.wait_stream(torch.cuda.current_stream())
+        counts, gathered, offsets = g2.gather(pts, cnt2)
+    side.synchronize()
+    assert counts[0, 1] == ex.max_pts and gathered.shape[0] == int(counts.sum())
+    # a buffer that is too small is an error, not an overrun
+    g3 = SiftGatherer(comm, 5, ex.max_pts, capacity=7)
+    with pytest.raises(capi.CusiftError, match="gathered"):
+        g3.gather(pts, cnt)
+    # finish without begin / begin twice
+    with pytest.raises(capi.CusiftError):
+        comm.allgatherv_finish(g.out[0].data_ptr(), g.capacity)
+    comm.close()
+    ctx.close()
+
+
+def test_exchange_rows_self(ctx):
+    """cusift_exchange_rows with the rank itself as the peer (self_p2p): rows are sent and received inside ONE group,
+    exactly the halo step's call pattern.  Band layout [2 halo][6 own][2 halo]."""
+    pitch, rows = 128, 10
+    band = torch.arange(rows * pitch, dtype=torch.float32, device="cuda").reshape(rows, pitch)
+    before = band.clone()
+    st = torch.cuda.Stream()
+    c = capi.Context(0, stream=st.cuda_stream)
+    comm = make_comm(c, self_p2p=True)
+    with torch.cuda.stream(st):
+        st.wait_stream(torch.cuda.current_stream())
+        # first 2 owned rows -> top halo, last 2 owned rows -> bottom halo (what a neighbour would receive)
+        comm.exchange_rows(band.data_ptr(), pitch, [(0, 2, 2, 0, 2), (0, 6, 2, 8, 2)])
+    st.synchronize()
+    assert torch.equal(band[0:2], before[2:4]) and torch.equal(band[8:10], before[6:8])
+    assert torch.equal(band[2:8], before[2:8])
+    # world 1 has no neighbours: the halo form is a no-op
+    comm.exchange_halos(band.data_ptr(), pitch, 0, rows, 0, 2)
+    # without self_p2p a self-addressed op is refused
+    comm2 = make_comm(c)
+    with pytest.raises(capi.CusiftError, match="addresses this rank"):
+        comm2.exchange_rows(band.data_ptr(), pitch, [(0, 2, 2, 0, 2)])
+    comm2.close()
+    comm.close()
+    c.close()
+
+
+def test_ctx_wait_orders_two_contexts(ctx, gray1):
+    """cusift_ctx_wait: a second context (its own stream) consumes what the first one produced, no host wait."""
+    other = capi.Context(0)
+    a = capi.DeviceBuffer(ctx, 1 << 24)
+    b = capi.DeviceBuffer(other, 1 << 24)
+    ctx.memset(a.ptr, 0x5A, a.nbytes)          # asynchronous on ctx's stream
+    other.wait(ctx)
+    capi.check(capi.lib().cusift_memcpy_d2d(other.handle, b.ptr, a.ptr, a.nbytes))
+    got = b.to_numpy(np.uint8, (a.nbytes,))
+    assert (got == 0x5A).all()
+    other.close()
