@@ -22,6 +22,7 @@ __global__ void scale_down_kernel(float *, int, long, const float *, int, int, i
 __global__ void scale_down_fast_kernel(float *, int, long, const float *, int, int, int, long, int, ScaleDownTaps,
                                        RowWindow, int, int, int);
 __global__ void laplace_multi_kernel(const float *, float *, int, int, int, long, long, int, int, LaplaceTaps);
+template <int kStoreAux>
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                         FindParams);
@@ -528,7 +529,7 @@ extern "C" int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, i
   hipError_t e = hipErrorInvalidValue;
   if (k == "detect_fused")  // single-wave workgroups, 9 KB refinement cube each
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false>, t = 64, 9 * 256 * sizeof(float));
-  else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel, t, 0);
+  else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel<0>, t, 0);
   else if (k == "find_points") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, find_points_fast_kernel, t, 0);
   else if (k == "scale_down") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scale_down_fast_kernel, t, 0);
   else if (k == "describe_all") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, describe_all_kernel, t = 64, 0);
@@ -757,8 +758,9 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
                      (img_stride % 4 == 0) && (dog_stride % 4 == 0) && (((size_t)h * pitch) % 4 == 0);
   const int strips = idiv_up(w, kBlurStrip);
   // short chunks: the halo rows they re-read come from L2, and the chip sustains a visibly higher store rate when
-  // many short waves write than when few long ones do (tools/probe_rows.py, 64x1080p: r = 6 0.737 ms, r = 32 0.820 ms)
-  int rlo = 3, rhi = 6;
+  // many short waves write than when few long ones do (tools/ab_laplace_rows.sh with non-temporal stores, 64x1080p, all
+  // octaves at one r: r = 3 0.263 ms per launch, 6: 0.242, 8: 0.234, 12: 0.239, 16: 0.243, 32: 0.270)
+  int rlo = 3, rhi = 8;
   rows_bounds("LAPLACE", rlo, rhi);
   const int rows = pick_rows(h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
@@ -776,8 +778,19 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
     int wpb = kWavesPerBlock;
     if (const char *e = getenv("CUSIFT_LAPLACE_WAVES")) wpb = std::max(1, std::min(4, atoi(e)));  // experiments only
     dim3 fgrid(strips, idiv_up(idiv_up(h, rows), wpb), n_images);
-    hipLaunchKernelGGL(laplace_multi_fast_kernel, fgrid, dim3(64 * wpb), 0, ctx->stream, d_img, d_dog, w, h, pitch,
-                       (long)img_stride, (long)dog_stride, rows, TP);
+    // DoG planes are written once and read much later (by FindPointsMulti): non-temporal stores keep them from
+    // displacing the source rows' halo in L2 -- measured on one box (tools/ab_laplace_aux.sh): 4.35 -> 4.63 TB/s for
+    // this kernel and 3.87 -> 4.18 TB/s for the FindPointsMulti that follows
+    int aux = 2;
+    if (const char *e = getenv("CUSIFT_LAPLACE_AUX")) aux = atoi(e);  // experiments: cache policy of the DoG stores
+#define LAUNCH_LAPLACE(A)                                                                                         \
+  hipLaunchKernelGGL(laplace_multi_fast_kernel<A>, fgrid, dim3(64 * wpb), 0, ctx->stream, d_img, d_dog, w, h, pitch, \
+                     (long)img_stride, (long)dog_stride, rows, TP)
+    if (aux == 2) LAUNCH_LAPLACE(2);
+    else if (aux == 16) LAUNCH_LAPLACE(16);
+    else if (aux == 18) LAUNCH_LAPLACE(18);
+    else LAUNCH_LAPLACE(0);
+#undef LAUNCH_LAPLACE
   } else {
     hipLaunchKernelGGL(laplace_multi_kernel, grid, dim3(256), 0, ctx->stream, d_img, d_dog, w, h, pitch,
                        (long)img_stride, (long)dog_stride, rows, vec_ok, T);

@@ -184,6 +184,7 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 __device__ __forceinline__ f2 dpp_prev2(f2 v) { return f2{from_prev_lane(v.x), from_prev_lane(v.y)}; }
 __device__ __forceinline__ f2 dpp_next2(f2 v) { return f2{from_next_lane(v.x), from_next_lane(v.y)}; }
 
+template <int kStoreAux>
 __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__restrict__ img,
                                                                 float *__restrict__ dog, int w, int h, int pitch,
                                                                 long img_stride, long dog_stride, int rows_per_wave,
@@ -259,14 +260,14 @@ __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__
         const f4 d = f4{prev_hi[0] - L[0].x, prev_hi[1] - L[1].x, prev_hi[2] - L[2].x, prev_hi[3] - L[3].x};
         const __amdgpu_buffer_rsrc_t ro =
             __builtin_amdgcn_make_buffer_rsrc((void *)(row + (long)(2 * q - 1) * plane), 0, w * 4, kBufFlags);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), ro, voff_out, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), ro, voff_out, 0, kStoreAux);
       }
       {  // DoG plane 2q = level 2q - level 2q+1 (both halves of this pair)
         const f4 d = f4{L[0].x - L[0].y, L[1].x - L[1].y, L[2].x - L[2].y, L[3].x - L[3].y};
         if (2 * q < kNumDog) {
           const __amdgpu_buffer_rsrc_t ro =
               __builtin_amdgcn_make_buffer_rsrc((void *)(row + (long)(2 * q) * plane), 0, w * 4, kBufFlags);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), ro, voff_out, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d), ro, voff_out, 0, kStoreAux);
         }
       }
 #pragma unroll
@@ -277,6 +278,10 @@ __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__
     win[8] = nxt;
   }
 }
+template __global__ void laplace_multi_fast_kernel<0>(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
+template __global__ void laplace_multi_fast_kernel<2>(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
+template __global__ void laplace_multi_fast_kernel<16>(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
+template __global__ void laplace_multi_fast_kernel<18>(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 
 // ------------------------------------------------------------------------------------------------
 // ScaleDown, fast path (16-byte aligned source rows, any w >= 4, 8-byte aligned destination rows).
@@ -520,7 +525,8 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf
 // ------------------------------------------------------------------------------------------------
 // FindPointsMulti, fast path (8-byte aligned DoG rows: pitch % 2 == 0, any w >= 2, block < 2 GiB): the same test and the
 // same refinement as find_points_kernel, with buffer_load_dwordx2 on a wave-uniform row base, the next
-// row of all 7 planes requested one iteration ahead, and v_min3/v_max3 trees.
+// row of all 7 planes requested one iteration ahead, and v_min3/v_max3 trees.  (Non-temporal loads were tried and
+// lose: 4.2 -> 3.6 TB/s, tools/ab_findpoints.sh -- the 3-row window's re-reads want the L2.)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__restrict__ dog, int w, int h, int pitch,
                                                               long dog_stride, cusift_point *__restrict__ points,
