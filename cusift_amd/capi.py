@@ -118,7 +118,7 @@ SIGNATURES = {
     "cusift_math_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
     "cusift_scale_down_band": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f]),
     "cusift_detect_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i, _vp]),
-    "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i]),
+    "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),
     "cusift_match": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "cusift_find_homography": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, C.POINTER(_i), _vp, _vp]),
@@ -357,9 +357,9 @@ class Context:
                                        peak_thresh, edge_thresh, subsampling, d_points, max_pts, d_counter))
 
     def describe_band(self, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first, d_counter, subsampling,
-                      tex_frac_bits=8):
+                      tex_frac_bits=8, d_flags=None):
         check(lib().cusift_describe_band(self.handle, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first,
-                                         d_counter, subsampling, tex_frac_bits))
+                                         d_counter, subsampling, tex_frac_bits, d_flags))
 
     def math_eval(self, op, d_a, d_b, d_out, d_out2, n):
         """cusift_math_eval: op 0 expf, 1 exp2f, 2 atan2f(a, b), 3 sincosf -> (out, out2); device pointers."""

@@ -34,7 +34,7 @@ __global__ void find_points_kernel(const float *, int, int, int, long, cusift_po
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                     const unsigned int *, float, float, RowWindow);
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
-                                   const unsigned int *, float, float, float, RowWindow, int);
+                                   const unsigned int *, float, float, float, RowWindow, int, unsigned int *);
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int,
                                     unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
@@ -898,6 +898,10 @@ extern "C" int cusift_detect_band(cusift_ctx *ctx, const float *d_img, int w, in
                                   float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counter) {
   if (row0 < 0 || h < 1 || row0 + h > h_global || cy_begin < row0 || cy_end > row0 + h || cy_end <= cy_begin)
     return fail(CUSIFT_ERR_INVALID, "Detect (band): bad row geometry");
+  // centres need 4 blur rows + 1 extremum row of true data on either side, unless the band ends at the image border
+  if ((row0 > 0 && cy_begin - row0 < 5) || (row0 + h < h_global && row0 + h - cy_end < 5))
+    return fail(CUSIFT_ERR_INVALID, "Detect (band): centres [%d,%d) need 5 halo rows inside the band [%d,%d)", cy_begin,
+                cy_end, row0, row0 + h);
   return detect_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, init_blur, peak_thresh, edge_thresh, subsampling,
                      d_points, max_pts, d_counter, 1, RowWindow{row0, h_global}, cy_begin, cy_end);
 }
@@ -927,7 +931,7 @@ static int orientations_impl(cusift_ctx *ctx, const float *d_img, int w, int h, 
 static int descriptors_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
                             cusift_point *d_points, int max_pts, const unsigned int *d_first,
                             const unsigned int *d_counters, float subsampling, int tex_frac_bits, int n_images,
-                            RowWindow rw, int root_sift = 0) {
+                            RowWindow rw, int root_sift = 0, unsigned int *d_flags = nullptr) {
   TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "ExtractSiftDescriptors: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -937,7 +941,7 @@ static int descriptors_impl(cusift_ctx *ctx, const float *d_img, int w, int h, i
   dim3 grid(keypoint_grid_x(max_pts, n_images), n_images);
   StageTimer t(ctx, CUSIFT_STAGE_DESCR);
   hipLaunchKernelGGL(descriptors_kernel, grid, dim3(64), 0, ctx->stream, d_img, w, h, pitch, (long)img_stride,
-                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q, rw, root_sift);
+                     d_points, max_pts, d_first, d_counters, subsampling, q, inv_q, rw, root_sift, d_flags);
   return check_launch("extract_descriptors");
 }
 
@@ -959,13 +963,14 @@ extern "C" int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, i
 
 extern "C" int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0,
                                     int h_global, cusift_point *d_points, int max_pts, const unsigned int *d_first,
-                                    const unsigned int *d_counter, float subsampling, int tex_frac_bits) {
+                                    const unsigned int *d_counter, float subsampling, int tex_frac_bits,
+                                    unsigned int *d_flags) {
   if (row0 < 0 || h < 1 || row0 + h > h_global) return fail(CUSIFT_ERR_INVALID, "Describe (band): bad row geometry");
   const RowWindow rw{row0, h_global};
   TRY(orientations_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
                         tex_frac_bits, 1, rw));
   return descriptors_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
-                          subsampling, tex_frac_bits, 1, rw);
+                          subsampling, tex_frac_bits, 1, rw, 0, d_flags);
 }
 
 extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts) {

@@ -604,7 +604,8 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
                                                         long img_stride, cusift_point *__restrict__ points,
                                                         int max_pts, const unsigned int *__restrict__ first,
                                                         const unsigned int *__restrict__ counters, float subsampling,
-                                                        float q, float inv_q, RowWindow rw, int root_sift) {
+                                                        float q, float inv_q, RowWindow rw, int root_sift,
+                                                        unsigned int *__restrict__ flags) {
   __shared__ KpShared S;
   const int lane = threadIdx.x;
   img += (long)blockIdx.y * img_stride;
@@ -618,6 +619,17 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
     cusift_point *pt = points + bx;
     const float px = uniform(pt->coords2D[0]), py = uniform(pt->coords2D[1]);
     const float kscale = uniform(pt->scale), ori = uniform(pt->orientation);
+    if (flags) {
+      // Band of a strip-tiled image: count the keypoints whose sampling footprint (orientation window +-6 px,
+      // descriptor grid +-7.5*spacing*(|cos|+|sin|), +-1 px taps, bilinear 2x2) leaves the band where the band does
+      // not end at the image border -- there the clamp would replace the neighbour's rows (cusift_describe_band).
+      float sn, cs;
+      sm_sincosf(2.0f * 3.1415f / 360.0f * ori, &sn, &cs);
+      const float r = fmaxf(7.5f * (12.0f / 16.0f * kscale) * (fabsf(sn) + fabsf(cs)), 6.0f) + 2.5f;
+      const bool cut = (rw.row0 > 0 && !(py - r >= (float)rw.row0)) ||
+                       (rw.row0 + h < rw.hg && !(py + r <= (float)(rw.row0 + h - 1)));
+      if (cut && lane == 0) atomicAdd(flags, 1u);
+    }
     // every tap is within `reach` of the keypoint: 7.5*spacing*(|cos|+|sin|) for the grid + 1 for the tap
     const float reach = 7.5f * (12.0f / 16.0f * kscale) * 1.41422f + 1.0f + 0.01f;  // |cos| + |sin| <= sqrt 2
     PatchGeom g;

@@ -206,8 +206,13 @@ int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b
  *   that starts at global row dst_row0, from a source band {src_row0, h_src_global}; needs source rows
  *   2r-1 .. 2r+3 (cuSIFT_D.cu:75,123-125) inside the source band.
  * cusift_detect_band: fused LaplaceMulti+FindPointsMulti with extremum centres restricted to global rows
- *   [cy_begin, cy_end); keypoint rows are written in global coordinates.  Needs >= 6 halo rows.
- * cusift_describe_band: ComputeOrientations + ExtractSiftDescriptors for keypoints in global coordinates. */
+ *   [cy_begin, cy_end); keypoint rows are written in global coordinates.  Needs >= 5 halo rows of true data on each
+ *   side that is not the image border (4 blur + 1 extremum; CUSIFT_ERR_INVALID otherwise).
+ * cusift_describe_band: ComputeOrientations + ExtractSiftDescriptors for keypoints in global coordinates.
+ *   d_flags (may be NULL): one counter, incremented for every keypoint whose sampling footprint (orientation window,
+ *   rotated descriptor grid, +-1 px taps, bilinear 2x2) reaches beyond the band on a side that is not the image
+ *   border -- such a keypoint samples clamped rows instead of the neighbour's and would differ from the whole image;
+ *   the caller must treat a non-zero count as an error (cusift_amd.tiling.StripExtractor.check does). */
 int cusift_scale_down_band(cusift_ctx *ctx, float *d_dst, int dst_pitch, int dst_row0, int r_begin, int r_end,
                            const float *d_src, int w, int h_src, int src_pitch, int src_row0, int h_src_global,
                            float variance);
@@ -216,7 +221,7 @@ int cusift_detect_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
                        float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counter);
 int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0, int h_global,
                          cusift_point *d_points, int max_pts, const unsigned int *d_first,
-                         const unsigned int *d_counter, float subsampling, int tex_frac_bits);
+                         const unsigned int *d_counter, float subsampling, int tex_frac_bits, unsigned int *d_flags);
 
 /* ---- matcher (first consumer of SiftData) ----------------------------- */
 /* MatchSiftData(data1, data2, distance, ...), extras/matching.cu:232-362: for every point of d_sift1 the best

@@ -66,9 +66,12 @@ def test_batch64_1080p_matches_oracle(ctx, oracle):
         b.free()
 
 
-def test_strips_8192_equal_whole_image(ctx):
+@pytest.mark.parametrize("n_oct", [5, 7])
+def test_strips_8192_equal_whole_image(ctx, n_oct):
+    """5 octaves: all tiled.  7 octaves: octaves 5 and 6 (32 and 16 owned rows per rank < the 48-row halo) collapse onto
+    rank 0, which runs the whole-image driver on the gathered 256-row octave."""
     W = H = 8192
-    P, n_oct = 8, 5
+    P = 8
     img = synth.tile(4242, W, H, preblur=1.0)
     prm = capi.default_params(num_octaves=n_oct, init_blur=1.0, peak_thresh=3.0, max_pts=1 << 18)
     d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
@@ -82,6 +85,7 @@ def test_strips_8192_equal_whole_image(ctx):
     rows = H // P
     sprm = capi.default_params(num_octaves=n_oct, init_blur=1.0, peak_thresh=3.0, max_pts=1 << 16)
     exts = [StripExtractor(k, P, W, H, sprm, device=dev) for k in range(P)]
+    assert exts[0].plan.collapse == 5
     parts = run_virtual(exts, [full[k * rows:(k + 1) * rows] for k in range(P)])
     for k, pts in enumerate(parts):
         assert 0 < len(pts) < sprm.max_pts

@@ -20,23 +20,35 @@ def whole_image(ctx, img, prm):
     return h_pts[:n]
 
 
-@pytest.mark.parametrize("W,H,P,n_oct,blur,thresh", [(1024, 2048, 4, 4, 1.0, 3.0), (512, 1536, 2, 5, 0.0, 2.0),
-                                                      (256, 768, 1, 3, 0.0, 2.0)])
-def test_strips_equal_whole_image(ctx, W, H, P, n_oct, blur, thresh):
+@pytest.mark.parametrize("W,H,P,n_oct,blur,thresh,collapse", [
+    (1024, 2048, 4, 4, 1.0, 3.0, 4),   # every octave tiled (512 .. 64 owned rows)
+    (512, 1536, 2, 5, 0.0, 2.0, 5),
+    (256, 768, 1, 3, 0.0, 2.0, 3),     # one rank: the plain whole image through the band entry points
+    (1024, 2048, 4, 7, 1.0, 3.0, 4),   # octaves 4..6 (128, 64, 32 rows) collapse onto rank 0
+    (1000, 1531, 3, 6, 0.5, 2.0, 4),   # uneven strips (510/510/511 rows), ragged widths (1000 -> 500 -> 250 -> 125 ...)
+    (640, 300, 8, 4, 0.0, 1.0, 0),     # strips thinner than the halo from the start: everything runs on rank 0
+])
+def test_strips_equal_whole_image(ctx, W, H, P, n_oct, blur, thresh, collapse):
     img = synth.tile(77, W, H, preblur=blur)
     prm = capi.default_params(num_octaves=n_oct, init_blur=blur, peak_thresh=thresh, max_pts=65536)
     want = canonical_order(whole_image(ctx, img, prm))
     assert len(want) > 300
     dev = torch.device("cuda", 0)
     full = torch.from_numpy(img).to(dev)
-    rows = H // P
     exts = [StripExtractor(k, P, W, H, prm, device=dev) for k in range(P)]
-    parts = run_virtual(exts, [full[k * rows:(k + 1) * rows] for k in range(P)])
-    # ownership: every rank only reports keypoints whose detection row it owns (octave rows -> base rows)
+    plan = exts[0].plan
+    assert plan.collapse == collapse, plan.collapse
+    bounds = plan.bounds
+    parts = run_virtual(exts, [full[bounds[k]:bounds[k + 1]] for k in range(P)])
+    # ownership: every rank only reports keypoints whose detection row it owns (octave rows -> base rows); the
+    # collapsed octaves all belong to rank 0
     for k, pts in enumerate(parts):
-        if len(pts):
-            yb = pts["coords2D"][:, 1]
-            assert yb.min() >= k * rows - 0.51 * pts["subsampling"].max() and yb.max() < (k + 1) * rows + 0.51 * pts["subsampling"].max()
+        tiled = pts[pts["subsampling"] < prm.subsampling * 2 ** plan.collapse]
+        if len(tiled):
+            yb, slack = tiled["coords2D"][:, 1], 0.51 * tiled["subsampling"].max()
+            assert yb.min() >= bounds[k] - slack - tiled["subsampling"].max() and yb.max() < bounds[k + 1] + slack
+        if k != plan.root:
+            assert len(tiled) == len(pts)
         # coarsest octave first inside each rank's list
         assert np.all(np.diff(pts["subsampling"]) <= 0)
     got = canonical_order(np.concatenate(parts))
@@ -51,21 +63,38 @@ def test_strips_equal_whole_image(ctx, W, H, P, n_oct, blur, thresh):
         e.close()
 
 
-def test_plan_rejects_bad_geometry():
-    with pytest.raises(ValueError):
-        StripPlan(1000, 2048, 4, 4)   # width not a multiple of 32
-    with pytest.raises(ValueError):
-        StripPlan(1024, 2000, 4, 4)   # height not a multiple of 32
-    with pytest.raises(ValueError):
-        StripPlan(1024, 1024, 8, 5)   # coarsest octave owns 8 rows < halo
-    pl = StripPlan(8192, 8192, 8, 5)
-    assert pl.own(3, 0) == (3072, 4096) and pl.own(3, 4) == (192, 256)
-    assert pl.band(0, 0) == (0, 1024 + 48) and pl.band(7, 4) == (448 - 48, 512)
+def test_footprint_beyond_the_halo_is_an_error_not_a_clamped_read(ctx):
+    """A keypoint whose descriptor grid reaches past the halo would sample clamped rows instead of the neighbour's:
+    the band kernel counts it and the extractor raises (strict) or reports (strict=False) -- never silently different."""
+    W, H, P = 512, 1024, 2
+    img = synth.tile(5, W, H)
+    prm = capi.default_params(num_octaves=2, init_blur=0.0, peak_thresh=1.0, max_pts=65536)
+    dev = torch.device("cuda", 0)
+    full = torch.from_numpy(img).to(dev)
+    for strict in (True, False):
+        exts = [StripExtractor(k, P, W, H, prm, device=dev, halo=8, strict=strict) for k in range(P)]
+        b = exts[0].plan.bounds
+        if strict:
+            with pytest.raises(capi.CusiftError, match="halo"):
+                run_virtual(exts, [full[b[k]:b[k + 1]] for k in range(P)])
+        else:
+            parts = run_virtual(exts, [full[b[k]:b[k + 1]] for k in range(P)])
+            assert sum(e.check() for e in exts) > 0 and sum(len(p) for p in parts) > 300
+        for e in exts:
+            e.close()
+    # with the default halo nothing on this image is flagged
+    exts = [StripExtractor(k, P, W, H, prm, device=dev) for k in range(P)]
+    run_virtual(exts, [full[b[k]:b[k + 1]] for k in range(P)])
+    assert all(e.check() == 0 for e in exts)
+    for e in exts:
+        e.close()
 
 
 def test_band_entry_points_validate_rows(ctx):
     d = DeviceBuffer(ctx, 1 << 20)
     with pytest.raises(capi.CusiftError, match="row geometry"):
         ctx.detect_band(d.ptr, 128, 64, 128, 10, 60, 10, 74, 0.0, 1.0, 10.0, 1.0, d.ptr, 16, d.ptr)  # band leaves the image
+    with pytest.raises(capi.CusiftError, match="halo rows"):
+        ctx.detect_band(d.ptr, 128, 40, 128, 10, 100, 12, 48, 0.0, 1.0, 10.0, 1.0, d.ptr, 16, d.ptr)  # 2 rows of halo
     with pytest.raises(capi.CusiftError, match="row geometry"):
         ctx.scale_down_band(d.ptr, 128, 0, 0, 40, d.ptr, 128, 64, 128, 0, 64, 0.5)  # r_end > h/2
