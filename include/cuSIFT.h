@@ -83,6 +83,38 @@ inline void InitCuda(int devNum) {
   safeCall(cusift_init(devNum));
 }
 
+// ---- cutils.h:21-69: safeThreadSync / checkMsg / deviceInit -------------------------------------------------
+// safeThreadSync(): cudaThreadSynchronize + exit(-1) on error -> wait for the drop-in context's stream.
+// checkMsg(msg): the reference polls cudaGetLastError() after its own kernel launches; here every launch lives behind a
+//   C-ABI entry point that returns a status (already routed through safeCall), so there is no sticky launch error left
+//   to poll: the macro evaluates its argument and is otherwise a no-op, which keeps reference-style code compiling.
+// deviceInit(dev): clamp into [0, n-1] and select, false if there is no device (cutils.h:50-69).
+inline void cusift_safe_thread_sync_(const char *file, int line) {
+  if (cusift_ctx_synchronize(cusift_dropin::ctx()) != CUSIFT_OK) {
+#ifdef CUSIFT_NO_EXIT
+    throw std::runtime_error(std::string("threadSynchronize(): ") + cusift_last_error());
+#else
+    std::fprintf(stderr, "threadSynchronize() runtime error in file '%s' in line %i : %s.\n", file, line,
+                 cusift_last_error());
+    std::exit(-1);
+#endif
+  }
+}
+#define safeThreadSync() cusift_safe_thread_sync_(__FILE__, __LINE__)
+#define checkMsg(msg) ((void)(msg))
+inline bool deviceInit(int dev) {
+  int n = 0;
+  cusift_device_count(&n);
+  if (n == 0) {
+    std::fprintf(stderr, "error: no GPU devices available.\n");
+    return false;
+  }
+  if (dev < 0) dev = 0;
+  if (dev > n - 1) dev = n - 1;
+  InitCuda(dev);
+  return true;
+}
+
 // ---- cutils.h:94-140 ------------------------------------------------------------------------------
 // The reference brackets work with cudaEvents on the default stream; every entry point of this shim
 // blocks until its GPU work is done, so wall-clock between construction and read() measures the same span.

@@ -32,8 +32,10 @@ int main(int argc, char **argv) {
   int w = 0, h = 0;
   if (!read_pgm(argv[1], im, w, h)) return 2;
 
-  InitCuda(0);
+  if (!deviceInit(0)) return 2;  // cutils.h:50-69 (calls InitCuda)
   cuImage *cuIm = new cuImage(w, h, im.data());
+  safeThreadSync();                // cutils.h:21,32-39
+  checkMsg("upload");              // cutils.h:22,41-48 (compiles, no sticky error to poll: see cuSIFT.h)
 
   // ---- live API, test/detector.cpp:37-49 ----
   SiftData *siftData = new SiftData(4096, true, true);

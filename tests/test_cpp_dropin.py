@@ -10,16 +10,17 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(CPP, "detector_dropin")
 BIN_MATCH = os.path.join(CPP, "matching_dropin")
 BIN_HOMO = os.path.join(CPP, "homography_dropin")
+BIN_MULTI = os.path.join(CPP, "multigpu_dropin")
 
 
 def build():
     subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
-    assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO)
+    assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO) and os.path.exists(BIN_MULTI)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH, BIN_HOMO):
+    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -76,3 +77,16 @@ def test_dropin_homography_program_passes_on_gpu():
     print(out.stdout[-2000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "PASSED" in out.stdout and "FindHomography:" in out.stdout and "ImproveHomography:" in out.stdout
+
+
+@pytest.mark.gpu
+def test_dropin_multigpu_program_passes_on_one_gpu(tmp_path):
+    """The C++ rank program of INTEGRATION.md section 5 (ExtractSift per image, then cusift_allgatherv_*) with
+    world = 1: the shard still travels through RCCL (self send/recv inside one ncclGroup).  No torch in the process:
+    RCCL is the system's, found next to the system HIP runtime."""
+    build()
+    out = subprocess.run([BIN_MULTI, "0", "1", str(tmp_path / "comm.id"), os.path.join(ROOT, "tests", "golden", "gray1.pgm"),
+                          "3"], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "PASSED" in out.stdout and "rccl" in out.stdout.lower()

@@ -24,7 +24,7 @@ def main():
     import torch.distributed as dist
 
     from cusift_amd import capi, synth
-    from cusift_amd.dist import allgather_siftdata
+    from cusift_amd.dist import SiftGatherer, make_comm
     from cusift_amd.tiling import StripExtractor, run_distributed, run_virtual
 
     W = H = int(os.environ.get("TILED_SIZE", "8192"))
@@ -34,29 +34,38 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=3.0, max_pts=1 << 19)
+    prm = capi.default_params(num_octaves=int(os.environ.get("TILED_OCTAVES", "5")), init_blur=1.0, peak_thresh=3.0,
+                              max_pts=1 << 19)
     img = synth.tile(4242, W, H, preblur=1.0)
     out = {"workload": "single %dx%d image, 5 octaves, initBlur=1.0, thresh=3.0" % (W, H)}
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-        rows = H // world
-        strip = torch.from_numpy(img[rank * rows:(rank + 1) * rows]).to(dev)
-        ext = StripExtractor(rank, world, W, H, prm, device=dev)
+        dist.init_process_group("nccl", device_id=dev)  # carries the communicator id + the barrier only
+        # the halo / row exchanges and the all-gatherv go through the C ABI's communicator (RCCL from C++)
+        ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+        comm = make_comm(ctx)
+        ext = StripExtractor(rank, world, W, H, prm, device=dev, comm=comm)
+        b = ext.plan.bounds
+        strip = torch.from_numpy(img[b[rank]:b[rank + 1]]).to(dev)
+        gat = SiftGatherer(comm, 1, ext.max_pts, capacity=ext.max_pts, device=dev)
         for it in range(steps + 2):
             if it == 2:
                 dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             pts, cnt = run_distributed(ext, strip)
-            ac, ga, off = allgather_siftdata(pts, cnt, ext.max_pts)
+            ac, ga, off = gat.gather(pts, cnt)
+        ext.check()
         dist.barrier()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         if rank == 0:
             out.update({"n_gpus": world, "ms_per_image": round(dt * 1e3, 3), "Mpix_per_s": round(W * H / dt / 1e6, 1),
-                        "keypoints": int(off[-1]), "mode": "distributed strips + halo exchange + all-gatherv"})
+                        "keypoints": int(off[-1]), "collapse_octave": ext.plan.collapse,
+                        "mode": "distributed strips + halo exchange + all-gatherv (C ABI over RCCL)"})
             print(json.dumps(out), flush=True)
+        comm.close()
+        ctx.close()
         dist.destroy_process_group()
         return
 
