@@ -857,14 +857,18 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   const int strips = idiv_up(w, 240);  // kDetStrip
   // Chunk height.  A chunk of r centre rows costs r + 2 blurred rows (+ an 8-row window fill), so tall chunks waste
   // the least arithmetic -- but the launch ends with a tail in which the last chunks run on a part-empty chip, and
-  // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work): measured optima on MI355X
-  // (tools/probe_rows.py, 64 images): 1920x1080 r = 16 (0.685 ms; r = 32: 0.731), 960x540 r = 8 (0.199 vs 0.248),
-  // 480x270 r = 6-8, 240x135 r = 2-4, 120x67 r = 2-3 -- all within 4 % of 0.022 * sqrt(rows * strips * images)
-  // (the same optima with one and with four waves per workgroup).
-  int rows_lo = 2, rows_hi = 24;
+  // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work).  Measured on MI355X, 64 x 1080p
+  // (tools/ab_detect_rows.sh; r = coef * sqrt(rows * strips * images)): one stream alone is fastest at coef 0.022-0.035
+  // (1.849 / 1.824 ms per step) and loses from 0.06 on (1.877; 0.1: 1.99); with consecutive batches on two streams --
+  // the throughput mode, where the other batch's kernels fill the tail -- taller chunks win: 0.022 1.610, 0.045 1.530,
+  // 0.06 1.517, 0.08 1.505, 0.1 1.508, 0.15 1.554 ms.  0.05 keeps the single stream where it was (+0.3 %) and takes
+  // most of the two-stream gain (-5 %).
+  int rows_lo = 2, rows_hi = 56;
   rows_bounds("DETECT", rows_lo, rows_hi);
   const double wave_rows = (double)rows_total * strips * n_images;
-  const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(0.022 * sqrt(wave_rows))));
+  double coef = 0.05;
+  if (const char *e = getenv("CUSIFT_DETECT_ROWS_COEF")) coef = atof(e);  // tuning experiments only
+  const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
   // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
   // threshold pre-test makes the waves' run times uneven -- measured 64x1080p, r = 16: 4 waves per workgroup 0.693 ms,
   // 2: 0.645 ms, 1: 0.630 ms (tools/probe_rows.py with CUSIFT_DETECT_WAVES).

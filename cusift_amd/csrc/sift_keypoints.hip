@@ -7,7 +7,20 @@
 // bit-identical to the oracle's, descriptors differ only by the summation order of the histogram (~1e-7).
 #include "sift_device.h"
 
+// Cost-attribution experiments (tools/exp_describe_phases.sh): -DCUSIFT_EXP=<n> removes one phase of the keypoint body
+// (results are then wrong on purpose); never defined in the product build.
+#ifndef CUSIFT_EXP
+#define CUSIFT_EXP 0
+#endif
+
 namespace cusift {
+
+#if CUSIFT_EXP == 4
+#define sm_atan2f(y, x) ((y) * 0.5f + (x))
+#endif
+#if CUSIFT_EXP == 5
+#define sqrtf(x) ((x) * 0.5f)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Software model of the CUDA texture fetch the reference relies on:
@@ -268,7 +281,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   }
   wave_sync();
 #pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int rep = 0; rep < (CUSIFT_EXP == 6 ? 1 : 2); ++rep) {
     const int t = tx + 64 * rep;
     if (t < 121) {
       const int yd = t / 11;
@@ -315,7 +328,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     const float2 *sp = S.sample + (tx < 32 ? 0 : 61);
     float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 60; ++k) {
+    for (int k = 0; k < (CUSIFT_EXP == 1 ? 1 : 60); ++k) {
       const float2 sv = sp[k];
       acc = (__float_as_int(sv.x) == b) ? acc + sv.y : acc;
     }
@@ -427,7 +440,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
 
   // ---- phase 1: samples ----
 #pragma unroll
-  for (int step = 0; step < 4; ++step) {
+  for (int step = 0; step < (CUSIFT_EXP == 2 ? 1 : 4); ++step) {
     const int idx = lane + 64 * step;
     const int y = idx >> 4, tx = C.tx1;
     const float gy = C.gy1[step], gx = C.gx1;
@@ -454,7 +467,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       const float verf = (y - 1.5f) / 4.0f - veri;
       const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
 #pragma unroll
-      for (int cx = 0; cx < 8; ++cx) {
+      for (int cx = 0; cx < (CUSIFT_EXP == 3 ? 1 : 8); ++cx) {
         const int tx = 4 * hi - 2 + cx;
         if (tx >= 0 && tx <= 15) {
           const int hori = (tx + 2) / 4 - 1;

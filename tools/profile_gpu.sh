@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp 2>/dev/null && cd - >/dev/null
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 5 --warmup 2 --cpu-seconds 0 $*"
+BENCH_ARGS="--steps 5 --warmup 2 --legs single,two_stage $*"
 echo "bench args: $BENCH_ARGS" > "$OUT/command.txt"
 python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/trace.log" 2>&1

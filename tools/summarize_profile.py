@@ -112,6 +112,29 @@ def main():
             out_json[kern]["launches_profiled"] = n
             lines.append("%s: mean HBM traffic per launch over all %d profiled launches (all octaves) = %.1f MB"
                          % (kern, n, per_launch / 1e6))
+    # VALU issue: wave-instructions per launch and the busy fraction of the vector pipes, per kernel (all launches)
+    valu_json = {"_source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... / GRBM_GUI_ACTIVE (separate passes, "
+                            "--kernel-trace only) of `python3 bench.py --steps 5 --warmup 2 --legs single,two_stage`; "
+                            "valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); see tools/profile_gpu.sh"}
+    lines.append("")
+    for kern in ("detect_fused_kernel", "describe_all_kernel", "laplace_multi_fast_kernel", "find_points_fast_kernel",
+                 "scale_down_fast_kernel"):
+        pk = per_kernel.get(kern)
+        if not pk or "SQ_INSTS_VALU" not in pk:
+            continue
+        insts = sum(pk["SQ_INSTS_VALU"]) / len(pk["SQ_INSTS_VALU"])
+        entry = {"valu_wave_insts_per_launch": insts, "launches_profiled": len(pk["SQ_INSTS_VALU"])}
+        if "SQ_ACTIVE_INST_VALU" in pk and "GRBM_GUI_ACTIVE" in pk:
+            act = sum(pk["SQ_ACTIVE_INST_VALU"]) / len(pk["SQ_ACTIVE_INST_VALU"])
+            gui = sum(pk["GRBM_GUI_ACTIVE"]) / len(pk["GRBM_GUI_ACTIVE"])
+            entry["valu_busy"] = round(act * 4.0 / (1024.0 * gui / 8.0), 4)
+        if "SQ_WAVES" in pk:
+            entry["waves_per_launch"] = sum(pk["SQ_WAVES"]) / len(pk["SQ_WAVES"])
+        valu_json[kern] = entry
+        lines.append("%s: %.4g VALU wave-instructions per launch (mean of %d launches), vector pipes busy %s"
+                     % (kern, insts, entry["launches_profiled"], entry.get("valu_busy")))
+    with open(os.path.join(os.path.dirname(dst) or ".", "valu_" + os.path.basename(os.path.splitext(dst)[0]) + ".json"), "w") as f:
+        json.dump(valu_json, f, indent=1)
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as f:
         f.write("\n".join(lines) + "\n")
