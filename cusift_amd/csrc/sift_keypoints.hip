@@ -67,26 +67,46 @@ struct PatchGeom {
 
 __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
                                             float *lds, const PatchGeom &g, int pw, int ph, int lane) {
-  // rows of up to 32 columns are loaded two at a time, wider rows one at a time (wave-uniform choice)
-  const int cols = pw <= 32 ? 32 : 64;
-  const int rows_per_iter = 64 / cols;
-  const int c = lane & (cols - 1), rsub = lane / cols;
-  const int col = clampi(g.x0 + c, 0, w - 1);
+  // Everything about the patch is wave-uniform (it derives from the keypoint's fields); saying so keeps the row
+  // arithmetic -- two clamps and a multiply per row -- on the scalar unit.  Rows of up to 32 columns are loaded two at
+  // a time (lanes 32..63 take the next row), wider rows one at a time.
+  const int x0 = __builtin_amdgcn_readfirstlane(g.x0), y0 = __builtin_amdgcn_readfirstlane(g.y0);
+  pw = __builtin_amdgcn_readfirstlane(pw);
+  ph = __builtin_amdgcn_readfirstlane(ph);
+  const bool wide = pw > 32;
+  const int rpi = wide ? 1 : 2;                 // rows per load instruction
+  const int c = lane & (wide ? 63 : 31);
+  const int rsub = wide ? 0 : (lane >> 5);
+  const int voff_col = clampi(x0 + c, 0, w - 1) * 4;
+  // buffer descriptor re-based at the patch's first row: offsets stay small whatever the image size
+  const int row_first = local_row(y0, h, rw);
+  const long left = ((long)(h - row_first) * pitch) * 4;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(img + (long)row_first * pitch), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL), kBufFlags);
+  const int pitch_b = pitch * 4;
+  float *lds_lane = lds + rsub * g.stride + c;
+  const bool col_in = c < pw;
   // eight row loads in flight, then eight LDS writes (left to itself the compiler issued one load, waited for it,
   // wrote it, and only then issued the next: one full memory round trip per patch row)
   constexpr int kBatch = 8;
-  for (int r0 = rsub; r0 < ph; r0 += rows_per_iter * kBatch) {
-    float v[kBatch];
+  for (int r0 = 0; r0 < ph; r0 += rpi * kBatch) {
+    unsigned int v[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-      const int r = min(r0 + k * rows_per_iter, ph - 1);  // rows past the patch re-read its last row (not stored)
-      const int row = local_row(g.y0 + r, h, rw);
-      v[k] = img[(long)row * pitch + col];
+      const int r = r0 + k * rpi;  // wave-uniform
+      if (r < ph) {
+        const int row_a = local_row(y0 + r, h, rw);
+        const int row_b = local_row(y0 + r + 1, h, rw);  // the second half-wave's row (narrow patches only)
+        const int off_a = (row_a - row_first) * pitch_b;
+        const int d_ab = wide ? 0 : (row_b - row_a) * pitch_b;  // 0 or one pitch (rows are clamped, so non-decreasing)
+        v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_col + rsub * d_ab, off_a, 0);
+      }
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-      const int r = r0 + k * rows_per_iter;
-      if (r < ph && c < pw) lds[r * g.stride + c] = v[k];
+      const int r = r0 + k * rpi;
+      // a narrow patch with an odd row count writes one row past it: still inside the patch storage (ph <= 39 then)
+      if (r < ph && col_in) lds_lane[r * g.stride] = __builtin_bit_cast(float, v[k]);
     }
   }
 }
@@ -176,29 +196,45 @@ __device__ __forceinline__ float uniform(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
+// Where descriptor sample (row y, column tx) of the 16x16 grid lives in grad() / angraw().  The gather reads, in one
+// instruction, rows {y0 + 2j} x columns {t0 + 4i} (8 x 4 distinct samples, shared by the lanes of vertically and
+// horizontally adjacent cells).  With the plain index 16 y + tx every second of those rows falls on the same banks
+// (32 j mod 64): a 4-way conflict on each of the 36 gather reads -- PMC: half of this kernel's LDS cycles were bank
+// conflicts.  The skew 5 (y >> 1) moves row pair j to bank 37 j mod 64 = 0, 37, 10, 47, 20, 57, 30, 3: any two rows
+// either differ mod 4 or lie >= 16 banks apart, so the 32 samples of a gather read sit on 32 different banks.
+constexpr int kDescSlots = 16 * 16 + 5 * 7 + 5;  // 296
+__device__ __forceinline__ int desc_slot(int y, int tx) { return 16 * y + tx + 5 * (y >> 1); }
+
 // LDS of one keypoint wave (8.75 KB => 16 waves per CU together with the 1 KB prefix table of describe_all).
 // The descriptor's histogram buffers are only needed after its sampling phase, when the patch is dead, so they
 // live inside the patch storage.
-struct KpShared {
+struct alignas(16) KpShared {
   float hist[64];
   float gauss[11];      // orientation window; gauss[0] also carries the finished orientation to all lanes
-  union {
-    float2 sample[128];  // orientation: (bin as float bits, weight)
-    float grad[256];     // descriptor samples (the two stages never overlap in time)
-  };
-  float angraw[256];    // descriptor samples: 4/pi*atan2 + 4 (integer part = bin, fraction = weight)
+  float pad_[1];        // keeps scratch 16-byte aligned (float4 stores)
+  // shared by the two stages (they never overlap in time):
+  //   orientation: wmat() = [2 halves][8 rows][32 bins] one-hot weights of the samples being summed
+  //   descriptor : grad() / angraw() = weighted gradient magnitude and 4/pi*atan2 + 4 of the 16x16 samples, stored
+  //                at desc_slot(y, tx) -- a skewed layout, see there
+  float scratch[2 * kDescSlots];
+  __device__ __forceinline__ float *wmat() { return scratch; }
+  __device__ __forceinline__ float *grad() { return scratch; }
+  __device__ __forceinline__ float *angraw() { return scratch + kDescSlots; }
   float patch[kDescPatch * kDescPatch];
-  __device__ __forceinline__ float *hist8() { return patch; }              // 64 lanes x 9 (stride 9)
+  __device__ __forceinline__ float *hist8() { return patch; }              // [9 slots][64 lanes]: slot-major
   __device__ __forceinline__ float *fin() { return patch + 64 * 9; }       // 128
   __device__ __forceinline__ float *sums() { return patch + 64 * 9 + 128; }  // 64
 };
+static_assert(2 * kDescSlots >= 512, "the orientation stage's one-hot matrix lives in the same storage");
 static_assert(64 * 9 + 128 + 64 <= kDescPatch * kDescPatch, "histogram buffers must fit in the patch storage");
 
 // LDS of the orientation-only stage kernel
-struct OriShared {
+struct alignas(16) OriShared {
   float hist[64];
   float gauss[11];
-  float2 sample[128];
+  float pad_[1];
+  float scratch[512];
+  __device__ __forceinline__ float *wmat() { return scratch; }
   float patch[16 * 16];
 };
 
@@ -280,6 +316,8 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     }
   }
   wave_sync();
+  int sbin[2] = {0, 0};            // this lane's samples tx and tx + 64: histogram bin ...
+  float swgt[2] = {0.0f, 0.0f};    // ... and weight (sample tx + 64 exists for tx < 57)
 #pragma unroll
   for (int rep = 0; rep < (CUSIFT_EXP == 6 ? 1 : 2); ++rep) {
     const int t = tx + 64 * rep;
@@ -314,28 +352,48 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
       int bin = (int)(16.0f * sm_atan2f(dy, dx) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
       if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
       const float grad = sqrtf(dx * dx + dy * dy);
-      S.sample[t] = make_float2(__int_as_float(bin), grad * S.gauss[xd] * S.gauss[yd]);
+      sbin[rep] = bin;
+      swgt[rep] = grad * S.gauss[xd] * S.gauss[yd];
     }
   }
-  wave_sync();
   {
-    // bins are lanes (lane & 31); the lower half-wave sums samples 0..60 in index order, the upper half-wave
-    // samples 61..120, then hist = lower + upper -- the oracle accumulates in exactly this order
-    const int b = tx & 31;
-    // 60 samples per half-wave from a per-lane base, fully unrolled (immediate LDS offsets, loads in flight in
-    // batches: the rolled loop waited out one LDS round trip per sample and spent as many instructions on loop
-    // control as on the sum), then sample 60 for the lower half; adding 0.0f to a non-negative sum is exact
-    const float2 *sp = S.sample + (tx < 32 ? 0 : 61);
+    // Histogram without LDS atomics and without a compare per (bin, sample) pair.  Bins are lanes (tx & 31); the
+    // lower half-wave sums samples 0..63 in index order, the upper half-wave samples 64..120, then hist = lower +
+    // upper -- the oracle accumulates in exactly this order (the reference's LDS atomics have none).  In step k the
+    // eight lanes 8k..8k+7 -- the owners of samples 8k+r and 64+8k+r -- post their weights one-hot into an
+    // [8 rows][32 bins] matrix per half (row r, column = the sample's bin; everything else is +0), every lane adds its
+    // column's eight entries in row order, and the owners take their weights back out.  Adding +0 to a non-negative sum
+    // is exact, so each bin's sum is the sum of its own samples in index order: 64 additions per lane instead of 61
+    // compare / add / select triples.  One wave, in-order LDS: a compiler barrier is all the synchronisation needed.
+    float *W = S.wmat();
+    {
+      const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f4 *>(W + tx * 8) = z;
+      *reinterpret_cast<f4 *>(W + tx * 8 + 4) = z;
+    }
+    float *w0p = W + (tx & 7) * 32 + sbin[0];
+    float *w1p = W + 256 + (tx & 7) * 32 + sbin[1];
+    const bool has1 = tx < 57;
+    const float *col = W + (tx >> 5) * 256 + (tx & 31);
     float acc = 0.0f;
+    asm volatile("" ::: "memory");
+#pragma unroll 4
+    for (int k = 0; k < (CUSIFT_EXP == 1 ? 1 : 8); ++k) {
+      const bool owner = (tx >> 3) == k;
+      if (owner) {
+        *w0p = swgt[0];
+        if (has1) *w1p = swgt[1];
+      }
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < (CUSIFT_EXP == 1 ? 1 : 60); ++k) {
-      const float2 sv = sp[k];
-      acc = (__float_as_int(sv.x) == b) ? acc + sv.y : acc;
+      for (int r = 0; r < 8; ++r) acc += col[r * 32];
+      asm volatile("" ::: "memory");
+      if (owner) {
+        *w0p = 0.0f;
+        if (has1) *w1p = 0.0f;
+      }
     }
-    if (tx < 32) {
-      const float2 sv = S.sample[60];
-      acc = (__float_as_int(sv.x) == b) ? acc + sv.y : acc;
-    }
+    wave_sync();
     if (tx >= 32) S.hist[tx] = acc;  // hist[32 + b]: scratch until the smoothing pass overwrites it
     wave_sync();
     if (tx < 32) S.hist[tx] = acc + S.hist[tx + 32];
@@ -377,7 +435,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
 //   phase 2  gather: lane l = (cell l/4, row pair l%4) walks its 2x8 share of the 8x8 samples that reach
 //            its histogram cell, forms the same products as the reference (horizontal, vertical, then
 //            angle weight) and accumulates them into a private 8-bin LDS histogram (plain read-add-write,
-//            lane-private rows, stride 9 -> conflict free).  The reference's column-14 spill into the
+//            lane-private, slot-major [slot][lane] -> conflict free).  The reference's column-14 spill into the
 //            next row's first cell (guard `tx<=14`, cuSIFT_D.cu:243) is gathered the same way; its
 //            angle-index-8 spill (atan2f == +pi) is collected in the row's 9th slot and folded into the
 //            next linear cell in phase 3.
@@ -407,7 +465,7 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
 __device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float grad, float angraw, float wx,
                                               float wy) {
   // angraw = 4/pi*atan2 + 4 lies in [0, 8.0001] for every finite gradient and v_cvt_i32_f32 turns a NaN into 0; the
-  // unsigned min is for memory safety only (slots 0..8 exist: the histogram rows have stride 9)
+  // unsigned min is for memory safety only (slots 0..8 exist)
   const int angc = (int)angraw;
   const float angf = angraw - angc;
   const int angi = (int)min((unsigned int)angc, 8u);
@@ -420,9 +478,10 @@ __device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float 
   const int angp = (angi < 7 ? angi + 1 : 0);
   // angp != angi always, so the two read-modify-writes are independent: both reads first (one LDS round trip per
   // sample instead of two)
-  const float h1 = myhist[angi], h2 = myhist[angp];
-  myhist[angi] = h1 + v1;
-  myhist[angp] = h2 + v2;
+  // the lane's private histogram is slot-major ([slot][lane]): whatever slots the lanes pick, lane l is on bank l
+  const float h1 = myhist[angi * 64], h2 = myhist[angp * 64];
+  myhist[angi * 64] = h1 + v1;
+  myhist[angp * 64] = h2 + v2;
 }
 
 template <typename TEX>
@@ -430,7 +489,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
                                               float py, float kp_scale, float orientation, int lane, float &out0,
                                               float &out1) {
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
-  float *myhist = S.hist8() + lane * 9;
+  float *myhist = S.hist8() + lane;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
   float sina, cosa;
   sm_sincosf(theta, &sina, &cosa);  // sift_math.h
@@ -449,13 +508,14 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     const float dx = tex(xpos + cosa, ypos + sina) - tex(xpos - cosa, ypos - sina);
     const float dy = tex(xpos - sina, ypos + cosa) - tex(xpos + sina, ypos - cosa);
     const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
-    S.grad[idx] = grad;
-    S.angraw[idx] = 4.0f / 3.1415f * sm_atan2f(dy, dx) + 4.0f;
+    const int slot = desc_slot(y, tx);
+    S.grad()[slot] = grad;
+    S.angraw()[slot] = 4.0f / 3.1415f * sm_atan2f(dy, dx) + 4.0f;
   }
   wave_sync();
   // the patch is dead from here on: its storage becomes the histogram buffers
 #pragma unroll
-  for (int b = 0; b < 9; ++b) myhist[b] = 0.0f;
+  for (int b = 0; b < 9; ++b) myhist[b * 64] = 0.0f;
   wave_sync();
 
   // ---- phase 2: gather into the lane-private histogram ----
@@ -473,8 +533,8 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
           const int hori = (tx + 2) / 4 - 1;
           const float horf = (tx - 1.5f) / 4.0f - hori;
           const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
-          const int idx = y * 16 + tx;
-          gather_sample(myhist, S.grad[idx], S.angraw[idx], wx, wy);
+          const int idx = desc_slot(y, tx);
+          gather_sample(myhist, S.grad()[idx], S.angraw()[idx], wx, wy);
         }
       }
     }
@@ -489,8 +549,8 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
         const float verf = (y - 1.5f) / 4.0f - veri;
         const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
         const float horf = (14 - 1.5f) / 4.0f - 3;
-        const int idx = y * 16 + 14;
-        gather_sample(myhist, S.grad[idx], S.angraw[idx], horf, wy);
+        const int idx = desc_slot(y, 14);
+        gather_sample(myhist, S.grad()[idx], S.angraw()[idx], horf, wy);
       }
     }
   }
@@ -501,11 +561,11 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int b = lane + 64 * r;
-    const float *hc = S.hist8() + (b >> 3) * 4 * 9 + (b & 7);
-    bsum[r] = ((hc[0] + hc[9]) + hc[18]) + hc[27];
+    const float *hc = S.hist8() + (b & 7) * 64 + (b >> 3) * 4;  // bin b & 7 of the four lanes of cell b >> 3
+    bsum[r] = ((hc[0] + hc[1]) + hc[2]) + hc[3];
     if ((b & 7) == 0 && b >= 8) {  // bin 0 of cell b/8 also receives the angle-index-8 spill of the cell before it
-      const float *hp = S.hist8() + ((b >> 3) - 1) * 4 * 9 + 8;
-      bsum[r] = (((hp[0] + hp[9]) + hp[18]) + hp[27]) + bsum[r];
+      const float *hp = S.hist8() + 8 * 64 + ((b >> 3) - 1) * 4;
+      bsum[r] = (((hp[0] + hp[1]) + hp[2]) + hp[3]) + bsum[r];
     }
   }
   float b0 = bsum[0], b1 = bsum[1];
@@ -684,7 +744,9 @@ __device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, c
   finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
 }
 
-__global__ void __launch_bounds__(64) describe_all_kernel(OctaveTable T, cusift_point *__restrict__ points, int max_pts,
+// 4 waves per SIMD (<= 128 VGPRs) is what this kernel needs: its LDS read-modify-write chains and dependent taps are
+// latency that only other waves hide (forced to 3 / 2 waves the launch takes 1.25x / 1.8x as long)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) describe_all_kernel(OctaveTable T, cusift_point *__restrict__ points, int max_pts,
                                                          const unsigned int *__restrict__ counters, int n_images,
                                                          float q, float inv_q, int root_sift,
                                                          unsigned int *__restrict__ queue) {

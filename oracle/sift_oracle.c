@@ -367,8 +367,8 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
       if (bin > 31 || bin < 0) bin = 0; /* < 0 only for non-finite input (memory safety) */
       float grad = sqrtf(dx * dx + dy * dy);
       /* reference: LDS float atomicAdd in arbitrary order.  This restatement (and the HIP kernel) fixes one:
-       * samples 0..60 and 61..120 are summed separately in index order, then added. */
-      if (tx < 61) hist[bin] += grad * gauss[xd] * gauss[yd];
+       * samples 0..63 and 64..120 are summed separately in index order, then added. */
+      if (tx < 64) hist[bin] += grad * gauss[xd] * gauss[yd];
       else hist_hi[bin] += grad * gauss[xd] * gauss[yd];
     }
     for (int i = 0; i < 32; i++) hist[i] = hist[i] + hist_hi[i];
