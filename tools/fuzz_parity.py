@@ -4,9 +4,9 @@ contents, octave counts, thresholds, initial blurs, capacities and batch sizes. 
 
     python tools/fuzz_parity.py [n_cases] [seed]
 
-Checks per case: identical point sets (location / scale within 1e-3 octave px, sharpness / edgeness bit-exact),
-octave blocks coarsest first, >= 98.5 % of orientations within 1e-3 deg and of descriptors within 1e-4 L2 (small
-images have few points, so the fraction bars are a little looser than in tests/), counts saturate like the reference."""
+Checks per case, for EVERY keypoint (no tolerated fraction): identical point sets with bit-identical location, scale,
+sharpness, edgeness and orientation (NaN in the same places), octave blocks coarsest first, every finite descriptor
+within 1e-4 L2 of the oracle's, counts saturate like the reference.  Reports the largest descriptor distance seen."""
 import os
 import sys
 
@@ -42,11 +42,12 @@ def main():
     rng = np.random.default_rng(seed)
     oracle = Oracle()
     bad = 0
+    worst = 0.0
     with capi.Context(0) as ctx:
         for case in range(n_cases):
             w = int(rng.choice([4, 8, 12, 36, 64, 100, 124, 240, 244, 256, 320, 484, 500, 640, 964, 1000]))
             if rng.random() < 0.3:
-                w += int(rng.integers(1, 4))  # widths that are not multiples of 4: the generic two-stage path
+                w += int(rng.integers(1, 4))  # ragged widths: the partial last column group of the fast kernels
             h = int(rng.choice([3, 5, 9, 16, 17, 33, 64, 67, 100, 135, 240, 270, 480, 540]))
             kw = dict(num_octaves=int(rng.integers(1, 7)), init_blur=float(rng.choice([0.0, 0.5, 1.0, 1.3])),
                       peak_thresh=float(rng.choice([0.1, 0.5, 1.0, 3.0])), edge_thresh=float(rng.choice([10.0, 5.0])),
@@ -90,49 +91,17 @@ def main():
                 if np.any(np.diff(got["subsampling"]) > 0):
                     msg.append("img %d: octave blocks not coarsest first" % i)
                 a, b = canonical_order(want_all), canonical_order(got)
-                sub = a["subsampling"].astype(np.float64)
-                dxy = np.abs(a["coords2D"].astype(np.float64) - b["coords2D"].astype(np.float64)).max(axis=1) / sub
-                dsc = np.abs(a["scale"].astype(np.float64) - b["scale"].astype(np.float64)) / sub
-                if not (dxy.max() < 1e-3 and dsc.max() < 1e-3):
-                    msg.append("img %d: location/scale off by %.3g / %.3g" % (i, dxy.max(), dsc.max()))
-                    continue
-                if not (np.array_equal(a["sharpness"], b["sharpness"]) and np.array_equal(a["edgeness"], b["edgeness"])):
-                    msg.append("img %d: sharpness/edgeness differ" % i)
-                dor = ang_diff(a["orientation"].astype(np.float64), b["orientation"].astype(np.float64))
-                fin = np.isfinite(dor) & np.isfinite(a["orientation"])
-                nanmis = int((np.isnan(a["orientation"]) != np.isnan(b["orientation"])).sum())
-                if nanmis:
-                    msg.append("img %d: %d NaN-orientation mismatches" % (i, nanmis))
-                ok = fin & (dor < 1e-3)
-                slack = 2.0 / max(n, 1)
-                if fin.sum() and ok.sum() / fin.sum() < 0.985 - slack:
-                    msg.append("img %d: only %.4f of %d orientations within 1e-3" % (i, ok.sum() / fin.sum(), fin.sum()))
-                if ok.sum():
-                    l2 = np.linalg.norm(a["data"][ok].astype(np.float64) - b["data"][ok].astype(np.float64), axis=1)
-                    good = np.nan_to_num(l2, nan=0.0) < 1e-4  # NaN descriptors (flat patches) match as NaN
-                    nanm = int((np.isnan(a["data"][ok]).any(axis=1) != np.isnan(b["data"][ok]).any(axis=1)).sum())
-                    if nanm:
-                        msg.append("img %d: %d NaN-descriptor mismatches" % (i, nanm))
-                    if good.mean() < 0.985 - slack:
-                        # High-contrast content (white noise) amplifies the one chaotic element of the texture model:
-                        # a libm-ulp change of a sample position that crosses a 1/256 fraction step.  With exact
-                        # fractions (tex_frac_bits = 0) on both sides the same image must meet a tighter bar.
-                        want0 = oracle.extract(img, tex_frac_bits=0, **big)
-                        prm0 = capi.default_params(fused_detect=fused, tex_frac_bits=0, **dict(kw, max_pts=1 << 19))
-                        d0 = capi.DeviceBuffer(ctx, prm0.max_pts * 588)
-                        h0 = np.zeros(prm0.max_pts, dtype=capi.SIFT_POINT_DTYPE)
-                        n0 = ctx.extract_host(img, prm0, d0.ptr, h0)
-                        d0.free()
-                        a0, b0 = canonical_order(want0), canonical_order(h0[:n0])
-                        ok0 = ang_diff(a0["orientation"].astype(np.float64), b0["orientation"].astype(np.float64)) < 1e-3
-                        l20 = np.linalg.norm(a0["data"][ok0].astype(np.float64) - b0["data"][ok0].astype(np.float64), axis=1)
-                        g0 = (np.nan_to_num(l20, nan=0.0) < 1e-4).mean() if ok0.sum() else 1.0
-                        note = "img %d: descriptors %.4f within 1e-4 with 8-bit fractions (max %.1e), %.4f with exact ones" % (
-                            i, good.mean(), float(np.nanmax(l2)), g0)
-                        if n0 != len(want0) or g0 < 0.995 - slack or float(np.nanmax(l2)) > 3e-2:
-                            msg.append(note)
-                        else:
-                            print("     note " + note)
+                for f in ("subsampling", "coords2D", "scale", "sharpness", "edgeness", "orientation"):
+                    if not np.array_equal(a[f], b[f], equal_nan=True):
+                        msg.append("img %d: %s differs (%d of %d)" % (i, f, int((a[f] != b[f]).sum()), a[f].size))
+                fin = np.isfinite(a["data"]).all(axis=1)
+                if not np.array_equal(np.isfinite(b["data"]).all(axis=1), fin):
+                    msg.append("img %d: NaN-descriptor pattern differs" % i)
+                elif fin.any():
+                    l2 = np.linalg.norm(a["data"][fin].astype(np.float64) - b["data"][fin].astype(np.float64), axis=1)
+                    worst = max(worst, float(l2.max()))
+                    if l2.max() >= 1e-4:
+                        msg.append("img %d: %d descriptors >= 1e-4 (max %.2e)" % (i, int((l2 >= 1e-4).sum()), l2.max()))
             status = "ok " if not msg else "BAD"
             bad += bool(msg)
             print("%s case %3d: %dx%d x%d oct=%d blur=%.1f thr=%.1f edge=%.0f low=%.0f sub=%.0f max=%d fused=%d counts=%s %s"
@@ -141,7 +110,7 @@ def main():
                   flush=True)
             for bfr in (d_imgs, d_pts, d_cnt):
                 bfr.free()
-    print("%d of %d cases failed" % (bad, n_cases))
+    print("%d of %d cases failed; largest descriptor L2 distance to the oracle over all keypoints: %.3e" % (bad, n_cases, worst))
     return 1 if bad else 0
 
 

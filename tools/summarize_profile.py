@@ -19,8 +19,9 @@ from collections import defaultdict
 def short(name):
     n = name.split("(")[0]
     n = n.replace("cusift::", "").replace("void ", "")
-    if n.startswith("detect_fused_kernel"):  # template instances <true>/<false> are one kernel here
-        n = "detect_fused_kernel"
+    for k in ("detect_fused_kernel", "laplace_multi_fast_kernel"):  # template instances are one kernel here
+        if n.startswith(k):
+            n = k
     return n[:60]
 
 
@@ -34,7 +35,12 @@ def main():
     lines = []
     stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
-        lines.append("== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0) ==")
+        cmd = "python3 bench.py --steps 5 --warmup 2 --legs single,two_stage"
+        try:
+            cmd = "python3 bench.py " + open(os.path.join(src, "command.txt")).read().split(":", 1)[1].strip()
+        except Exception:
+            pass
+        lines.append("== rocprofv3 --kernel-trace --stats (%s) ==" % cmd)
         lines.append("%-62s %6s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
         for r in read_csv(stats[0]):
             lines.append("%-62s %6s %12.2f %12.2f %12.2f %7s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
@@ -133,13 +139,22 @@ def main():
         valu_json[kern] = entry
         lines.append("%s: %.4g VALU wave-instructions per launch (mean of %d launches), vector pipes busy %s"
                      % (kern, insts, entry["launches_profiled"], entry.get("valu_busy")))
-    with open(os.path.join(os.path.dirname(dst) or ".", "valu_" + os.path.basename(os.path.splitext(dst)[0]) + ".json"), "w") as f:
+    with open(os.path.join(os.path.dirname(dst) or ".", "valu.json"), "w") as f:
         json.dump(valu_json, f, indent=1)
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     with open(dst, "w") as f:
         f.write("\n".join(lines) + "\n")
     with open(os.path.splitext(dst)[0] + ".json", "w") as f:
         json.dump(out_json, f, indent=1)
+    # what bench.py reads for `roofline.traffic` / `roofline_kernels[].hbm_traffic_bytes_per_launch`
+    traffic = {"_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s`; "
+                          "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged over all launches of the kernel "
+                          "(all octaves); see %s and tools/profile_gpu.sh" % ("bench.py --steps 5 --warmup 2 --legs single,two_stage", os.path.basename(dst))}
+    for kern, v in out_json.items():
+        if "hbm_bytes_per_launch" in v:
+            traffic[kern] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches_profiled": v["launches_profiled"]}
+    with open(os.path.join(os.path.dirname(dst) or ".", "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
     print("\n".join(lines))
 
 
