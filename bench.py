@@ -528,6 +528,8 @@ def main():
             rate = B * rw * rh / (r_ms * 1e-3) / 1e6
             leg = {"workload": "%d x %dx%d (octave widths 1366, 683, 341, 170, 85: none a multiple of 4)" % (B, rw, rh),
                    "ms_per_step_single_stream": round(r_ms, 4), "Mpix_per_s_single_stream": round(rate, 1),
+                   "stage_ms_per_step": {k: round(r_st[k][0] / max(4, K // 2), 4)
+                                         for k in ("scale_down", "detect_multi", "describe_all")},
                    "detect_launches_fused": r_st["detect_multi"][1], "laplace_launches": r_st["laplace_multi"][1],
                    "keypoints_per_step": int(rex.valid_counts().sum().item())}
             if "single_stream_leg" in out:

@@ -123,6 +123,7 @@ SIGNATURES = {
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "cusift_find_homography": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, C.POINTER(_i), _vp, _vp]),
     "cusift_pack_points": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "cusift_sort_points_host": (_i, [_vp, _i]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_graph_create": (_i, [_vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_graph_launch": (_i, [_vp]),
@@ -557,6 +558,14 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def sort_points(points):
+    """cusift_sort_points_host: canonical order (octave coarsest first, then y, x, scale) of a host SiftPoint array,
+    in place; equal point sets give equal arrays."""
+    assert points.dtype == SIFT_POINT_DTYPE and points.flags["C_CONTIGUOUS"]
+    check(lib().cusift_sort_points_host(points.ctypes.data, len(points)))
+    return points
 
 
 def match_filter(points, score_threshold=999.0, ambiguity_threshold=1.0):

@@ -1108,6 +1108,24 @@ extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitc
   return CUSIFT_OK;
 }
 
+// Canonical order of extracted records (host side).  Octave blocks arrive coarsest first, but inside an octave the
+// order is that of an atomic append -- racy here as in the reference (atomicInc, cuSIFT_D.cu:512).  Callers that
+// need run-to-run identical ARRAYS (not just sets) sort: octave (coarsest first, as emitted), then y, x, scale; the
+// remaining fields break exact ties, so equal sets give equal arrays.
+extern "C" int cusift_sort_points_host(cusift_point *h_points, int num_pts) {
+  if (num_pts <= 0) return CUSIFT_OK;
+  if (!h_points) return fail(CUSIFT_ERR_INVALID, "sort: h_points is NULL");
+  std::stable_sort(h_points, h_points + num_pts, [](const cusift_point &a, const cusift_point &b) {
+    if (a.subsampling != b.subsampling) return a.subsampling > b.subsampling;
+    if (a.coords2D[1] != b.coords2D[1]) return a.coords2D[1] < b.coords2D[1];
+    if (a.coords2D[0] != b.coords2D[0]) return a.coords2D[0] < b.coords2D[0];
+    if (a.scale != b.scale) return a.scale < b.scale;
+    if (a.sharpness != b.sharpness) return a.sharpness < b.sharpness;
+    return a.orientation < b.orientation;
+  });
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
                                   int n_images, int max_pts, cusift_point *d_packed, size_t capacity,
                                   unsigned int *d_offsets) {

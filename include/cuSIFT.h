@@ -268,6 +268,17 @@ class SiftData {
       safeCall(cusift_memcpy_d2h(cusift_dropin::ctx(), h_data, d_data, sizeof(SiftPoint) * (size_t)numPts));
   }
 
+  // New (not in the reference): puts the host AND device copies into the canonical order -- octave blocks coarsest
+  // first as extracted, inside an octave by y, x, scale.  The append order inside an octave is that of an atomic
+  // counter, racy in the reference as well (atomicInc, cuSIFT_D.cu:512); sort when arrays, not just sets, must
+  // repeat from run to run.  Needs the host copy (host = true).
+  void SortCanonical() {
+    if (!h_data || numPts <= 0) return;
+    safeCall(cusift_sort_points_host(as_c(h_data), numPts));
+    if (d_data)
+      safeCall(cusift_memcpy_h2d(cusift_dropin::ctx(), d_data, h_data, sizeof(SiftPoint) * (size_t)numPts));
+  }
+
   // cuSIFT.cu:61-120: dense host image -> numPts, d_data, h_data
   void Extract(float *im, int width, int height, float subsampling = 1.0f) {
     TimerGPU timer;

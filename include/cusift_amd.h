@@ -254,6 +254,11 @@ int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sift, int num_
 int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters, int n_images,
                        int max_pts, cusift_point *d_packed, size_t capacity, unsigned int *d_offsets);
 
+/* Canonical order of extracted records, on the HOST copy: octave blocks coarsest first (as emitted), inside an octave
+ * by y, x, scale.  The append order inside an octave is that of an atomic counter -- racy in the reference as well
+ * (atomicInc, cuSIFT_D.cu:512) -- so callers that need run-to-run identical arrays, not just identical sets, sort. */
+int cusift_sort_points_host(cusift_point *h_points, int num_pts);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (BASELINE configs[3], [4]) --------------------------------
  * New functionality: the reference is single-GPU, single-image (no collective call sites).
  * A communicator wraps one ncclComm_t bound to a context: every exchange is enqueued on that context's stream.

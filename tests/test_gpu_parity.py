@@ -545,6 +545,21 @@ def test_extract_fixture_vs_reference_golden(ctx, gray1, golden_check):
     assert (dist0 < 1e-2).mean() >= 0.995
 
 
+def test_canonical_sort_makes_runs_identical_arrays(ctx, gray1):
+    """cusift_sort_points_host: the append order inside an octave is racy (as in the reference); after the canonical
+    sort two runs give byte-identical arrays, and the order is the one the tests' canonical_order() uses."""
+    runs = []
+    for _ in range(3):
+        got = gpu_extract(ctx, gray1, **REF_PARAMS).copy()
+        capi.sort_points(got)
+        runs.append(got)
+    assert runs[0].tobytes() == runs[1].tobytes() == runs[2].tobytes()
+    ref = canonical_order(runs[0])
+    for f in ("subsampling", "coords2D", "scale", "orientation"):
+        np.testing.assert_array_equal(runs[0][f], ref[f])
+    assert np.all(np.diff(runs[0]["subsampling"]) <= 0)
+
+
 def test_extract_saturates_like_the_reference(ctx, gray1):
     """maxPts=4096 as in test/detector.cpp:41: numPts == maxPts, coarse octaves complete (1555 rows)."""
     prm = dict(REF_PARAMS)
