@@ -3,7 +3,7 @@
 # purpose) into /tmp and times the single-stream leg with each; run on the GPU box:  tools/exp_describe_phases.sh
 set -u
 SRC=cusift_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-gpu-rdc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -fno-gpu-rdc"
 for v in 0 1 2 3 4 5 6; do
   /opt/rocm/bin/hipcc $FLAGS -DCUSIFT_EXP=$v -o /tmp/libexp$v.so $SRC/sift_capi.hip $SRC/sift_stencils.hip $SRC/sift_keypoints.hip \
       $SRC/sift_match.hip $SRC/sift_frontend.hip $SRC/sift_homography.hip $SRC/sift_comm.hip || exit 1
