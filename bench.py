@@ -544,6 +544,8 @@ def main():
             if world > 1:
                 out["cpu_baseline"]["note"] = "timed on rank 0's host share after the timed region (other ranks idle)"
 
+    if world > 1:
+        dist.barrier()  # the other ranks wait here while rank 0 runs its legs: communicators are torn down together
     for x in exs:
         x.close()
     if use_dist:
