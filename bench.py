@@ -204,7 +204,7 @@ def main():
 
     from cusift_amd import capi, synth
     from cusift_amd.batch import BatchExtractor, PipelinedExtractor
-    from cusift_amd.dist import SiftGatherer, make_comm
+    from cusift_amd.dist import SiftGatherer, begin_allgather, finish_allgather, make_comm
 
     # Rank 0 prints exactly ONE line on stdout.  Libraries write there too (RCCL prints a version banner on
     # communicator creation), so from here on file descriptor 1 points at stderr and the JSON line goes to a
@@ -222,6 +222,7 @@ def main():
     capi.lib()  # fail loudly if the HIP extension is missing -- there is no fallback
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    local_rank %= max(1, torch.cuda.device_count())  # rehearsals with more ranks than GPUs share devices (RCCL permitting)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_gather
@@ -259,18 +260,43 @@ def main():
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream() if use_dist else None
     gatherer = None
+    gather_impl = None
+    comm = side_ctx = None
     if use_dist:
-        side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
-        comm = make_comm(side_ctx, self_p2p=(world == 1))
-        gatherer = SiftGatherer(comm, B, args.max_pts, capacity=world * B * args.gather_capacity, device=dev, n_out=2)
+        # The exchange is the C ABI's (RCCL called from libcusift_amd.so).  It has never met more than one rank on the
+        # build box (RCCL refuses two ranks per GPU), so a failure to bring the communicator up is not allowed to cost
+        # the run: all ranks then agree to fall back to the torch.distributed twin of the same exchange, and the JSON
+        # line says which one ran (config.gather_impl).
+        err = ""
+        try:
+            side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
+            comm = make_comm(side_ctx, self_p2p=(world == 1))
+            gatherer = SiftGatherer(comm, B, args.max_pts, capacity=world * B * args.gather_capacity, device=dev, n_out=2)
+        except Exception as e:  # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            gather_impl = "C ABI (cusift_allgatherv_*): ncclAllGather of counts + one ncclGroup of ncclSend/ncclRecv"
+        else:
+            print("bench.py: C-ABI communicator unavailable (%s); using the torch.distributed exchange" % err,
+                  file=sys.stderr)
+            gatherer = None
+            gather_impl = "torch.distributed fallback (C ABI communicator failed: %s)" % (err or "on another rank")
     pending = []
     state = {"gathered": None}
     slot_free = {}  # (stream index, slot) -> event after which the slot's last gather no longer reads it
+    packer = ex.make_packer(side_stream) if (use_dist and gatherer is None) else None
 
     def finish_one():
-        key = pending.pop(0)
+        key, ticket = pending.pop(0)
         with torch.cuda.stream(side_stream):
-            state["gathered"] = gatherer.finish()
+            if gatherer is not None:
+                state["gathered"] = gatherer.finish()
+            else:
+                ac, ga, off = finish_allgather(ticket, method="p2p", packer=packer)
+                state["gathered"] = (ac, ga, off.numpy())
             done = torch.cuda.Event()
             done.record(side_stream)
         slot_free[key] = done
@@ -283,10 +309,14 @@ def main():
             # then this step's counts exchange is started
             if pending:
                 finish_one()
+            ticket = None
             with torch.cuda.stream(side_stream):
                 side_stream.wait_event(ev)
-                gatherer.begin(pts, cnt)
-            pending.append(key)
+                if gatherer is not None:
+                    gatherer.begin(pts, cnt)
+                else:
+                    ticket = begin_allgather(pts, cnt, ex.max_pts, n_images_max=B)
+            pending.append((key, ticket))
 
     def drain():
         while pending:
@@ -374,6 +404,7 @@ def main():
             "keypoints_per_step": total_kp,
         }
         if use_dist:
+            out["config"]["gather_impl"] = gather_impl
             out["config"]["rccl_library"] = capi.Comm.library()
 
     # ================================================================================================================
@@ -548,8 +579,9 @@ def main():
         dist.barrier()  # the other ranks wait here while rank 0 runs its legs: communicators are torn down together
     for x in exs:
         x.close()
-    if use_dist:
+    if comm is not None:
         comm.close()
+    if side_ctx is not None:
         side_ctx.close()
     if world > 1:
         dist.barrier()
