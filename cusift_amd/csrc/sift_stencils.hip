@@ -703,9 +703,13 @@ __device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTa
 }
 
 // refinement of one candidate from the LDS cube [plane c-1,c,c+1][row y-1,y,y+1][kCubeCols]; `col` is the
-// candidate's column inside the wave's strip.  Arithmetic: refine_and_append / oracle_find_points_multi.
-__device__ __forceinline__ void refine_from_cube(const float *cube, int col, int x, int y, int s, const FindParams &P,
-                                                 cusift_point *__restrict__ pts, int max_pts, unsigned int *counter) {
+// candidate's column inside the wave's strip.  Arithmetic: refine_and_append / oracle_find_points_multi.  Returns
+// whether the candidate passes the edge test; the record fields go to `r` (nothing is stored here: see KeyList).
+struct RefinedPoint {
+  float x, y, scale, sharpness, edgeness;
+};
+__device__ __forceinline__ bool refine_from_cube(const float *cube, int col, int x, int y, int s, const FindParams &P,
+                                                 RefinedPoint &r) {
   constexpr int RS = kCubeCols, PS = 3 * kCubeCols;
   const float *d1 = cube + PS + RS + col;  // centre plane, centre row
   const float val = d1[0];
@@ -714,7 +718,7 @@ __device__ __forceinline__ void refine_from_cube(const float *cube, int col, int
   const float dxy = 0.25f * (d1[RS + 1] + d1[-RS - 1] - d1[-RS + 1] - d1[RS - 1]);
   const float tra = dxx + dyy;
   const float det = dxx * dyy - dxy * dxy;
-  if (!(tra * tra < P.edge_limit * det)) return;
+  if (!(tra * tra < P.edge_limit * det)) return false;
   const float edge = (tra * tra) / det;
   const float dx = 0.5f * (d1[1] - d1[-1]);
   const float dy = 0.5f * (d1[RS] - d1[-RS]);
@@ -740,16 +744,65 @@ __device__ __forceinline__ void refine_from_cube(const float *cube, int col, int
     pds = ds / dss;
   }
   const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
-  const unsigned int idx = atomicAdd(counter, 1u);
-  if (idx >= (unsigned int)max_pts) return;
-  cusift_point *pt = pts + idx;
-  pt->coords2D[0] = (float)x + pdx;
-  pt->coords2D[1] = (float)y + pdy;
-  pt->scale = P.scales[s] * sm_exp2f(pds * P.factor);
-  pt->sharpness = val + dval;
-  pt->edgeness = edge;
-  pt->subsampling = P.subsampling;
+  r.x = (float)x + pdx;
+  r.y = (float)y + pdy;
+  r.scale = P.scales[s] * sm_exp2f(pds * P.factor);
+  r.sharpness = val + dval;
+  r.edgeness = edge;
+  return true;
 }
+
+// Per-wave list of refined keypoints in LDS, appended to the image's SiftData in batches.  The reference (and round 1
+// of this build) takes its output slot with one atomic per candidate (atomicInc, cuSIFT_D.cu:512): the detecting
+// wave then waits a full device-memory round trip (~1.5 us) before it can store the record and go on blurring --
+// ten times per chunk on the benchmark images, and the single largest cost on keypoint-dense ones.  Here the wave
+// parks accepted keypoints in LDS (slot = list length + rank among the accepting lanes: ballot + mbcnt, no memory
+// traffic) and takes its slots with ONE atomic per flush (list nearly full, or end of the chunk).  Same records;
+// the order inside an octave, unspecified before, is unspecified still; overflow beyond max_pts is dropped as before
+// while the counter keeps counting.
+constexpr int kKeyListCap = 128;                 // records; a flush is forced when fewer than 64 slots are free
+constexpr int kKeyListFloats = kKeyListCap * 5;  // x, y, scale, sharpness, edgeness
+
+struct KeyList {
+  float *buf;  // [kKeyListCap][5] in LDS
+  int n;       // wave-uniform
+  __device__ __forceinline__ void push(bool accept, const RefinedPoint &r) {  // called by ALL lanes (convergent)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(accept);
+    if (m == 0) return;
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (accept) {
+      float *d = buf + (n + rank) * 5;
+      d[0] = r.x;
+      d[1] = r.y;
+      d[2] = r.scale;
+      d[3] = r.sharpness;
+      d[4] = r.edgeness;
+    }
+    n += __builtin_popcountll(m);
+  }
+  __device__ __forceinline__ void flush(cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
+                                        float subsampling, int lane) {
+    if (n == 0) return;  // wave-uniform
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned int)n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's list writes have landed (one wave, in-order LDS)
+    for (int i = lane; i < n; i += 64) {
+      const unsigned int idx = base + (unsigned int)i;
+      if (idx < (unsigned int)max_pts) {
+        const float *d = buf + i * 5;
+        cusift_point *pt = pts + idx;
+        pt->coords2D[0] = d[0];
+        pt->coords2D[1] = d[1];
+        pt->scale = d[2];
+        pt->sharpness = d[3];
+        pt->edgeness = d[4];
+        pt->subsampling = subsampling;
+      }
+    }
+    n = 0;
+  }
+};
 
 template <bool kIdent0>
 __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
@@ -757,7 +810,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
                                                           int max_pts, unsigned int *__restrict__ counters,
                                                           int rows_per_wave, LaplaceTapsPk T, FindParams P,
                                                           RowWindow rw, int cy_begin, int cy_end) {
-  extern __shared__ float s_cube[];  // [waves per workgroup][9 * kCubeCols]
+  extern __shared__ float s_cube[];  // [waves per workgroup][9 * kCubeCols cube + kKeyListFloats keypoint list]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -771,7 +824,8 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
   img += (long)bz * img_stride;
   points += (long)bz * max_pts;
   unsigned int *counter = counters + bz;
-  float *cube = s_cube + wv * (9 * kCubeCols);
+  float *cube = s_cube + wv * (9 * kCubeCols + kKeyListFloats);
+  KeyList keys{cube + 9 * kCubeCols, 0};
 
   const int c0 = bx * kDetStrip - kDetHaloLanes * kBlurCols + lane * kBlurCols;
   const EdgeFix4 edge(c0, w);  // any w >= 4
@@ -897,9 +951,15 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (int j = 0; j < 4; ++j)
-            if (m & (1u << j))
-              refine_from_cube(cube, lane * 4 + j, c0 + j, y + rw.row0, s, P, points, max_pts, counter);
+          for (int j = 0; j < 4; ++j) {
+            const bool mine = (m >> j) & 1u;
+            if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;  // wave-uniform
+            RefinedPoint r;
+            bool accept = false;
+            if (mine) accept = refine_from_cube(cube, lane * 4 + j, c0 + j, y + rw.row0, s, P, r);
+            keys.push(accept, r);
+            if (keys.n > kKeyListCap - 64) keys.flush(points, max_pts, counter, P.subsampling, lane);
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
@@ -917,6 +977,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
     if (yy + 2 > yb) break;
     row_step(yy + 2, DC, DA, DB);
   }
+  keys.flush(points, max_pts, counter, P.subsampling, lane);  // what the chunk found, with one atomic
 }
 
 template __global__ void detect_fused_kernel<false>(const float *, int, int, int, long, cusift_point *, int,
