@@ -372,6 +372,107 @@ __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict_
 // Not reproduced from the reference: the per-tile candidate list that wraps at 32,
 // and the overflow path that overwrites slot maxPts-1 -- overflow is dropped here.
 // ------------------------------------------------------------------------------------------------
+struct RefinedPoint {
+  float x, y, scale, sharpness, edgeness;
+};
+
+// Per-wave list of refined keypoints in LDS, appended to the image's SiftData in batches.  The reference (and round 1
+// of this build) takes its output slot with one atomic per candidate (atomicInc, cuSIFT_D.cu:512): the detecting
+// wave then waits a full device-memory round trip (~1.5 us) before it can store the record and go on blurring --
+// ten times per chunk on the benchmark images, and the single largest cost on keypoint-dense ones.  Here the wave
+// parks accepted keypoints in LDS (slot = list length + rank among the accepting lanes: ballot + mbcnt, no memory
+// traffic) and takes its slots with ONE atomic per flush (list nearly full, or end of the chunk).  Same records;
+// the order inside an octave, unspecified before, is unspecified still; overflow beyond max_pts is dropped as before
+// while the counter keeps counting.
+constexpr int kKeyListCap = 128;                 // records; a flush is forced when fewer than 64 slots are free
+constexpr int kKeyListFloats = kKeyListCap * 5;  // x, y, scale, sharpness, edgeness
+
+struct KeyList {
+  float *buf;  // [kKeyListCap][5] in LDS
+  int n;       // wave-uniform
+  __device__ __forceinline__ void push(bool accept, const RefinedPoint &r) {  // called by ALL lanes (convergent)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(accept);
+    if (m == 0) return;
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (accept) {
+      float *d = buf + (n + rank) * 5;
+      d[0] = r.x;
+      d[1] = r.y;
+      d[2] = r.scale;
+      d[3] = r.sharpness;
+      d[4] = r.edgeness;
+    }
+    n += __builtin_popcountll(m);
+  }
+  __device__ __forceinline__ void flush(cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
+                                        float subsampling, int lane) {
+    if (n == 0) return;  // wave-uniform
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned int)n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's list writes have landed (one wave, in-order LDS)
+    for (int i = lane; i < n; i += 64) {
+      const unsigned int idx = base + (unsigned int)i;
+      if (idx < (unsigned int)max_pts) {
+        const float *d = buf + i * 5;
+        cusift_point *pt = pts + idx;
+        pt->coords2D[0] = d[0];
+        pt->coords2D[1] = d[1];
+        pt->scale = d[2];
+        pt->sharpness = d[3];
+        pt->edgeness = d[4];
+        pt->subsampling = subsampling;
+      }
+    }
+    n = 0;
+  }
+};
+
+// refinement of one candidate from the DoG planes in global memory (L2-hot): cuSIFT_D.cu:478-521, evaluated operation
+// by operation exactly as oracle_find_points_multi.  Returns whether it passes the edge test; fields go to `r`.
+__device__ __forceinline__ bool refine_from_planes(const float *__restrict__ dog, long plane, int pitch, int x, int y,
+                                                   int s, const FindParams &P, RefinedPoint &r) {
+  const float *d1 = dog + (long)(s + 1) * plane + (long)y * pitch + x;
+  const float val = d1[0];
+  const float dxx = 2.0f * val - d1[-1] - d1[1];
+  const float dyy = 2.0f * val - d1[-pitch] - d1[pitch];
+  const float dxy = 0.25f * (d1[pitch + 1] + d1[-pitch - 1] - d1[-pitch + 1] - d1[pitch - 1]);
+  const float tra = dxx + dyy;
+  const float det = dxx * dyy - dxy * dxy;
+  if (!(tra * tra < P.edge_limit * det)) return false;
+  const float edge = (tra * tra) / det;
+  const float dx = 0.5f * (d1[1] - d1[-1]);
+  const float dy = 0.5f * (d1[pitch] - d1[-pitch]);
+  const float *d0 = d1 - plane;
+  const float *d2 = d1 + plane;
+  const float ds = 0.5f * (d0[0] - d2[0]);
+  const float dss = 2.0f * val - d2[0] - d0[0];
+  const float dxs = 0.25f * (d2[1] + d0[-1] - d0[1] - d2[-1]);
+  const float dys = 0.25f * (d2[pitch] + d0[-pitch] - d2[-pitch] - d0[pitch]);
+  const float idxx = dyy * dss - dys * dys;
+  const float idxy = dys * dxs - dxy * dss;
+  const float idxs = dxy * dys - dyy * dxs;
+  const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
+  const float idyy = dxx * dss - dxs * dxs;
+  const float idys = dxy * dxs - dxx * dys;
+  const float idss = dxx * dyy - dxy * dxy;
+  float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
+  float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
+  float pds = idet * (idxs * dx + idys * dy + idss * ds);
+  if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
+    pdx = dx / dxx;
+    pdy = dy / dyy;
+    pds = ds / dss;
+  }
+  const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+  r.x = (float)x + pdx;
+  r.y = (float)y + pdy;
+  r.scale = P.scales[s] * sm_exp2f(pds * P.factor);
+  r.sharpness = val + dval;
+  r.edgeness = edge;
+  return true;
+}
+
 __device__ __forceinline__ void refine_and_append(const float *__restrict__ dog, long plane, int pitch, int x, int y,
                                                    int s, const FindParams &P, cusift_point *__restrict__ pts,
                                                    int max_pts, unsigned int *counter) {
@@ -562,6 +663,8 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
     }
   };
 
+  __shared__ float s_keys[kWavesPerBlock][kKeyListFloats];
+  KeyList keys{s_keys[wv], 0};
   f2 r0[kNumDog], r1[kNumDog], r2[kNumDog], nxt[kNumDog];
   load_row(y0 - 1, r0);
   load_row(y0, r1);
@@ -609,13 +712,16 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
       }
     }
     if (!lane_valid) cand = 0;
-    if (cand) {
+    if (__builtin_amdgcn_ballot_w64(cand != 0) != 0) {  // wave-uniform, rare
       for (int b = 0; b < 2 * kNumScales; ++b) {
-        if (cand & (1u << b)) {
-          const int x = c0 + (b & 1), s = b >> 1;
-          if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2)
-            refine_and_append(dog, plane, pitch, x, y, s, P, points, max_pts, counter);
-        }
+        const int x = c0 + (b & 1), s = b >> 1;
+        const bool mine = (cand & (1u << b)) && x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;  // wave-uniform
+        RefinedPoint r;
+        bool accept = false;
+        if (mine) accept = refine_from_planes(dog, plane, pitch, x, y, s, P, r);
+        keys.push(accept, r);
+        if (keys.n > kKeyListCap - 64) keys.flush(points, max_pts, counter, P.subsampling, lane);
       }
     }
 #pragma unroll
@@ -625,6 +731,7 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
       r2[p] = nxt[p];
     }
   }
+  keys.flush(points, max_pts, counter, P.subsampling, lane);  // what the chunk found, with one atomic (see KeyList)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,9 +812,6 @@ __device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTa
 // refinement of one candidate from the LDS cube [plane c-1,c,c+1][row y-1,y,y+1][kCubeCols]; `col` is the
 // candidate's column inside the wave's strip.  Arithmetic: refine_and_append / oracle_find_points_multi.  Returns
 // whether the candidate passes the edge test; the record fields go to `r` (nothing is stored here: see KeyList).
-struct RefinedPoint {
-  float x, y, scale, sharpness, edgeness;
-};
 __device__ __forceinline__ bool refine_from_cube(const float *cube, int col, int x, int y, int s, const FindParams &P,
                                                  RefinedPoint &r) {
   constexpr int RS = kCubeCols, PS = 3 * kCubeCols;
@@ -751,58 +855,6 @@ __device__ __forceinline__ bool refine_from_cube(const float *cube, int col, int
   r.edgeness = edge;
   return true;
 }
-
-// Per-wave list of refined keypoints in LDS, appended to the image's SiftData in batches.  The reference (and round 1
-// of this build) takes its output slot with one atomic per candidate (atomicInc, cuSIFT_D.cu:512): the detecting
-// wave then waits a full device-memory round trip (~1.5 us) before it can store the record and go on blurring --
-// ten times per chunk on the benchmark images, and the single largest cost on keypoint-dense ones.  Here the wave
-// parks accepted keypoints in LDS (slot = list length + rank among the accepting lanes: ballot + mbcnt, no memory
-// traffic) and takes its slots with ONE atomic per flush (list nearly full, or end of the chunk).  Same records;
-// the order inside an octave, unspecified before, is unspecified still; overflow beyond max_pts is dropped as before
-// while the counter keeps counting.
-constexpr int kKeyListCap = 128;                 // records; a flush is forced when fewer than 64 slots are free
-constexpr int kKeyListFloats = kKeyListCap * 5;  // x, y, scale, sharpness, edgeness
-
-struct KeyList {
-  float *buf;  // [kKeyListCap][5] in LDS
-  int n;       // wave-uniform
-  __device__ __forceinline__ void push(bool accept, const RefinedPoint &r) {  // called by ALL lanes (convergent)
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(accept);
-    if (m == 0) return;
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-    if (accept) {
-      float *d = buf + (n + rank) * 5;
-      d[0] = r.x;
-      d[1] = r.y;
-      d[2] = r.scale;
-      d[3] = r.sharpness;
-      d[4] = r.edgeness;
-    }
-    n += __builtin_popcountll(m);
-  }
-  __device__ __forceinline__ void flush(cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
-                                        float subsampling, int lane) {
-    if (n == 0) return;  // wave-uniform
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(counter, (unsigned int)n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's list writes have landed (one wave, in-order LDS)
-    for (int i = lane; i < n; i += 64) {
-      const unsigned int idx = base + (unsigned int)i;
-      if (idx < (unsigned int)max_pts) {
-        const float *d = buf + i * 5;
-        cusift_point *pt = pts + idx;
-        pt->coords2D[0] = d[0];
-        pt->coords2D[1] = d[1];
-        pt->scale = d[2];
-        pt->sharpness = d[3];
-        pt->edgeness = d[4];
-        pt->subsampling = subsampling;
-      }
-    }
-    n = 0;
-  }
-};
 
 template <bool kIdent0>
 __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
