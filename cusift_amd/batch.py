@@ -124,6 +124,7 @@ class PipelinedExtractor:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(1, n_streams) - 1)]
+            kw.setdefault("concurrent_batches", len(self.streams))  # scheduling hint: other batches fill launch tails
             self.extractors = []
             for st in self.streams:
                 with torch.cuda.stream(st):

@@ -54,6 +54,7 @@ class Params(C.Structure):
         ("tex_frac_bits", C.c_int),
         ("fused_detect", C.c_int),
         ("root_sift", C.c_int),
+        ("concurrent_batches", C.c_int),
     ]
 
 

@@ -395,6 +395,7 @@ extern "C" void cusift_default_params(cusift_params *p) {
   p->tex_frac_bits = 8;
   p->fused_detect = 1;
   p->root_sift = 0;
+  p->concurrent_batches = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -837,7 +838,8 @@ static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t 
 
 static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
                        float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
-                       unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end) {
+                       unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end,
+                       int concurrent = 1) {
   TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -858,16 +860,16 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   const int strips = idiv_up(w, 240);  // kDetStrip
   // Chunk height.  A chunk of r centre rows costs r + 2 blurred rows (+ an 8-row window fill), so tall chunks waste
   // the least arithmetic -- but the launch ends with a tail in which the last chunks run on a part-empty chip, and
-  // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work).  Measured on MI355X, 64 x 1080p
-  // (tools/ab_detect_rows.sh; r = coef * sqrt(rows * strips * images)): one stream alone is fastest at coef 0.022-0.035
-  // (1.849 / 1.824 ms per step) and loses from 0.06 on (1.877; 0.1: 1.99); with consecutive batches on two streams --
-  // the throughput mode, where the other batch's kernels fill the tail -- taller chunks win: 0.022 1.610, 0.045 1.530,
-  // 0.06 1.517, 0.08 1.505, 0.1 1.508, 0.15 1.554 ms.  0.05 keeps the single stream where it was (+0.3 %) and takes
-  // most of the two-stream gain (-5 %).
-  int rows_lo = 2, rows_hi = 56;
+  // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work): r = coef * sqrt(rows * strips *
+  // images).  Measured on MI355X, 64 x 1080p (tools/ab_detect_rows.sh, profiles/r02_ab/): a launch that has the GPU to
+  // itself is fastest at coef 0.022-0.035 and loses from 0.06 on (+2 %; 0.1: +8 %); with consecutive batches on
+  // several streams -- the throughput mode -- the other batches' kernels fill the tail and taller chunks win: two
+  // streams 0.05 -> 1.451, 0.08 -> 1.414 ms per step; four streams 0.05 -> 1.414, 0.08 -> 1.370, 0.1 -> 1.379,
+  // 0.13 -> 1.382.  The caller says which case it is (cusift_params.concurrent_batches).
+  int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 40;
   rows_bounds("DETECT", rows_lo, rows_hi);
   const double wave_rows = (double)rows_total * strips * n_images;
-  double coef = 0.05;
+  double coef = concurrent >= 2 ? 0.09 : 0.03;
   if (const char *e = getenv("CUSIFT_DETECT_ROWS_COEF")) coef = atof(e);  // tuning experiments only
   const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
   // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
@@ -1204,9 +1206,9 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     if (!flat)
       HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
     if (prm->fused_detect && !generic && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o])) {
-      TRY(cusift_detect_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o],
-                              prm->peak_thresh, prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters,
-                              n_images));
+      TRY(detect_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], prm->peak_thresh,
+                      prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters, n_images,
+                      RowWindow{0, pl.h[o]}, 0, pl.h[o], prm->concurrent_batches));
     } else {
       const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
       float *dog = ctx->dog;

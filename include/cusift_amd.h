@@ -73,6 +73,11 @@ typedef struct cusift_params {
   int root_sift;       /* 0 (default): SIFT descriptors; 1: the drivers emit RootSIFT -- ConvertSiftToRootSift
                           (cuSIFT.cu:383-395) applied in the descriptor kernel's epilogue, the fusion the reference
                           leaves as a TODO (cuSIFT.cu:122-134,376-379); same bits as extract + cusift_rootsift() */
+  int concurrent_batches; /* scheduling hint, results do not depend on it: how many extractions the caller keeps in
+                          flight on this device at once (one context + stream each).  1 (default): this call has the
+                          GPU to itself -- the detection launches use short row chunks so that their tails stay
+                          short; >= 2: other batches fill the tails, so tall chunks (less redundant blurring at chunk
+                          borders) are faster.  cusift_amd.batch.PipelinedExtractor sets it to its stream count. */
 } cusift_params;
 
 typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */

@@ -34,6 +34,7 @@ def test_binding_loads_and_reports_version():
     assert b"cusift_amd" in lib.cusift_version()
     p = capi.default_params()
     assert p.num_octaves == 5 and p.edge_thresh == 10.0 and p.tex_frac_bits == 8 and p.max_pts == 1024
+    assert p.fused_detect == 1 and p.root_sift == 0 and p.concurrent_batches == 1  # the struct's tail: layout check
 
 
 def test_point_record_is_588_bytes():
