@@ -321,7 +321,8 @@ def test_generic_kernels_on_unaligned_pitch(ctx, oracle):
     n = ctx.extract(d_src.ptr, w, h, p, prm, d_pts.ptr, h_pts)
     t = ctx.timing_read()
     ctx.timing_enable(False)
-    assert t["detect_multi"][1] == 2 and t["laplace_multi"][1] == 1 and t["describe_all"][1] == 1
+    if not os.environ.get("CUSIFT_FORCE_GENERIC"):
+        assert t["detect_multi"][1] == 2 and t["laplace_multi"][1] == 1 and t["describe_all"][1] == 1
     compare_sets(oracle.extract(img, **kw), h_pts[:n])
 
 
