@@ -1123,8 +1123,9 @@ extern "C" int cusift_sort_points_host(cusift_point *h_points, int num_pts) {
     if (a.coords2D[1] != b.coords2D[1]) return a.coords2D[1] < b.coords2D[1];
     if (a.coords2D[0] != b.coords2D[0]) return a.coords2D[0] < b.coords2D[0];
     if (a.scale != b.scale) return a.scale < b.scale;
-    if (a.sharpness != b.sharpness) return a.sharpness < b.sharpness;
-    return a.orientation < b.orientation;
+    // exact ties of location and scale (two scales of one pixel refined onto the same point): the rest of the
+    // extracted fields as BIT PATTERNS -- a total order even where an orientation is NaN (flat patch)
+    return memcmp(&a.sharpness, &b.sharpness, 3 * sizeof(float)) < 0;  // sharpness, edgeness, orientation
   });
   return CUSIFT_OK;
 }

@@ -72,3 +72,21 @@ def test_product_does_not_reference_the_oracle():
     for f in os.listdir(os.path.join(ROOT, "include")):
         text = open(os.path.join(ROOT, "include", f), errors="ignore").read()
         assert "sift_oracle" not in text, f
+
+
+def test_canonical_sort_is_a_host_function(oracle, gray1):
+    """cusift_sort_points_host needs no GPU: octave coarsest first, then y, x, scale -- the order the parity tests'
+    canonical_order() uses; a shuffled copy sorts back to the same bytes."""
+    from cusift_amd import capi
+    from parity_utils import canonical_order
+
+    pts = oracle.extract(gray1, num_octaves=4, peak_thresh=1.0, max_pts=4096).view(capi.SIFT_POINT_DTYPE).copy()
+    assert len(pts) > 500
+    rng = np.random.default_rng(1)
+    a, b = pts[rng.permutation(len(pts))].copy(), pts[rng.permutation(len(pts))].copy()
+    capi.sort_points(a)
+    capi.sort_points(b)
+    assert a.tobytes() == b.tobytes()
+    ref = canonical_order(pts)
+    for f in ("subsampling", "coords2D", "scale"):
+        np.testing.assert_array_equal(a[f], ref[f])
