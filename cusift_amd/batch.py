@@ -108,17 +108,18 @@ class PipelinedExtractor:
 
     A single launch sequence leaves the chip part-idle at times: the ScaleDown chain is HBM-bound while everything
     else is VALU-bound, and the last waves of every detection / description launch run on a nearly empty device.
-    With two batches in flight those gaps are filled by the other batch's kernels (64 x 1080p on MI355X: 1.96 ms per
-    batch on one stream, 1.72 ms on two; a third adds nothing).  Results are those of BatchExtractor.
+    With several batches in flight those gaps are filled by the other batches' kernels, and the detection can use tall
+    row chunks (cusift_params.concurrent_batches, set here to the stream count).  64 x 1080p on MI355X: 1.64 ms per
+    batch on one stream, 1.44 on two, 1.41 on four (1.38 with the chunk hint).  Results are those of BatchExtractor.
 
-        pipe = PipelinedExtractor(64, 1920, 1080, n_streams=2, num_octaves=5, init_blur=1.0, peak_thresh=3.0)
+        pipe = PipelinedExtractor(64, 1920, 1080, n_streams=4, num_octaves=5, init_blur=1.0, peak_thresh=3.0)
         for frames in source:                       # frames: float32 device tensor [n, h, pitch]
             points, counts, done = pipe.submit(frames)
             ...                                     # consume after `done` (an event) -- e.g. other_stream.wait_event(done)
     The output tensors of a submit are reused by the submit `n_streams * n_slots` calls later.
     """
 
-    def __init__(self, n_images, w, h, n_streams=2, n_slots=1, device=None, **kw):
+    def __init__(self, n_images, w, h, n_streams=4, n_slots=1, device=None, **kw):
         if not torch.cuda.is_available():
             raise capi.CusiftError("PipelinedExtractor needs a GPU (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
