@@ -28,6 +28,7 @@ leg says otherwise), `--legs` selects them:
   content    the same pipeline on other image content (`blobs`, un-pre-blurred `tile`): keypoints/step and the
              fraction of octave-0 wave-rows the threshold pre-test skips -- how much of the rate is the images
   ragged     64 x 1366x768 (no octave width is a multiple of 4): per-pixel rate next to 1080p's
+  match      MatchSiftData (section 8 row f1) on 16384 x 16384 descriptors: TFLOP/s vs the fp32 MFMA peak
   cpu        `cpu_baseline`: the CPU oracle on this box's host cores over a bounded sample; OpenCV if importable
 """
 import argparse
@@ -48,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 FP32_VALU_PEAK_TF = 157.3  # ibid. "Peak FP32 (vector)": 256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz
-ALL_LEGS = ("single", "two_stage", "host", "content", "ragged", "cpu")
+ALL_LEGS = ("single", "two_stage", "host", "content", "ragged", "match", "cpu")
 
 
 def octave_dims(w, h, n_oct):
@@ -574,6 +575,10 @@ def main():
             rex.close()
             del rimgs
 
+        # ---- matcher leg (the first caller after the path): fp32 MFMA bound ----
+        if "match" in legs:
+            out["match_leg"] = match_leg(capi, ex.ctx, 16384)
+
         if "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(w, h, dict(prm_kw), args.init_blur, args.cpu_seconds)
             if world > 1:
@@ -594,6 +599,37 @@ def main():
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+
+
+def match_leg(capi, ctx, n):
+    """MatchSiftData (cusift_match) on n x n synthetic unit descriptors: 2*n*n*128 flop per call on the exact-fp32
+    MFMA (v_mfma_f32_16x16x4_f32), priced against the fp32 matrix peak."""
+    rng = np.random.default_rng(5)
+    p = np.zeros(n, dtype=capi.SIFT_POINT_DTYPE)
+    d = np.abs(rng.normal(size=(n, 128))).astype(np.float32)
+    p["data"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    d1 = capi.DeviceBuffer.from_numpy(ctx, p)
+    d2 = capi.DeviceBuffer.from_numpy(ctx, p[::-1].copy())
+    for _ in range(3):
+        ctx.match(d1.ptr, n, d2.ptr, n, 1)
+    ctx.synchronize()
+    reps = 10
+    t = time.perf_counter()
+    for _ in range(reps):
+        ctx.match(d1.ptr, n, d2.ptr, n, 1)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    got = d1.to_numpy(capi.SIFT_POINT_DTYPE, n)
+    ok = bool((got["match"] == np.arange(n)[::-1]).all())  # every descriptor's best match is its own copy
+    d1.free()
+    d2.free()
+    tf = 2.0 * n * n * 128 / dt / 1e12
+    return {"workload": "%d x %d descriptors of 128 floats, L2 distance, best + second best per row" % (n, n),
+            "ms_per_call": round(dt * 1e3, 4), "pairs_per_s": round(n * n / dt, 1),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(tf / FP32_VALU_PEAK_TF, 4), "traffic": None,
+                         "note": "fp32 matrix peak = fp32 vector peak on gfx950 (MI355X_MICROARCH.md)"},
+            "self_match_ok": ok}
 
 
 def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp):

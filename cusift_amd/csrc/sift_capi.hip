@@ -38,7 +38,8 @@ __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_po
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int,
                                     unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
-__global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, int, MatchPartial *, int);
+template <bool kL2>
+__global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, MatchPartial *, int);
 __global__ void match_merge_kernel(cusift_point *, int, const cusift_point *, int, int, const MatchPartial *, int, int);
 __global__ void homography_gather_kernel(const cusift_point *, int, float *);
 __global__ void homography_solve_kernel(const float *, int, const int *, int, float *);
@@ -1032,8 +1033,12 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
     }
     partials = ctx->match_scratch;
   }
-  hipLaunchKernelGGL(match_kernel, dim3(row_blocks, splits), dim3(256), 0, ctx->stream, d_sift1, num_pts1, d_sift2,
-                     num_pts2, distance, cols_per_split, partials, n1_pad);
+  if (distance)
+    hipLaunchKernelGGL(match_kernel<true>, dim3(row_blocks, splits), dim3(256), 0, ctx->stream, d_sift1, num_pts1,
+                       d_sift2, num_pts2, cols_per_split, partials, n1_pad);
+  else
+    hipLaunchKernelGGL(match_kernel<false>, dim3(row_blocks, splits), dim3(256), 0, ctx->stream, d_sift1, num_pts1,
+                       d_sift2, num_pts2, cols_per_split, partials, n1_pad);
   if (splits > 1)
     hipLaunchKernelGGL(match_merge_kernel, dim3(idiv_up(num_pts1, 256)), dim3(256), 0, ctx->stream, d_sift1, num_pts1,
                        d_sift2, num_pts2, distance, partials, n1_pad, splits);

@@ -18,6 +18,10 @@
 // for exact-score near-ties (tests bound both).
 #include "sift_device.h"
 
+#ifndef CUSIFT_MATCH_EXP
+#define CUSIFT_MATCH_EXP 0  // cost-attribution experiments (tools/exp_match.sh); results are wrong on purpose when != 0
+#endif
+
 namespace cusift {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,22 +60,34 @@ __device__ __forceinline__ void write_match(cusift_point *pt, const cusift_point
 // 16-byte loads from the 588-byte records: descriptors are only 4-byte aligned
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// The same update without branches: four selects and two min/max per score.  (val NaN changes nothing, as in the
+// reference: comparisons are false and v_min/v_max return the other operand.)
+template <bool kL2>
+__device__ __forceinline__ void top2_update(float &best, float &second, int &idx, float val, int i) {
+  const bool win = kL2 ? (val < best) : (val > best);
+  const float other = kL2 ? fminf(second, val) : fmaxf(second, val);
+  second = win ? best : other;
+  idx = win ? i : idx;
+  best = kL2 ? fminf(best, val) : fmaxf(best, val);
+}
+
 // One workgroup = 64 descriptors of image 1 (16 per wave) x one contiguous range of image 2's columns
 // (blockIdx.y = column split; the host picks the number of splits so that the grid fills 256 CUs even for a few
 // thousand keypoints).  With one split the kernel writes the final fields; otherwise the (best, second, index)
 // partial of every row goes to `partials[split][row]` and match_merge_kernel folds the splits in column order.
+template <bool kL2>
 __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ sift1, int n1,
-                                                   const cusift_point *__restrict__ sift2, int n2, int l2_mode,
+                                                   const cusift_point *__restrict__ sift2, int n2,
                                                    int cols_per_split, MatchPartial *__restrict__ partials,
                                                    int n1_pad) {
   __shared__ float sB[kMatchTileCols * kBStride];
-  const bool l2 = l2_mode != 0;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int p1_base = blockIdx.x * kMatchRowsPerBlock + wv * 16;
   const int col_begin = blockIdx.y * cols_per_split;
   const int col_end = min(col_begin + cols_per_split, n2);  // padded columns (:57) can never win: skip them
+  constexpr float kInit = kL2 ? kMatchFltMax : -1.0f;       // also what a masked column scores: it changes nothing
 
   // A fragments: lane (r, g) holds elements 16u + 4g + j of descriptor p1_base + r (u = 0..7, j = 0..3)
   float a[8][4];
@@ -89,54 +105,81 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
   int bidx[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    best[q] = second[q] = l2 ? kMatchFltMax : -1.0f;
+    best[q] = second[q] = kInit;
     bidx[q] = -1;
   }
 
-  // staging: thread t moves four 16-byte chunks per tile; chunk c = t + 256 i -> descriptor c >> 5, floats 4 (c & 31)
+  // staging: thread t moves four 16-byte chunks per tile; chunk c = t + 256 i -> descriptor c >> 5, floats 4 (c & 31).
+  // Columns past col_end are read from the last valid column instead (no branch); their scores are masked below.
   f4u stage[4];
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = threadIdx.x + 256 * i;
-      const int col = c0 + (c >> 5);
-      stage[i] = (col < col_end) ? *reinterpret_cast<const f4u *>(sift2[col].data + 4 * (c & 31)) : f4u{0.f, 0.f, 0.f, 0.f};
+      const int col = min(c0 + (c >> 5), col_end - 1);
+      stage[i] = *reinterpret_cast<const f4u *>(sift2[col].data + 4 * (c & 31));
     }
   };
   if (col_begin < col_end) fetch(col_begin);
+  const float *brow = sB + r * kBStride + 4 * g;
   for (int c0 = col_begin; c0 < col_end; c0 += kMatchTileCols) {
+#if CUSIFT_MATCH_EXP != 2
     __syncthreads();  // the previous tile has been consumed
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = threadIdx.x + 256 * i;
       *reinterpret_cast<f4 *>(sB + (c >> 5) * kBStride + 4 * (c & 31)) = f4{stage[i][0], stage[i][1], stage[i][2], stage[i][3]};
     }
+#if CUSIFT_MATCH_EXP != 2
     __syncthreads();
+#endif
     if (c0 + kMatchTileCols < col_end) fetch(c0 + kMatchTileCols);  // in flight while this tile is multiplied
 
-    // two independent 16x16 accumulators (columns c0 + r and c0 + 16 + r), each a k-ordered chain
+    // two independent 16x16 accumulators (columns c0 + r and c0 + 16 + r), each a k-ordered chain; the B fragments
+    // of step u + 1 are read from LDS before the MFMAs of step u are issued
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const float *brow = sB + r * kBStride + 4 * g;
+    f4 b0 = *reinterpret_cast<const f4 *>(brow);
+    f4 b1 = *reinterpret_cast<const f4 *>(brow + 16 * kBStride);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const f4 b0 = *reinterpret_cast<const f4 *>(brow + 16 * u);
-      const f4 b1 = *reinterpret_cast<const f4 *>(brow + 16 * kBStride + 16 * u);
+      f4 n0 = b0, n1v = b1;
+      if (u < 7) {
+        n0 = *reinterpret_cast<const f4 *>(brow + 16 * (u + 1));
+        n1v = *reinterpret_cast<const f4 *>(brow + 16 * kBStride + 16 * (u + 1));
+      }
+#if CUSIFT_MATCH_EXP == 3
+      acc0 += b0 * a[u][0];
+      acc1 += b1 * a[u][1];
+#else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b0[j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b1[j], acc1, 0, 0, 0);
       }
+#endif
+      b0 = n0;
+      b1 = n1v;
     }
     // acc[q] = <descriptor p1_base + 4g + q, descriptor p2>
+#if CUSIFT_MATCH_EXP == 1
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int p2 = c0 + 16 * t + r;
-      if (p2 < col_end) {
+    for (int q = 0; q < 4; ++q) best[q] = fminf(best[q], acc0[q] + acc1[q]);
+    if (false)
+#endif
+    {
+      const bool full = c0 + kMatchTileCols <= col_end;  // wave-uniform: only a split's last tile can be partial
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int p2 = c0 + 16 * t + r;
+        const bool live = full || p2 < col_end;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float dot = t ? acc1[q] : acc0[q];
-          const float val = l2 ? (dot > -1.0f ? 2 - 2 * dot : kMatchFltMax) : dot;  // ComputeL2Distance :71-72
-          top2_scan(best[q], second[q], bidx[q], val, p2, l2);
+          // ComputeL2Distance :71-72, 2 - 2*dot (2*dot is exact, so the fused form has the same bits)
+          float val = kL2 ? (dot > -1.0f ? __builtin_fmaf(-2.0f, dot, 2.0f) : kMatchFltMax) : dot;
+          val = live ? val : kInit;
+          top2_update<kL2>(best[q], second[q], bidx[q], val, p2);
         }
       }
     }
@@ -150,8 +193,8 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
       const float os = __shfl_down(second[q], len, 16);
       const int oi = __shfl_down(bidx[q], len, 16);
       if (r < len) {
-        top2_scan(best[q], second[q], bidx[q], ob, oi, l2);
-        if (beats(os, second[q], l2)) second[q] = os;
+        top2_scan(best[q], second[q], bidx[q], ob, oi, kL2);
+        if (beats(os, second[q], kL2)) second[q] = os;
       }
     }
   }
@@ -167,11 +210,14 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
         mp.idx = bidx[q];
         partials[(size_t)blockIdx.y * n1_pad + p1] = mp;
       } else {
-        write_match(sift1 + p1, sift2, n2, best[q], second[q], bidx[q], l2);
+        write_match(sift1 + p1, sift2, n2, best[q], second[q], bidx[q], kL2);
       }
     }
   }
 }
+
+template __global__ void match_kernel<false>(cusift_point *, int, const cusift_point *, int, int, MatchPartial *, int);
+template __global__ void match_kernel<true>(cusift_point *, int, const cusift_point *, int, int, MatchPartial *, int);
 
 // Folds the column splits of one row in column order: the same update the tree applies between lanes.
 __global__ void __launch_bounds__(256) match_merge_kernel(cusift_point *__restrict__ sift1, int n1,
