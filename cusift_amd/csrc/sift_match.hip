@@ -60,15 +60,15 @@ __device__ __forceinline__ void write_match(cusift_point *pt, const cusift_point
 // 16-byte loads from the 588-byte records: descriptors are only 4-byte aligned
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// The same update without branches: four selects and two min/max per score.  (val NaN changes nothing, as in the
-// reference: comparisons are false and v_min/v_max return the other operand.)
+// The same update without branches: two compares and four selects per score (a NaN score changes nothing, as in the
+// reference: both comparisons are false).
 template <bool kL2>
 __device__ __forceinline__ void top2_update(float &best, float &second, int &idx, float val, int i) {
   const bool win = kL2 ? (val < best) : (val > best);
-  const float other = kL2 ? fminf(second, val) : fmaxf(second, val);
-  second = win ? best : other;
+  const bool place = kL2 ? (val < second) : (val > second);
+  second = win ? best : (place ? val : second);
   idx = win ? i : idx;
-  best = kL2 ? fminf(best, val) : fmaxf(best, val);
+  best = win ? val : best;
 }
 
 // One workgroup = 64 descriptors of image 1 (16 per wave) x one contiguous range of image 2's columns
@@ -110,15 +110,18 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
   }
 
   // staging: thread t moves four 16-byte chunks per tile; chunk c = t + 256 i -> descriptor c >> 5, floats 4 (c & 31).
-  // Columns past col_end are read from the last valid column instead (no branch); their scores are masked below.
-  f4u stage[4];
+  // Raw buffer loads from a descriptor based at this split's first column: the lane offset is computed once, the tile
+  // and the chunk row advance in the scalar offset, and columns past col_end read as 0 (their scores are masked below).
+  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(sift2 + col_begin), 0, (int)((col_end > col_begin ? col_end - col_begin : 0) * sizeof(cusift_point)),
+      kBufFlags);
+  constexpr int kRec = (int)sizeof(cusift_point);
+  const int voff = (int)(threadIdx.x >> 5) * kRec + (int)offsetof(cusift_point, data) + 16 * (int)(threadIdx.x & 31);
+  u4 stage[4];
   auto fetch = [&](int c0) {
+    const int soff = __builtin_amdgcn_readfirstlane((c0 - col_begin) * kRec);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = threadIdx.x + 256 * i;
-      const int col = min(c0 + (c >> 5), col_end - 1);
-      stage[i] = *reinterpret_cast<const f4u *>(sift2[col].data + 4 * (c & 31));
-    }
+    for (int i = 0; i < 4; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc2, voff, soff + 8 * i * kRec, 0);
   };
   if (col_begin < col_end) fetch(col_begin);
   const float *brow = sB + r * kBStride + 4 * g;
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = threadIdx.x + 256 * i;
-      *reinterpret_cast<f4 *>(sB + (c >> 5) * kBStride + 4 * (c & 31)) = f4{stage[i][0], stage[i][1], stage[i][2], stage[i][3]};
+      *reinterpret_cast<u4 *>(sB + (c >> 5) * kBStride + 4 * (c & 31)) = stage[i];
     }
 #if CUSIFT_MATCH_EXP != 2
     __syncthreads();
@@ -139,6 +142,7 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
     // two independent 16x16 accumulators (columns c0 + r and c0 + 16 + r), each a k-ordered chain; the B fragments
     // of step u + 1 are read from LDS before the MFMAs of step u are issued
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(1);  // a wave with MFMAs to issue goes before its SIMD's waves that are in the update
     f4 b0 = *reinterpret_cast<const f4 *>(brow);
     f4 b1 = *reinterpret_cast<const f4 *>(brow + 16 * kBStride);
 #pragma unroll
@@ -161,7 +165,9 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
       b0 = n0;
       b1 = n1v;
     }
-    // acc[q] = <descriptor p1_base + 4g + q, descriptor p2>
+    __builtin_amdgcn_s_setprio(0);
+    // acc[q] = <descriptor p1_base + 4g + q, descriptor p2>.  (Deferring this update into the next tile's MFMA gaps
+    // -- one score per step u -- was built and measured: no change, 110-112 TFLOP/s at 16k either way.)
 #if CUSIFT_MATCH_EXP == 1
 #pragma unroll
     for (int q = 0; q < 4; ++q) best[q] = fminf(best[q], acc0[q] + acc1[q]);
