@@ -117,6 +117,39 @@ def test_gpu_matcher_ragged_sizes(ctx, oracle, n1, n2):
 
 
 @pytest.mark.gpu
+def test_gpu_matcher_signed_descriptors_hit_the_l2_clamp(ctx, oracle):
+    """ComputeL2Distance writes FLT_MAX (999) where the dot product is <= -1 (extras/matching.cu:71-72).  Signed unit
+    vectors and their exact negatives reach that branch; a row whose every column is clamped keeps match = -1."""
+    rng = np.random.default_rng(41)
+    n1, n2 = 70, 95
+    d = rng.normal(size=(n1, 128)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    s1 = np.zeros(n1, dtype=SIFT_POINT_DTYPE)
+    s1["data"] = d
+    s2 = np.zeros(n2, dtype=SIFT_POINT_DTYPE)
+    e = rng.normal(size=(n2, 128)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    e[:n1:2] = -d[::2][: len(e[:n1:2])] * np.float32(1.5)  # dot = -1.5 with the row of the same index
+    s2["data"] = e
+    s2["coords2D"] = rng.uniform(0, 500, (n2, 2)).astype(np.float32)
+    for distance in (1, 0):
+        want = s1.copy()
+        oracle.match(want, s2, distance)
+        got = gpu_match(ctx, s1, s2, distance)
+        np.testing.assert_allclose(got["score"], want["score"], atol=4e-6, rtol=0)
+        np.testing.assert_array_equal(got["match"], want["match"])
+    # every column clamped: one row, all of image 2 = -2 x that row
+    one = s1[:1].copy()
+    allneg = np.zeros(40, dtype=SIFT_POINT_DTYPE)
+    allneg["data"] = -2.0 * one["data"][0]
+    want = one.copy()
+    oracle.match(want, allneg, 1)
+    got = gpu_match(ctx, one, allneg, 1)
+    assert got["match"][0] == want["match"][0] == -1
+    assert got["score"][0] == want["score"][0] == np.float32(999.0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n1,n2", [(3000, 2900), (200, 5000), (5000, 130)])
 def test_gpu_matcher_column_splits_fold_to_the_single_scan(ctx, oracle, monkeypatch, n1, n2):
     """The matcher splits image 2's columns over the grid (auto: several splits at these sizes) and folds the splits
