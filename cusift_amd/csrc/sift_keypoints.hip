@@ -13,6 +13,17 @@
 #define CUSIFT_EXP 0
 #endif
 
+// -DCUSIFT_EXP=10: phase stamps (s_memtime) of every keypoint, written into unused fields of its own record (score,
+// ambiguity, match_*, empty, coords3D) and read back by tools/exp_describe_stamps.py
+#if CUSIFT_EXP >= 10
+#define KP_STAMP(st, i)                                                  \
+  do {                                                                   \
+    if (st) (st)[i] = (unsigned int)__builtin_amdgcn_s_memtime();        \
+  } while (0)
+#else
+#define KP_STAMP(st, i) ((void)0)
+#endif
+
 namespace cusift {
 
 #if CUSIFT_EXP == 4
@@ -67,9 +78,8 @@ struct PatchGeom {
 
 __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
                                             float *lds, const PatchGeom &g, int pw, int ph, int lane) {
-  // Everything about the patch is wave-uniform (it derives from the keypoint's fields); saying so keeps the row
-  // arithmetic -- two clamps and a multiply per row -- on the scalar unit.  Rows of up to 32 columns are loaded two at
-  // a time (lanes 32..63 take the next row), wider rows one at a time.
+  // Everything about the patch is wave-uniform (it derives from the keypoint's fields).  Rows of up to 32 columns are
+  // loaded two at a time (lanes 32..63 take the next row), wider rows one at a time.
   const int x0 = __builtin_amdgcn_readfirstlane(g.x0), y0 = __builtin_amdgcn_readfirstlane(g.y0);
   pw = __builtin_amdgcn_readfirstlane(pw);
   ph = __builtin_amdgcn_readfirstlane(ph);
@@ -83,22 +93,31 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
   const long left = ((long)(h - row_first) * pitch) * 4;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void *)(img + (long)row_first * pitch), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL), kBufFlags);
-  const int pitch_b = pitch * 4;
+  // Byte offset of patch row i, computed by lane i for all rows at once (ph <= 64) and handed to the loads with
+  // v_readlane.  (Round 2 first had this on the scalar unit, row by row: two clamps and a multiply are ~22 DEPENDENT
+  // scalar instructions per load, and phase stamps showed ~350 cycles per load instruction -- 5,000 of a keypoint's
+  // 28,000 cycles.)
+#if CUSIFT_EXP == 13  // every row load reads the patch's first row (stamps only: what does a row load cost when it hits?)
+  const int row_off = 0 * lane;
+#elif CUSIFT_EXP == 14  // rows 128 bytes apart instead of one pitch apart: same number of lines, one or two pages
+  const int row_off = lane * 128;
+#else
+  const int row_off = (local_row(y0 + lane, h, rw) - row_first) * (pitch * 4);
+#endif
   float *lds_lane = lds + rsub * g.stride + c;
   const bool col_in = c < pw;
   // eight row loads in flight, then eight LDS writes (left to itself the compiler issued one load, waited for it,
   // wrote it, and only then issued the next: one full memory round trip per patch row)
-  constexpr int kBatch = 8;
+  constexpr int kBatch = 16;
   for (int r0 = 0; r0 < ph; r0 += rpi * kBatch) {
     unsigned int v[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int r = r0 + k * rpi;  // wave-uniform
       if (r < ph) {
-        const int row_a = local_row(y0 + r, h, rw);
-        const int row_b = local_row(y0 + r + 1, h, rw);  // the second half-wave's row (narrow patches only)
-        const int off_a = (row_a - row_first) * pitch_b;
-        const int d_ab = wide ? 0 : (row_b - row_a) * pitch_b;  // 0 or one pitch (rows are clamped, so non-decreasing)
+        const int off_a = __builtin_amdgcn_readlane(row_off, r);
+        // the second half-wave's row (narrow patches only): 0 or one pitch further (rows are clamped, so non-decreasing)
+        const int d_ab = __builtin_amdgcn_readlane(row_off, (r + 1) & 63) - off_a;  // times rsub: 0 in a wide patch
         v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_col + rsub * d_ab, off_a, 0);
       }
     }
@@ -203,6 +222,7 @@ __device__ __forceinline__ float uniform(float v) {
 // conflicts.  The skew 5 (y >> 1) moves row pair j to bank 37 j mod 64 = 0, 37, 10, 47, 20, 57, 30, 3: any two rows
 // either differ mod 4 or lie >= 16 banks apart, so the 32 samples of a gather read sit on 32 different banks.
 constexpr int kDescSlots = 16 * 16 + 5 * 7 + 5;  // 296
+constexpr int kAngOffset = 320;                  // >= kDescSlots, a multiple of 64
 __device__ __forceinline__ int desc_slot(int y, int tx) { return 16 * y + tx + 5 * (y >> 1); }
 
 // LDS of one keypoint wave (8.75 KB => 16 waves per CU together with the 1 KB prefix table of describe_all).
@@ -216,17 +236,22 @@ struct alignas(16) KpShared {
   //   orientation: wmat() = [2 halves][8 rows][32 bins] one-hot weights of the samples being summed
   //   descriptor : grad() / angraw() = weighted gradient magnitude and 4/pi*atan2 + 4 of the 16x16 samples, stored
   //                at desc_slot(y, tx) -- a skewed layout, see there
-  float scratch[2 * kDescSlots];
+  //                at desc_slot(y, tx) -- a skewed layout, see there; the two arrays lie kAngOffset = 5 x 64 floats
+  //                apart, so one ds_read2st64_b32 / ds_write2st64_b32 moves a sample's pair
+  float scratch[kAngOffset + kDescSlots];
   __device__ __forceinline__ float *wmat() { return scratch; }
   __device__ __forceinline__ float *grad() { return scratch; }
-  __device__ __forceinline__ float *angraw() { return scratch + kDescSlots; }
+  __device__ __forceinline__ float *angraw() { return scratch + kAngOffset; }
   float patch[kDescPatch * kDescPatch];
   __device__ __forceinline__ float *hist8() { return patch; }              // [9 slots][64 lanes]: slot-major
   __device__ __forceinline__ float *fin() { return patch + 64 * 9; }       // 128
   __device__ __forceinline__ float *sums() { return patch + 64 * 9 + 128; }  // 64
+  // per sample, next to grad() / angraw(): byte offsets of its two histogram slots (angpk(), see kp_descriptor)
+  __device__ __forceinline__ unsigned int *angpk() { return reinterpret_cast<unsigned int *>(patch + 64 * 9 + 128 + 64); }
 };
-static_assert(2 * kDescSlots >= 512, "the orientation stage's one-hot matrix lives in the same storage");
-static_assert(64 * 9 + 128 + 64 <= kDescPatch * kDescPatch, "histogram buffers must fit in the patch storage");
+static_assert(kAngOffset + kDescSlots >= 512 && kAngOffset % 64 == 0 && kAngOffset >= kDescSlots,
+              "the orientation stage's one-hot matrix lives in the same storage");
+static_assert(64 * 9 + 128 + 64 + kDescSlots <= kDescPatch * kDescPatch, "histogram buffers must fit in the patch storage");
 
 // LDS of the orientation-only stage kernel
 struct alignas(16) OriShared {
@@ -282,7 +307,8 @@ __device__ __forceinline__ float tree_sum64(float x) {
 }
 
 template <typename SH, typename TEX>
-__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
+__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx,
+                                                unsigned int *st = nullptr) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
   if (tx < 11) S.gauss[tx] = sm_expf(i2sigma2 * (tx - 5) * (tx - 5));
   const float xp = kx - 5.0f;
@@ -318,63 +344,78 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   wave_sync();
   int sbin[2] = {0, 0};            // this lane's samples tx and tx + 64: histogram bin ...
   float swgt[2] = {0.0f, 0.0f};    // ... and weight (sample tx + 64 exists for tx < 57)
+  // Both samples are computed without a branch between them (lanes 57..63 repeat sample 120; their second weight is
+  // never posted), so that the two gradient / atan2f / sqrtf chains -- each a long run of dependent operations --
+  // interleave instead of running one after the other.
+  constexpr int kReps = CUSIFT_EXP == 6 ? 1 : 2;
+  int xd[2], yd[2];
+  float dx[2], dy[2];
 #pragma unroll
-  for (int rep = 0; rep < (CUSIFT_EXP == 6 ? 1 : 2); ++rep) {
-    const int t = tx + 64 * rep;
-    if (t < 121) {
-      const int yd = t / 11;
-      const int xd = t - yd * 11;
-      float dx = 0.0f, dy = 0.0f;
-      bool done = false;
-      if constexpr (TEX::kIsPatch) {
-        if (lattice) {
-          constexpr int RS = TEX::kPatchStride;
-          // P(r, c): pixel (floor(yb) + r, floor(xb) + c) of this sample's own T(x, y) footprint origin
-          const float *P = tex.patch + e_c + (yd - 5) * RS + (xd - 5);
-          auto T = [&](int r, int c) {  // T(x + c, y + r): footprint rows r, r+1 x columns c, c+1
-            float v = w00 * P[r * RS + c];
-            v = fmaf(w10, P[r * RS + c + 1], v);
-            v = fmaf(w01, P[(r + 1) * RS + c], v);
-            v = fmaf(w11, P[(r + 1) * RS + c + 1], v);
-            return v;
-          };
-          dx = T(0, 1) - T(0, -1);
-          dy = T(1, 0) - T(-1, 0);
-          done = true;
-        }
+  for (int rep = 0; rep < kReps; ++rep) {
+    const int t = min(tx + 64 * rep, 120);
+    yd[rep] = t / 11;
+    xd[rep] = t - yd[rep] * 11;
+  }
+  bool done = false;
+  if constexpr (TEX::kIsPatch) {
+    if (lattice) {  // wave-uniform
+      constexpr int RS = TEX::kPatchStride;
+#pragma unroll
+      for (int rep = 0; rep < kReps; ++rep) {
+        // P(r, c): pixel (floor(yb) + r, floor(xb) + c) of this sample's own T(x, y) footprint origin
+        const float *P = tex.patch + e_c + (yd[rep] - 5) * RS + (xd[rep] - 5);
+        auto T = [&](int r, int c) {  // T(x + c, y + r): footprint rows r, r+1 x columns c, c+1
+          float v = w00 * P[r * RS + c];
+          v = fmaf(w10, P[r * RS + c + 1], v);
+          v = fmaf(w01, P[(r + 1) * RS + c], v);
+          v = fmaf(w11, P[(r + 1) * RS + c + 1], v);
+          return v;
+        };
+        dx[rep] = T(0, 1) - T(0, -1);
+        dy[rep] = T(1, 0) - T(-1, 0);
       }
-      if (!done) {
-        const float xf = xp + xd;
-        const float yf = yp + yd;
-        dx = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
-        dy = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
-      }
-      int bin = (int)(16.0f * sm_atan2f(dy, dx) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
-      if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
-      const float grad = sqrtf(dx * dx + dy * dy);
-      sbin[rep] = bin;
-      swgt[rep] = grad * S.gauss[xd] * S.gauss[yd];
+      done = true;
     }
   }
+  if (!done) {
+#pragma unroll
+    for (int rep = 0; rep < kReps; ++rep) {
+      const float xf = xp + xd[rep];
+      const float yf = yp + yd[rep];
+      dx[rep] = tex(xf + 1.0f, yf) - tex(xf - 1.0f, yf);
+      dy[rep] = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
+    }
+  }
+#pragma unroll
+  for (int rep = 0; rep < kReps; ++rep) {
+    int bin = (int)(16.0f * sm_atan2f(dy[rep], dx[rep]) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
+    if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
+    const float grad = sqrtf(dx[rep] * dx[rep] + dy[rep] * dy[rep]);
+    sbin[rep] = bin;
+    swgt[rep] = grad * S.gauss[xd[rep]] * S.gauss[yd[rep]];
+  }
+  KP_STAMP(st, 2);  // orientation samples done
   {
     // Histogram without LDS atomics and without a compare per (bin, sample) pair.  Bins are lanes (tx & 31); the
     // lower half-wave sums samples 0..63 in index order, the upper half-wave samples 64..120, then hist = lower +
     // upper -- the oracle accumulates in exactly this order (the reference's LDS atomics have none).  In step k the
     // eight lanes 8k..8k+7 -- the owners of samples 8k+r and 64+8k+r -- post their weights one-hot into an
-    // [8 rows][32 bins] matrix per half (row r, column = the sample's bin; everything else is +0), every lane adds its
-    // column's eight entries in row order, and the owners take their weights back out.  Adding +0 to a non-negative sum
-    // is exact, so each bin's sum is the sum of its own samples in index order: 64 additions per lane instead of 61
-    // compare / add / select triples.  One wave, in-order LDS: a compiler barrier is all the synchronisation needed.
+    // [8 rows][64 columns] matrix (row r; column = the sample's bin, + 32 for the upper half's samples; everything
+    // else is +0), every lane adds its column's eight entries in row order, and the owners take their weights back out.
+    // Adding +0 to a non-negative sum is exact, so each bin's sum is the sum of its own samples in index order: 64
+    // additions per lane instead of 61 compare / add / select triples.  Lane tx reads column tx of every row: bank tx,
+    // no conflicts, and rows are 64 dwords apart, so two rows come with one ds_read2st64_b32.  One wave, in-order LDS: a
+    // compiler barrier is all the synchronisation needed.
     float *W = S.wmat();
     {
       const f4 z = f4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f4 *>(W + tx * 8) = z;
       *reinterpret_cast<f4 *>(W + tx * 8 + 4) = z;
     }
-    float *w0p = W + (tx & 7) * 32 + sbin[0];
-    float *w1p = W + 256 + (tx & 7) * 32 + sbin[1];
+    float *w0p = W + (tx & 7) * 64 + sbin[0];
+    float *w1p = W + (tx & 7) * 64 + 32 + sbin[1];
     const bool has1 = tx < 57;
-    const float *col = W + (tx >> 5) * 256 + (tx & 31);
+    const float *col = W + tx;
     float acc = 0.0f;
     asm volatile("" ::: "memory");
 #pragma unroll 4
@@ -386,7 +427,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int r = 0; r < 8; ++r) acc += col[r * 32];
+      for (int r = 0; r < 8; ++r) acc += col[r * 64];
       asm volatile("" ::: "memory");
       if (owner) {
         *w0p = 0.0f;
@@ -399,6 +440,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     if (tx < 32) S.hist[tx] = acc + S.hist[tx + 32];
   }
   wave_sync();
+  KP_STAMP(st, 3);  // histogram done
   const int x1m = (tx >= 1 ? tx - 1 : tx + 31);
   const int x1p = (tx <= 30 ? tx + 1 : tx - 31);
   if (tx < 32) {
@@ -424,6 +466,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * mv - val1 - val2);
   const float ori = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
   wave_sync();  // every lane has read hist before the caller reuses the buffers
+  KP_STAMP(st, 4);  // smoothing, peak
   return ori;
 }
 
@@ -462,32 +505,53 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
   return c;
 }
 
-__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float grad, float angraw, float wx,
-                                              float wy) {
-  // angraw = 4/pi*atan2 + 4 lies in [0, 8.0001] for every finite gradient and v_cvt_i32_f32 turns a NaN into 0; the
-  // unsigned min is for memory safety only (slots 0..8 exist)
+// The part of the reference's accumulation that depends on the sample alone (cuSIFT_D.cu:231-236: the angle index,
+// its fraction, the neighbouring bin) is done once per sample by split_angle(), not once per visiting cell lane:
+//   angraw()[slot] <- angf, the fraction;   angpk()[slot] <- byte offsets of the two slots in a lane's slot-major
+//   histogram, (angi * 256) | (angp * 256) << 16.
+// angraw = 4/pi*atan2 + 4 lies in [0, 8.0001] for every finite gradient and v_cvt_i32_f32 turns a NaN into 0; the
+// unsigned min is for memory safety only (slots 0..8 exist).  angi == 8 (atan2f == +pi): the reference's index 8 + ...
+// is bin 0 of the NEXT linear cell; it is collected in the lane's slot 8 and folded into that cell in phase 3 -- no
+// branch and no atomic in the loop.
+__device__ __forceinline__ void split_angle(float angraw, float &angf, unsigned int &pk) {
   const int angc = (int)angraw;
-  const float angf = angraw - angc;
-  const int angi = (int)min((unsigned int)angc, 8u);
+  angf = angraw - angc;
+  const unsigned int angi = min((unsigned int)angc, 8u);
+  const unsigned int angp = (angi < 7u ? angi + 1u : 0u);
+  pk = (angi << 8) | (angp << 24);
+}
+
+__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float grad, float angf, unsigned int pk,
+                                              float wx, float wy) {
   const float grad1 = wx * grad;
   const float grad2 = wy * grad1;
   const float v1 = (1.0f - angf) * grad2;
   const float v2 = angf * grad2;
-  // angi == 8 (atan2f == +pi): the reference's index 8 + ... is bin 0 of the NEXT linear cell; it is collected in the
-  // lane's slot 8 and folded into that cell in phase 3 -- no branch and no atomic in the loop
-  const int angp = (angi < 7 ? angi + 1 : 0);
+  // the lane's private histogram is slot-major ([slot][lane]): whatever slots the lanes pick, lane l is on bank l.
   // angp != angi always, so the two read-modify-writes are independent: both reads first (one LDS round trip per
   // sample instead of two)
-  // the lane's private histogram is slot-major ([slot][lane]): whatever slots the lanes pick, lane l is on bank l
-  const float h1 = myhist[angi * 64], h2 = myhist[angp * 64];
-  myhist[angi * 64] = h1 + v1;
-  myhist[angp * 64] = h2 + v2;
+  float *p1 = reinterpret_cast<float *>(reinterpret_cast<char *>(myhist) + (pk & 0xffffu));
+  float *p2 = reinterpret_cast<float *>(reinterpret_cast<char *>(myhist) + (pk >> 16));
+  const float h1 = *p1, h2 = *p2;
+  *p1 = h1 + v1;
+  *p2 = h2 + v2;
+}
+
+// Sensitivity experiments (tools/exp_describe_ballast.sh): 200 extra independent v_fma_f32 per keypoint, placed in the
+// sampling phase (CUSIFT_EXP == 7), in the gather (8) or at the end of the keypoint (9)
+__device__ __forceinline__ void valu_ballast(float &sink) {
+  float a = sink, b = sink + 1.0f, c = sink + 2.0f, d = sink + 3.0f;
+#pragma unroll
+  for (int i = 0; i < 50; ++i)
+    asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  sink = (a + b) + (c + d);
 }
 
 template <typename TEX>
 __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const DescLaneConsts &C, float px,
                                               float py, float kp_scale, float orientation, int lane, float &out0,
-                                              float &out1) {
+                                              float &out1, unsigned int *st = nullptr) {
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
   float *myhist = S.hist8() + lane;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
@@ -512,13 +576,34 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     S.grad()[slot] = grad;
     S.angraw()[slot] = 4.0f / 3.1415f * sm_atan2f(dy, dx) + 4.0f;
   }
+#if CUSIFT_EXP == 7
+  {
+    float sink = px;
+    valu_ballast(sink);
+    if (sink == 12345.678f) S.grad()[0] = sink;
+  }
+#endif
   wave_sync();
-  // the patch is dead from here on: its storage becomes the histogram buffers
+  KP_STAMP(st, 5);  // descriptor samples done
+  // the patch is dead from here on: its storage becomes the histogram buffers and the samples' slot offsets
 #pragma unroll
   for (int b = 0; b < 9; ++b) myhist[b * 64] = 0.0f;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int slot = desc_slot((lane >> 4) + 4 * step, C.tx1);
+    float angf;
+    unsigned int pk;
+    split_angle(S.angraw()[slot], angf, pk);
+    S.angraw()[slot] = angf;
+    S.angpk()[slot] = pk;
+  }
   wave_sync();
+  KP_STAMP(st, 6);  // angle split done
 
   // ---- phase 2: gather into the lane-private histogram ----
+  // Four samples of a row are read first, then accumulated: the compiler cannot move a sample read above the
+  // previous sample's histogram write (a run-time address), and left alone every visit paid two dependent LDS round
+  // trips -- read the sample, then read-modify-write its slots.
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int y = 4 * vi - 2 + 2 * kq + r;
@@ -527,18 +612,38 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       const float verf = (y - 1.5f) / 4.0f - veri;
       const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
 #pragma unroll
-      for (int cx = 0; cx < (CUSIFT_EXP == 3 ? 1 : 8); ++cx) {
-        const int tx = 4 * hi - 2 + cx;
-        if (tx >= 0 && tx <= 15) {
-          const int hori = (tx + 2) / 4 - 1;
-          const float horf = (tx - 1.5f) / 4.0f - hori;
-          const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
-          const int idx = desc_slot(y, tx);
-          gather_sample(myhist, S.grad()[idx], S.angraw()[idx], wx, wy);
+      for (int half = 0; half < (CUSIFT_EXP == 3 ? 1 : 2); ++half) {  // four samples at a time: register budget
+        float sg[4], sf[4];
+        unsigned int sp[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int tx = 4 * hi - 2 + 4 * half + c;
+          const int idx = desc_slot(y, clampi(tx, 0, 15));  // the row's edge cells read a valid slot and skip the add
+          sg[c] = S.grad()[idx];
+          sf[c] = S.angraw()[idx];
+          sp[c] = S.angpk()[idx];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int tx = 4 * hi - 2 + 4 * half + c;
+          if (tx >= 0 && tx <= 15) {
+            const int hori = (tx + 2) / 4 - 1;
+            const float horf = (tx - 1.5f) / 4.0f - hori;
+            const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
+            gather_sample(myhist, sg[c], sf[c], sp[c], wx, wy);
+          }
         }
       }
     }
   }
+#if CUSIFT_EXP == 8
+  {
+    float sink = px;
+    valu_ballast(sink);
+    if (sink == 12345.678f) myhist[0] = sink;
+  }
+#endif
   if (hi == 0 && vi >= 1) {
     // the reference's right-hand adds of column 14 (hori+1 == 4) land in cell (row+1, 0)
 #pragma unroll
@@ -550,11 +655,12 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
         const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
         const float horf = (14 - 1.5f) / 4.0f - 3;
         const int idx = desc_slot(y, 14);
-        gather_sample(myhist, S.grad()[idx], S.angraw()[idx], horf, wy);
+        gather_sample(myhist, S.grad()[idx], S.angraw()[idx], S.angpk()[idx], horf, wy);
       }
     }
   }
   wave_sync();
+  KP_STAMP(st, 7);  // gather done
 
   // ---- phase 3: cell sums (fixed order) and normalisation ----
   float bsum[2];
@@ -580,6 +686,14 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       if (b1 > 0.2f) b1 = 0.2f;
     }
   }
+#if CUSIFT_EXP == 9
+  {
+    float sink = px;
+    valu_ballast(sink);
+    if (sink == 12345.678f) b0 = sink;
+  }
+#endif
+  KP_STAMP(st, 8);  // cell sums, normalisation
   out0 = b0;
   out1 = b1;
 }
@@ -661,8 +775,13 @@ __device__ __forceinline__ void finish_descriptor(KpShared &S, cusift_point *pt,
     wave_sync();
     rootsift_lanes(v, lane, b0, b1);
   }
-  pt->data[lane] = b0;
-  pt->data[lane + 64] = b1;
+#if CUSIFT_EXP == 12
+  if (b0 == 12345.0f)
+#endif
+  {
+    pt->data[lane] = b0;
+    pt->data[lane + 64] = b1;
+  }
   if (lane == 0) {
     pt->coords2D[0] = px * sub;
     pt->coords2D[1] = py * sub;
@@ -736,10 +855,10 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
 template <typename TEX>
 __device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, const DescLaneConsts &C,
                                                   cusift_point *pt, float px, float py, float kscale, float sub,
-                                                  int lane, int root_sift) {
-  const float ori = kp_orientation(S, tex, px, py, kscale, lane);
+                                                  int lane, int root_sift, unsigned int *st = nullptr) {
+  const float ori = kp_orientation(S, tex, px, py, kscale, lane, st);
   float b0, b1;
-  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
+  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1, st);
   if (lane == 0) pt->orientation = ori;
   finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
 }
@@ -778,21 +897,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // with a static interleaving the launch waited for the unluckiest wave.
   // One cursor would serialise ~170 k same-address atomics (~12 ns each: measured 2.4x slower than no queue at all),
   // so the items are dealt into kQueueShards interleaved sub-sequences, each with a cursor on a cache line of its own.
+  // The record of the NEXT item (position, scale, subsampling: four floats behind one memory round trip) is fetched
+  // while the current one is described -- its index arrives with the cursor's atomic, long before the current
+  // keypoint is finished -- so a keypoint starts with its patch loads instead of with a wait for its own record.
   int im = 0;  // image of the current item; a workgroup sees increasing items, so the cursor only moves forward
   const unsigned int shard = blockIdx.x & (kQueueShards - 1);
   unsigned int *cursor = queue + shard * 32;                 // 128-byte stride
   const unsigned int per_shard = gridDim.x / kQueueShards;   // workgroups per shard (host: gridDim.x % shards == 0)
   unsigned int g = blockIdx.x;                               // = shard + kQueueShards * (blockIdx.x / kQueueShards)
+  auto locate = [&](unsigned int item) {  // item < total; moves `im` forward to the item's image
+    while (__builtin_amdgcn_readfirstlane(s_prefix[im + 1]) <= item) ++im;  // ends: item < total = s_prefix[n_images]
+    return points + (long)im * max_pts + (item - __builtin_amdgcn_readfirstlane(s_prefix[im]));
+  };
+  // lane l < 16 holds float l of the record's head (coords2D, scale, ..., subsampling = float 12): one register
+  constexpr int kSubIndex = (int)(offsetof(cusift_point, subsampling) / sizeof(float));
+  static_assert(kSubIndex < 16 && offsetof(cusift_point, scale) == 8, "record head layout");
+  cusift_point *pt = nullptr;
+  float rec = 0.0f;
+  auto fetch_head = [&](const cusift_point *p) { return reinterpret_cast<const float *>(p)[lane & 15]; };
+  auto head = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec), i)); };
+  if (g < total) {
+    pt = locate(g);
+    rec = fetch_head(pt);
+  }
   while (g < total) {
+#if CUSIFT_EXP >= 10
+    unsigned int stamps[11] = {};
+    unsigned int *st = stamps;
+#else
+    unsigned int *st = nullptr;
+#endif
+    KP_STAMP(st, 0);
     unsigned int nxt = 0;
     if (lane == 0) nxt = shard + kQueueShards * (atomicAdd(cursor, 1u) + per_shard);
-    while (__builtin_amdgcn_readfirstlane(s_prefix[im + 1]) <= g) ++im;  // ends: g < total = s_prefix[n_images]
-    cusift_point *pt = points + (long)im * max_pts + (g - __builtin_amdgcn_readfirstlane(s_prefix[im]));
-    const float px = uniform(pt->coords2D[0]), py = uniform(pt->coords2D[1]);
-    const float kscale = uniform(pt->scale), sub = uniform(pt->subsampling);
+    const float px = head(0), py = head(1), kscale = head(2), sub = head(kSubIndex);
+    const int im_cur = im;
     int o = ((__float_as_int(sub) >> 23) & 0xff) - exp0;  // subsampling = sub0 * 2^octave
     o = clampi(o, 0, T.n_oct - 1);
-    const float *img = T.base[o] + (long)im * T.stride[o];
+    const float *img = T.base[o] + (long)im_cur * T.stride[o];
     const int w = T.w[o], h = T.h[o], pitch = T.pitch[o];
     const RowWindow rw{0, h};
     // one patch for both stages: orientation taps reach 6 px, descriptor taps 7.5*spacing*sqrt(2)+1 at most
@@ -800,19 +942,50 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     PatchGeom pg;
     int pw, ph;
     const bool use_patch = patch_for_reach(px, py, reach, pg, pw, ph);
+    KP_STAMP(st, 10);  // record read, geometry known
+    if (use_patch) stage_patch(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
+    wave_sync();
+    KP_STAMP(st, 1);  // patch staged
+    // the patch loads have been waited for, so has the atomic issued before them: fetch the next record now.
+    // (Tried on top of this and dropped, tools/exp_describe_stamps.sh: forming the next keypoint's geometry between the
+    // stages -- the ~600 cycles it saves here come back, and more, in the descriptor stage; touching the next patch's
+    // lines with two LDS-DMA loads so that they are in L2 by the time they are staged -- no gain.)
+    g = __builtin_amdgcn_readfirstlane(nxt);
+    cusift_point *pt_next = nullptr;
+    if (g < total) {
+      pt_next = locate(g);
+      rec = fetch_head(pt_next);
+    }
     if (use_patch) {
-      stage_patch(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
       if (q > 0.0f)
         describe_keypoint(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
-                          sub, lane, root_sift);
+                          sub, lane, root_sift, st);
       else
         describe_keypoint(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
-                          sub, lane, root_sift);
+                          sub, lane, root_sift, st);
     } else {
-      describe_keypoint(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift);
+      describe_keypoint(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift,
+                        st);
     }
     wave_sync();
-    g = __builtin_amdgcn_readfirstlane(nxt);
+#if CUSIFT_EXP >= 10
+    KP_STAMP(st, 9);
+    if (lane == 0) {  // durations of the nine segments, in shader cycles
+      float *f = &pt->score;
+      f[0] = (float)(stamps[1] - stamps[0]);      // score: record + patch staging
+      f[1] = (float)(stamps[2] - stamps[1]);      // ambiguity: orientation samples
+      pt->match_xpos = (float)(stamps[3] - stamps[2]);   // orientation histogram
+      pt->match_ypos = (float)(stamps[4] - stamps[3]);   // smoothing + peak
+      pt->match_error = (float)(stamps[5] - stamps[4]);  // descriptor samples (incl. sincos)
+      pt->empty[0] = (float)(stamps[6] - stamps[5]);     // angle split + histogram zeroing
+      pt->empty[1] = (float)(stamps[7] - stamps[6]);     // gather
+      pt->empty[2] = (float)(stamps[8] - stamps[7]);     // cell sums + normalisation
+      pt->coords3D[0] = (float)(stamps[9] - stamps[8]);  // record stores
+      pt->coords3D[1] = (float)(stamps[10] - stamps[0]);  // of the first segment: until the geometry is known
+      pt->coords3D[2] = (float)(pw * 100 + ph);
+    }
+#endif
+    pt = pt_next;
   }
 }
 
