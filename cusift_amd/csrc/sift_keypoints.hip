@@ -95,8 +95,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
       (void *)(img + (long)row_first * pitch), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL), kBufFlags);
   // Byte offset of patch row i, computed by lane i for all rows at once (ph <= 64) and handed to the loads with
   // v_readlane.  (Round 2 first had this on the scalar unit, row by row: two clamps and a multiply are ~22 DEPENDENT
-  // scalar instructions per load, and phase stamps showed ~350 cycles per load instruction -- 5,000 of a keypoint's
-  // 28,000 cycles.)
+  // scalar instructions per load, and phase stamps showed ~350 cycles per load instruction.)
 #if CUSIFT_EXP == 13  // every row load reads the patch's first row (stamps only: what does a row load cost when it hits?)
   const int row_off = 0 * lane;
 #elif CUSIFT_EXP == 14  // rows 128 bytes apart instead of one pitch apart: same number of lines, one or two pages
@@ -106,7 +105,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
 #endif
   float *lds_lane = lds + rsub * g.stride + c;
   const bool col_in = c < pw;
-  // eight row loads in flight, then eight LDS writes (left to itself the compiler issued one load, waited for it,
+  // sixteen row loads in flight, then their LDS writes (left to itself the compiler issued one load, waited for it,
   // wrote it, and only then issued the next: one full memory round trip per patch row)
   constexpr int kBatch = 16;
   for (int r0 = 0; r0 < ph; r0 += rpi * kBatch) {
@@ -116,16 +115,17 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
       const int r = r0 + k * rpi;  // wave-uniform
       if (r < ph) {
         const int off_a = __builtin_amdgcn_readlane(row_off, r);
-        // the second half-wave's row (narrow patches only): 0 or one pitch further (rows are clamped, so non-decreasing)
         const int d_ab = __builtin_amdgcn_readlane(row_off, (r + 1) & 63) - off_a;  // times rsub: 0 in a wide patch
         v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_col + rsub * d_ab, off_a, 0);
       }
     }
+    if (col_in) {  // one exec mask around all the writes, wave-uniform row tests inside
 #pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int r = r0 + k * rpi;
-      // a narrow patch with an odd row count writes one row past it: still inside the patch storage (ph <= 39 then)
-      if (r < ph && col_in) lds_lane[r * g.stride] = __builtin_bit_cast(float, v[k]);
+      for (int k = 0; k < kBatch; ++k) {
+        const int r = r0 + k * rpi;
+        // a narrow patch with an odd row count writes one row past it: still inside the patch storage (ph <= 39 then)
+        if (r < ph) lds_lane[r * g.stride] = __builtin_bit_cast(float, v[k]);
+      }
     }
   }
 }
@@ -258,7 +258,7 @@ struct alignas(16) OriShared {
   float hist[64];
   float gauss[11];
   float pad_[1];
-  float scratch[512];
+  float scratch[512 + 64];  // the one-hot matrix + one junk word per lane (kp_orientation)
   __device__ __forceinline__ float *wmat() { return scratch; }
   float patch[16 * 16];
 };
@@ -416,23 +416,26 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     float *w1p = W + (tx & 7) * 64 + 32 + sbin[1];
     const bool has1 = tx < 57;
     const float *col = W + tx;
+    // No branches in the loop: a lane that does not own a sample of step k writes to a word of its own behind the
+    // matrix instead (storage the stage does not use).  With the exec-mask branches of `if (owner)` every step was
+    // three basic blocks and its LDS round trip could not overlap the additions of the step before.
+    float *junk = W + 512 + tx;
+    static_assert(kAngOffset + kDescSlots >= 512 + 64, "the junk words live behind the one-hot matrix");
     float acc = 0.0f;
     asm volatile("" ::: "memory");
 #pragma unroll 4
     for (int k = 0; k < (CUSIFT_EXP == 1 ? 1 : 8); ++k) {
       const bool owner = (tx >> 3) == k;
-      if (owner) {
-        *w0p = swgt[0];
-        if (has1) *w1p = swgt[1];
-      }
+      float *p0 = owner ? w0p : junk;
+      float *p1 = (owner && has1) ? w1p : junk;
+      *p0 = swgt[0];
+      *p1 = swgt[1];
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 8; ++r) acc += col[r * 64];
       asm volatile("" ::: "memory");
-      if (owner) {
-        *w0p = 0.0f;
-        if (has1) *w1p = 0.0f;
-      }
+      *p0 = 0.0f;
+      *p1 = 0.0f;
     }
     wave_sync();
     if (tx >= 32) S.hist[tx] = acc;  // hist[32 + b]: scratch until the smoothing pass overwrites it
