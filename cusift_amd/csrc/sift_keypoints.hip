@@ -78,24 +78,25 @@ struct PatchGeom {
 
 __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
                                             float *lds, const PatchGeom &g, int pw, int ph, int lane) {
-  // Everything about the patch is wave-uniform (it derives from the keypoint's fields).  Rows of up to 32 columns are
-  // loaded two at a time (lanes 32..63 take the next row), wider rows one at a time.
+  // Everything about the patch is wave-uniform (it derives from the keypoint's fields).  One instruction per patch
+  // row, lane = column, written by the memory pipeline straight into LDS (`buffer_load_dword ... lds`: LDS address =
+  // M0 + 4 * lane, lanes at or beyond the patch width masked off): no staging registers, so ALL rows of the patch are
+  // in flight at once and nothing but one vmcnt(0) stands between the last load and the first tap.
+  // History (phase stamps, tools/exp_describe_stamps.sh; 64 x 1080p, cycles per keypoint in this function):
+  //   row arithmetic on the scalar unit, 8 loads in flight, register staging + ds_write   5,450
+  //   row offsets by lane + v_readlane, 16 in flight                                      4,380
+  //   LDS-DMA                                                                             3,580   (wide patches: 9,700 -> 4,300)
   const int x0 = __builtin_amdgcn_readfirstlane(g.x0), y0 = __builtin_amdgcn_readfirstlane(g.y0);
   pw = __builtin_amdgcn_readfirstlane(pw);
   ph = __builtin_amdgcn_readfirstlane(ph);
-  const bool wide = pw > 32;
-  const int rpi = wide ? 1 : 2;                 // rows per load instruction
-  const int c = lane & (wide ? 63 : 31);
-  const int rsub = wide ? 0 : (lane >> 5);
-  const int voff_col = clampi(x0 + c, 0, w - 1) * 4;
+  const int voff = clampi(x0 + lane, 0, w - 1) * 4;
   // buffer descriptor re-based at the patch's first row: offsets stay small whatever the image size
   const int row_first = local_row(y0, h, rw);
   const long left = ((long)(h - row_first) * pitch) * 4;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void *)(img + (long)row_first * pitch), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL), kBufFlags);
-  // Byte offset of patch row i, computed by lane i for all rows at once (ph <= 64) and handed to the loads with
-  // v_readlane.  (Round 2 first had this on the scalar unit, row by row: two clamps and a multiply are ~22 DEPENDENT
-  // scalar instructions per load, and phase stamps showed ~350 cycles per load instruction.)
+  // byte offset of patch row i, computed by lane i for all rows at once (ph <= 64) and handed to the loads with
+  // v_readlane (on the scalar unit the two clamps and the multiply are ~22 dependent instructions per row)
 #if CUSIFT_EXP == 13  // every row load reads the patch's first row (stamps only: what does a row load cost when it hits?)
   const int row_off = 0 * lane;
 #elif CUSIFT_EXP == 14  // rows 128 bytes apart instead of one pitch apart: same number of lines, one or two pages
@@ -103,31 +104,14 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
 #else
   const int row_off = (local_row(y0 + lane, h, rw) - row_first) * (pitch * 4);
 #endif
-  float *lds_lane = lds + rsub * g.stride + c;
-  const bool col_in = c < pw;
-  // sixteen row loads in flight, then their LDS writes (left to itself the compiler issued one load, waited for it,
-  // wrote it, and only then issued the next: one full memory round trip per patch row)
-  constexpr int kBatch = 16;
-  for (int r0 = 0; r0 < ph; r0 += rpi * kBatch) {
-    unsigned int v[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int r = r0 + k * rpi;  // wave-uniform
-      if (r < ph) {
-        const int off_a = __builtin_amdgcn_readlane(row_off, r);
-        const int d_ab = __builtin_amdgcn_readlane(row_off, (r + 1) & 63) - off_a;  // times rsub: 0 in a wide patch
-        v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_col + rsub * d_ab, off_a, 0);
-      }
-    }
-    if (col_in) {  // one exec mask around all the writes, wave-uniform row tests inside
-#pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        const int r = r0 + k * rpi;
-        // a narrow patch with an odd row count writes one row past it: still inside the patch storage (ph <= 39 then)
-        if (r < ph) lds_lane[r * g.stride] = __builtin_bit_cast(float, v[k]);
-      }
+  if (lane < pw) {
+    for (int r = 0; r < ph; ++r) {
+      const int off = __builtin_amdgcn_readlane(row_off, r);
+      auto *dst = (__attribute__((address_space(3))) void *)(lds + r * g.stride);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voff, off, 0, 0);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch is in LDS (this also waits for the wave's older stores)
 }
 
 // (1-a)(1-b), a(1-b), (1-a)b, ab of the texture model.
