@@ -529,9 +529,9 @@ extern "C" int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, i
   const std::string k(kernel);
   int n = 0, t = 256;
   hipError_t e = hipErrorInvalidValue;
-  if (k == "detect_fused")  // single-wave workgroups, 9 KB refinement cube each
+  if (k == "detect_fused")  // single-wave workgroups, a 10.5 KB candidate list each
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false>, t = 64,
-                                                     (9 * 256 + 128 * 5) * sizeof(float));
+                                                     kDetectWaveLdsFloats * sizeof(float));
   else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel<0>, t, 0);
   else if (k == "find_points") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, find_points_fast_kernel, t, 0);
   else if (k == "scale_down") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scale_down_fast_kernel, t, 0);
@@ -879,7 +879,7 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   int wpb = 1;
   if (const char *e = getenv("CUSIFT_DETECT_WAVES")) wpb = std::max(1, std::min(4, atoi(e)));  // experiments only
   dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), wpb), n_images);
-  const size_t cube_bytes = (size_t)wpb * (9 * 256 + 128 * 5) * sizeof(float);  // kCubeCols = 256 + kKeyListFloats
+  const size_t cube_bytes = (size_t)wpb * kDetectWaveLdsFloats * sizeof(float);  // the wave's candidate list
   // levels 0 and 1 both identity (initBlur >= their sigma)?  then the kernel passes them through
   bool ident0 = true;
   for (int lv = 0; lv < 2; ++lv)

@@ -12,6 +12,8 @@
 //  * Arithmetic follows oracle/sift_oracle.c operation by operation (explicit fmaf chains in the
 //    filters, nothing else fused: this file is built with -ffp-contract=off); transcendental functions are
 //    the written-out ones of sift_math.h, which the oracle compiles too.
+#include <type_traits>
+
 #include "sift_device.h"
 
 namespace cusift {
@@ -753,9 +755,21 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
 //     cube, so the detecting lane can read its 3x3x3 neighbourhood (incl. neighbour lanes' columns) with
 //     the same code as the unfused kernel reads it from global memory.
 // ------------------------------------------------------------------------------------------------
+// -DCUSIFT_DET_STAMPS=1 (fill and total only) / =2 (per row: intrusive, 3x slower): s_memtime attribution of a wave's cycles (tools/exp_detect_stamps.sh); sums over all waves in
+// g_det_cycles = {window fill, blur + DoG, pre-test + extrema analysis, refinement + key list, window shift (waits for
+// the row loaded two steps ago), wave total, wave-rows, waves}
+#ifdef CUSIFT_DET_STAMPS
+constexpr int kDetLogWaves = 1 << 17;
+__device__ unsigned int g_det_log[kDetLogWaves][8];  // one row per wave of the LAST launch (slot = linear block index)
+#define DET_NOW() ((unsigned int)__builtin_amdgcn_s_memtime())
+#endif
+
 constexpr int kDetHaloLanes = 2;
 constexpr int kDetStrip = (64 - 2 * kDetHaloLanes) * kBlurCols;  // 240 columns of extremum centres per wave
 constexpr int kCubeCols = 64 * kBlurCols;                        // 256 floats per cube row
+constexpr int kCandWords = 21;                                   // 19 DoG values, x, (y << 3) | scale index
+constexpr int kCandCap = 128;                                    // < 64 waiting + at most 64 pushed at a time
+static_assert(kCandCap * kCandWords == kDetectWaveLdsFloats, "host and kernel agree on the LDS size");
 
 // kIdent0: levels 0 and 1 have identity taps (initBlur >= their sigma: the "var <= 1e-6 => identity" rule, e.g.
 // octave 0 of the initBlur = 1.0 configuration).  1*c and fma(0, x, c) are exact for finite x, so the pair is
@@ -809,29 +823,26 @@ __device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTa
   }
 }
 
-// refinement of one candidate from the LDS cube [plane c-1,c,c+1][row y-1,y,y+1][kCubeCols]; `col` is the
-// candidate's column inside the wave's strip.  Arithmetic: refine_and_append / oracle_find_points_multi.  Returns
-// whether the candidate passes the edge test; the record fields go to `r` (nothing is stored here: see KeyList).
-__device__ __forceinline__ bool refine_from_cube(const float *cube, int col, int x, int y, int s, const FindParams &P,
-                                                 RefinedPoint &r) {
-  constexpr int RS = kCubeCols, PS = 3 * kCubeCols;
-  const float *d1 = cube + PS + RS + col;  // centre plane, centre row
-  const float val = d1[0];
-  const float dxx = 2.0f * val - d1[-1] - d1[1];
-  const float dyy = 2.0f * val - d1[-RS] - d1[RS];
-  const float dxy = 0.25f * (d1[RS + 1] + d1[-RS - 1] - d1[-RS + 1] - d1[RS - 1]);
+// Refinement of one candidate from the 19 DoG values it reads (cuSIFT_D.cu:478-521): c[3*(dy+1) + (dx+1)] = centre
+// plane, lo[] / hi[] = planes below / above at {(0,0), (-1,0), (+1,0), (0,-1), (0,+1)} as (dx,dy).  Arithmetic:
+// refine_from_planes / oracle_find_points_multi, operation by operation.  Returns whether the candidate passes the edge
+// test; the record fields go to `r`.
+__device__ __forceinline__ bool refine_from_values(const float (&c)[9], const float (&lo)[5], const float (&hi)[5], int x,
+                                                   int y, int s, const FindParams &P, RefinedPoint &r) {
+  const float val = c[4];
+  const float dxx = 2.0f * val - c[3] - c[5];
+  const float dyy = 2.0f * val - c[1] - c[7];
+  const float dxy = 0.25f * (c[8] + c[0] - c[2] - c[6]);
   const float tra = dxx + dyy;
   const float det = dxx * dyy - dxy * dxy;
   if (!(tra * tra < P.edge_limit * det)) return false;
   const float edge = (tra * tra) / det;
-  const float dx = 0.5f * (d1[1] - d1[-1]);
-  const float dy = 0.5f * (d1[RS] - d1[-RS]);
-  const float *d0 = d1 - PS;
-  const float *d2 = d1 + PS;
-  const float ds = 0.5f * (d0[0] - d2[0]);
-  const float dss = 2.0f * val - d2[0] - d0[0];
-  const float dxs = 0.25f * (d2[1] + d0[-1] - d0[1] - d2[-1]);
-  const float dys = 0.25f * (d2[RS] + d0[-RS] - d2[-RS] - d0[RS]);
+  const float dx = 0.5f * (c[5] - c[3]);
+  const float dy = 0.5f * (c[7] - c[1]);
+  const float ds = 0.5f * (lo[0] - hi[0]);
+  const float dss = 2.0f * val - hi[0] - lo[0];
+  const float dxs = 0.25f * (hi[2] + lo[1] - lo[2] - hi[1]);
+  const float dys = 0.25f * (hi[4] + lo[3] - hi[3] - lo[4]);
   const float idxx = dyy * dss - dys * dys;
   const float idxy = dys * dxs - dxy * dss;
   const float idxs = dxy * dys - dyy * dxs;
@@ -856,13 +867,73 @@ __device__ __forceinline__ bool refine_from_cube(const float *cube, int col, int
   return true;
 }
 
+// Per-wave list of CANDIDATES in LDS, refined 64 at a time.  Measured (tools/exp_detect_parts.sh, 64 x 1080p): refining
+// each candidate where it is found -- one or two active lanes walking ~150 dependent instructions with three IEEE
+// divisions and an exp2, ~0.25 times per wave-row -- cost 21 % of the fused kernel although it is 1 % of its
+// arithmetic.  Now the detecting lane only copies the 19 DoG values its refinement reads (from the wave's cube) and its
+// (x, y, scale index) into the list; when 64 candidates have gathered, or at the end of the chunk, every lane refines
+// one of them -- the same instructions on the same values, so the same bits -- and the accepted ones are appended to
+// the image's SiftData with ONE atomic per batch (ballot + mbcnt for the slots; the reference takes one atomicInc per
+// candidate, cuSIFT_D.cu:512).  The order inside an octave, unspecified before, is unspecified still; overflow beyond
+// max_pts is dropped as before while the counter keeps counting.
+struct CandList {
+  float *buf;  // [kCandCap][kCandWords] in LDS; an entry's stride is odd: lane i reading word k of entry i is conflict-free
+  int n;       // wave-uniform
+  // Called by ALL lanes (convergent): the entry of a lane with `mine` set (its rank among them, after the `n` entries
+  // already waiting), nullptr for the others; the caller fills the kCandWords words.
+  __device__ __forceinline__ float *reserve(bool mine) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    float *e = mine ? buf + (n + rank) * kCandWords : nullptr;
+    n += __builtin_popcountll(m);
+    return e;
+  }
+  // refines the last min(n, 64) entries and appends the accepted ones to the image's SiftData
+  __device__ __forceinline__ void refine_batch(cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
+                                               const FindParams &P, int lane) {
+    const int cnt = n < 64 ? n : 64;  // wave-uniform
+    if (cnt == 0) return;
+    n -= cnt;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's list writes have landed (one wave, in-order LDS)
+    RefinedPoint r;
+    bool accept = false;
+    if (lane < cnt) {
+      const float *e = buf + (n + lane) * kCandWords;
+      float c[9], lo[5], hi[5];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) c[k] = e[k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) lo[k] = e[9 + k], hi[k] = e[14 + k];
+      const int x = __builtin_bit_cast(int, e[19]);
+      const int ys = __builtin_bit_cast(int, e[20]);
+      accept = refine_from_values(c, lo, hi, x, ys >> 3, ys & 7, P, r);
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(accept);
+    if (m == 0) return;
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned int)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const unsigned int idx = base + (unsigned int)rank;
+    if (accept && idx < (unsigned int)max_pts) {
+      cusift_point *pt = pts + idx;
+      pt->coords2D[0] = r.x;
+      pt->coords2D[1] = r.y;
+      pt->scale = r.scale;
+      pt->sharpness = r.sharpness;
+      pt->edgeness = r.edgeness;
+      pt->subsampling = P.subsampling;
+    }
+  }
+};
+
 template <bool kIdent0>
-__global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
                                                           long img_stride, cusift_point *__restrict__ points,
                                                           int max_pts, unsigned int *__restrict__ counters,
                                                           int rows_per_wave, LaplaceTapsPk T, FindParams P,
                                                           RowWindow rw, int cy_begin, int cy_end) {
-  extern __shared__ float s_cube[];  // [waves per workgroup][9 * kCubeCols cube + kKeyListFloats keypoint list]
+  extern __shared__ float s_cands[];  // [waves per workgroup][kDetectWaveLdsFloats]: the wave's candidate list
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -876,8 +947,7 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
   img += (long)bz * img_stride;
   points += (long)bz * max_pts;
   unsigned int *counter = counters + bz;
-  float *cube = s_cube + wv * (9 * kCubeCols + kKeyListFloats);
-  KeyList keys{cube + 9 * kCubeCols, 0};
+  CandList cands{s_cands + wv * kDetectWaveLdsFloats, 0};
 
   const int c0 = bx * kDetStrip - kDetHaloLanes * kBlurCols + lane * kBlurCols;
   const EdgeFix4 edge(c0, w);  // any w >= 4
@@ -894,9 +964,20 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
   };
   auto fix = [&](f4 v) -> f4 { return edge(v); };
 
+#ifdef CUSIFT_DET_STAMPS
+  unsigned int acc_fill = 0, acc_blur = 0, acc_ext = 0, acc_ref = 0, acc_shift = 0, n_rows = 0;
+  const unsigned int t_begin = DET_NOW();
+#endif
   f4 win[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 1 - 4 + i));
+#ifdef CUSIFT_DET_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  acc_fill = DET_NOW() - t_begin;
+#if CUSIFT_DET_STAMPS == 4
+  acc_fill = 0;
+#endif
+#endif
 
   // DoG rows yy-2, yy-1, yy live in three register sets whose roles rotate; the row loop is unrolled by
   // three so the rotation costs no moves.
@@ -906,9 +987,17 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
 
   f4 ahead = load_raw(ya - 1 + 5);  // row yy+5 of the first iteration; the loop keeps two rows in flight
   auto row_step = [&](int yy, f4 (&D0)[kNumDog], f4 (&D1)[kNumDog], f4 (&D2)[kNumDog]) {
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
+    const unsigned int s0 = DET_NOW();
+#endif
     const f4 nxt = ahead;        // requested one iteration ago (raw)
     ahead = load_raw(yy + 6);    // needed two iterations from now
     blur_dog_row<kIdent0>(win, T, D2);
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
+    const unsigned int s1 = DET_NOW();
+    unsigned int s2 = s1, s3 = s1;
+    bool had_event = false;
+#endif
 
     if (yy >= ya + 1) {
       const int y = yy - 1;  // centre row: D0 = y-1, D1 = y, D2 = y+1
@@ -930,7 +1019,12 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
       // halo lanes and lanes right of the image hold no centres (and their DoG values are not meaningful)
       const bool big = vmax > P.thr_pos && lane_valid && c0 < w;
       unsigned int cand = 0;  // bit (4*s + j)
+#if defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 2
+      if (big && vmax == 12345.0f) cand = 0x000fffffu;
+      if (false) {
+#else
       if (__builtin_amdgcn_ballot_w64(big) != 0) {  // wave-uniform
+#endif
         // per plane: 3-row column min/max, then the 3x3 min/max (h*) and the left/right neighbours' columns
         f4 hmn[kNumDog], hmx[kNumDog];
         f4 lmn[kNumScales], rmn[kNumScales], lmx[kNumScales], rmx[kNumScales];  // for the 5 centre planes 1..5
@@ -974,52 +1068,133 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
           }
         }
       }
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
+      s2 = DET_NOW();
+      s3 = s2;
+#endif
       if (!lane_valid) cand = 0;
       // border pixels are never extrema in the reference (clamped neighbour == centre)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (c0 + j < 1 || c0 + j > w - 2) cand &= ~(0x11111u << j);
+#if defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 1  // no refinement at all: what would a free refinement save?
+      if (cand == 0x000fffffu) counter[0] = 1;
+      if (false) {
+#elif defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 2  // no extrema analysis either (pre-test kept)
+      if (cand == 0x000fffffu) counter[0] = 1;
+      if (false) {
+#else
       if (__builtin_amdgcn_ballot_w64(cand != 0) != 0) {  // wave-uniform, rare
+#endif
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
+        had_event = true;
+#endif
 #pragma unroll 1
         for (int s = 0; s < kNumScales; ++s) {
           const unsigned int m = (cand >> (4 * s)) & 0xfu;
           if (__builtin_amdgcn_ballot_w64(m != 0) == 0) continue;  // wave-uniform
-          // dump planes s, s+1, s+2 x rows y-1, y, y+1 of the whole strip into the wave's LDS cube
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) {
-            f4 r0, r1, r2;
-            // static plane selection (s is a loop variable): select among the 5 possible triples
-            switch (s) {
-              case 0: r0 = D0[0 + pp]; r1 = D1[0 + pp]; r2 = D2[0 + pp]; break;
-              case 1: r0 = D0[1 + pp]; r1 = D1[1 + pp]; r2 = D2[1 + pp]; break;
-              case 2: r0 = D0[2 + pp]; r1 = D1[2 + pp]; r2 = D2[2 + pp]; break;
-              case 3: r0 = D0[3 + pp]; r1 = D1[3 + pp]; r2 = D2[3 + pp]; break;
-              default: r0 = D0[4 + pp]; r1 = D1[4 + pp]; r2 = D2[4 + pp]; break;
-            }
-            float *dst = cube + (pp * 3) * kCubeCols + lane * 4;
-            *reinterpret_cast<f4 *>(dst) = r0;
-            *reinterpret_cast<f4 *>(dst + kCubeCols) = r1;
-            *reinterpret_cast<f4 *>(dst + 2 * kCubeCols) = r2;
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
+          const unsigned int e0 = DET_NOW();
+          unsigned int t_ref = 0;
+#endif
+          // A candidate's refinement reads 19 DoG values: the 3x3 of its own plane, and the centre with its four
+          // neighbours in the planes below and above.  All of them are in the registers of the detecting lane, except
+          // the column beyond its float4 (from the lane before for column 0, the lane after for column 3: five DPP
+          // moves).  The scale index and the column are made compile-time constants -- one case per scale, one block
+          // per column -- so every value is a named register and the lane stores its entry directly.  (Round 2 first
+          // dumped the three planes of the strip into an LDS cube, 9 KB per wave, and copied from there: ~1,750
+          // cycles per row-and-scale with a candidate by the phase stamps.)
+          auto emit = [&](auto scale_c) {
+            constexpr int k = decltype(scale_c)::value;  // planes k (below), k + 1 (the candidate's), k + 2 (above)
+            auto column = [&](auto col_c) {
+              constexpr int j = decltype(col_c)::value;
+              const bool mine = (m >> j) & 1u;
+              if (__builtin_amdgcn_ballot_w64(mine) == 0) return;  // wave-uniform
+              // value of plane p, row set D, column j + dx
+              auto at = [&](const f4 (&D)[kNumDog], int p, int dx) -> float {
+                const int col = j + dx;
+                if (col < 0) return from_prev_lane(D[p][3]);
+                if (col > 3) return from_next_lane(D[p][0]);
+                return D[p][col];
+              };
+              // all lanes take part in the DPP moves; only the candidates' lanes store
+              const float c00 = at(D0, k + 1, -1), c01 = at(D0, k + 1, 0), c02 = at(D0, k + 1, 1);
+              const float c10 = at(D1, k + 1, -1), c11 = at(D1, k + 1, 0), c12 = at(D1, k + 1, 1);
+              const float c20 = at(D2, k + 1, -1), c21 = at(D2, k + 1, 0), c22 = at(D2, k + 1, 1);
+              const float l0 = at(D1, k, 0), l1 = at(D1, k, -1), l2 = at(D1, k, 1), l3 = at(D0, k, 0), l4 = at(D2, k, 0);
+              const float h0 = at(D1, k + 2, 0), h1 = at(D1, k + 2, -1), h2 = at(D1, k + 2, 1), h3 = at(D0, k + 2, 0),
+                          h4 = at(D2, k + 2, 0);
+              float *e = cands.reserve(mine);  // at most 64 more entries
+              if (mine) {
+                e[0] = c00, e[1] = c01, e[2] = c02, e[3] = c10, e[4] = c11, e[5] = c12, e[6] = c20, e[7] = c21, e[8] = c22;
+                e[9] = l0, e[10] = l1, e[11] = l2, e[12] = l3, e[13] = l4;
+                e[14] = h0, e[15] = h1, e[16] = h2, e[17] = h3, e[18] = h4;
+                e[19] = __builtin_bit_cast(float, c0 + j);
+                e[20] = __builtin_bit_cast(float, ((y + rw.row0) << 3) | k);
+              }
+              if (cands.n >= 64) {
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
+                const unsigned int r0s = DET_NOW();
+#endif
+                cands.refine_batch(points, max_pts, counter, P, lane);
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
+                t_ref += DET_NOW() - r0s;
+                acc_shift += 1;  // batches
+#endif
+              }
+            };
+            column(std::integral_constant<int, 0>{});
+            column(std::integral_constant<int, 1>{});
+            column(std::integral_constant<int, 2>{});
+            column(std::integral_constant<int, 3>{});
+          };
+          switch (s) {
+            case 0: emit(std::integral_constant<int, 0>{}); break;
+            case 1: emit(std::integral_constant<int, 1>{}); break;
+            case 2: emit(std::integral_constant<int, 2>{}); break;
+            case 3: emit(std::integral_constant<int, 3>{}); break;
+            default: emit(std::integral_constant<int, 4>{}); break;
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          for (int j = 0; j < 4; ++j) {
-            const bool mine = (m >> j) & 1u;
-            if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;  // wave-uniform
-            RefinedPoint r;
-            bool accept = false;
-            if (mine) accept = refine_from_cube(cube, lane * 4 + j, c0 + j, y + rw.row0, s, P, r);
-            keys.push(accept, r);
-            if (keys.n > kKeyListCap - 64) keys.flush(points, max_pts, counter, P.subsampling, lane);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned int e2 = DET_NOW();
+          acc_blur += 1;                   // scale-events
+          acc_ref += (e2 - e0) - t_ref;    // entries written
+          acc_fill += t_ref;               // batch refinement
+#endif
         }
       }
     }
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
+    if (yy >= ya + 1) s3 = DET_NOW();
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
     win[8] = fix(nxt);
+#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
+    const unsigned int s4 = DET_NOW();
+#if CUSIFT_DET_STAMPS == 4
+    (void)s0, (void)s4;
+#elif CUSIFT_DET_STAMPS == 3  // split the refinement segment: rows with a candidate vs rows without
+    if (yy >= ya + 1) {
+      if (had_event) {
+        acc_blur += 1;         // number of rows with at least one candidate
+        acc_ext += s3 - s2;    // cycles of the segment on those rows
+      } else {
+        acc_ref += s3 - s2;    // ... and on the others
+      }
+    }
+    acc_shift += s4 - s3;
+#else
+    acc_blur += s1 - s0;
+    acc_ext += s2 - s1;
+    acc_ref += s3 - s2;
+    acc_shift += s4 - s3;
+#endif
+#endif
+#ifdef CUSIFT_DET_STAMPS
+    ++n_rows;
+#endif
   };
 
   for (int yy = ya - 1; yy <= yb; yy += 3) {
@@ -1029,8 +1204,37 @@ __global__ void __launch_bounds__(256) detect_fused_kernel(const float *__restri
     if (yy + 2 > yb) break;
     row_step(yy + 2, DC, DA, DB);
   }
-  keys.flush(points, max_pts, counter, P.subsampling, lane);  // what the chunk found, with one atomic
+  cands.refine_batch(points, max_pts, counter, P, lane);  // what is left of the chunk's candidates (fewer than 64)
+#ifdef CUSIFT_DET_STAMPS
+  if (lane == 0) {
+    const unsigned int slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (slot < (unsigned int)kDetLogWaves) {
+      unsigned int *o = g_det_log[slot];
+      o[0] = acc_fill, o[1] = acc_blur, o[2] = acc_ext, o[3] = acc_ref, o[4] = acc_shift;
+      o[5] = DET_NOW() - t_begin, o[6] = n_rows, o[7] = 1u;
+    }
+  }
+#endif
 }
+
+#ifdef CUSIFT_DET_STAMPS
+}  // namespace cusift
+// sums over the waves of the last launch(es) since the last reset
+extern "C" int cusift_debug_det_cycles(unsigned long long out[8], int reset) {
+  static unsigned int host[cusift::kDetLogWaves][8];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(cusift::g_det_log), sizeof(host)) != hipSuccess) return 1;
+  for (int k = 0; k < 8; ++k) out[k] = 0;
+  for (int i = 0; i < cusift::kDetLogWaves; ++i)
+    for (int k = 0; k < 8; ++k) out[k] += host[i][k];
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(cusift::g_det_log)) != hipSuccess) return 1;
+    if (hipMemset(p, 0, sizeof(host)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+namespace cusift {
+#endif
 
 template __global__ void detect_fused_kernel<false>(const float *, int, int, int, long, cusift_point *, int,
                                                     unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, int, int);
