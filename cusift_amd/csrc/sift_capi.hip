@@ -863,14 +863,16 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   // the least arithmetic -- but the launch ends with a tail in which the last chunks run on a part-empty chip, and
   // that tail grows with r.  Minimising (r + c)/r * work + k * r gives r ~ sqrt(work): r = coef * sqrt(rows * strips *
   // images).  Measured on MI355X, 64 x 1080p (tools/ab_detect_rows.sh, profiles/r02_ab/): a launch that has the GPU to
-  // itself is fastest at coef 0.022-0.035 and loses from 0.06 on (+2 %; 0.1: +8 %); with consecutive batches on
+  // itself was fastest at coef 0.022-0.035 with the round-1 kernel and is at 0.05 since the candidates are refined in
+  // batches (0.03: 0.873 ms, 0.04: 0.862, 0.05: 0.850, 0.07: 0.883; a chunk's fill and its two extra rows weigh more
+  // now that a row with a candidate no longer costs 3,300 cycles); with consecutive batches on
   // several streams -- the throughput mode -- the other batches' kernels fill the tail and taller chunks win: two
   // streams 0.05 -> 1.451, 0.08 -> 1.414 ms per step; four streams 0.05 -> 1.414, 0.08 -> 1.370, 0.1 -> 1.379,
   // 0.13 -> 1.382.  The caller says which case it is (cusift_params.concurrent_batches).
-  int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 40;
+  int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 64;
   rows_bounds("DETECT", rows_lo, rows_hi);
   const double wave_rows = (double)rows_total * strips * n_images;
-  double coef = concurrent >= 2 ? 0.09 : 0.03;
+  double coef = concurrent >= 2 ? 0.09 : 0.05;
   if (const char *e = getenv("CUSIFT_DETECT_ROWS_COEF")) coef = atof(e);  // tuning experiments only
   const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
   // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
