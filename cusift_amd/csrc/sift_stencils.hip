@@ -378,58 +378,6 @@ struct RefinedPoint {
   float x, y, scale, sharpness, edgeness;
 };
 
-// Per-wave list of refined keypoints in LDS, appended to the image's SiftData in batches.  The reference (and round 1
-// of this build) takes its output slot with one atomic per candidate (atomicInc, cuSIFT_D.cu:512): the detecting
-// wave then waits a full device-memory round trip (~1.5 us) before it can store the record and go on blurring --
-// ten times per chunk on the benchmark images, and the single largest cost on keypoint-dense ones.  Here the wave
-// parks accepted keypoints in LDS (slot = list length + rank among the accepting lanes: ballot + mbcnt, no memory
-// traffic) and takes its slots with ONE atomic per flush (list nearly full, or end of the chunk).  Same records;
-// the order inside an octave, unspecified before, is unspecified still; overflow beyond max_pts is dropped as before
-// while the counter keeps counting.
-constexpr int kKeyListCap = 128;                 // records; a flush is forced when fewer than 64 slots are free
-constexpr int kKeyListFloats = kKeyListCap * 5;  // x, y, scale, sharpness, edgeness
-
-struct KeyList {
-  float *buf;  // [kKeyListCap][5] in LDS
-  int n;       // wave-uniform
-  __device__ __forceinline__ void push(bool accept, const RefinedPoint &r) {  // called by ALL lanes (convergent)
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(accept);
-    if (m == 0) return;
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-    if (accept) {
-      float *d = buf + (n + rank) * 5;
-      d[0] = r.x;
-      d[1] = r.y;
-      d[2] = r.scale;
-      d[3] = r.sharpness;
-      d[4] = r.edgeness;
-    }
-    n += __builtin_popcountll(m);
-  }
-  __device__ __forceinline__ void flush(cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
-                                        float subsampling, int lane) {
-    if (n == 0) return;  // wave-uniform
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(counter, (unsigned int)n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's list writes have landed (one wave, in-order LDS)
-    for (int i = lane; i < n; i += 64) {
-      const unsigned int idx = base + (unsigned int)i;
-      if (idx < (unsigned int)max_pts) {
-        const float *d = buf + i * 5;
-        cusift_point *pt = pts + idx;
-        pt->coords2D[0] = d[0];
-        pt->coords2D[1] = d[1];
-        pt->scale = d[2];
-        pt->sharpness = d[3];
-        pt->edgeness = d[4];
-        pt->subsampling = subsampling;
-      }
-    }
-    n = 0;
-  }
-};
-
 // refinement of one candidate from the DoG planes in global memory (L2-hot): cuSIFT_D.cu:478-521, evaluated operation
 // by operation exactly as oracle_find_points_multi.  Returns whether it passes the edge test; fields go to `r`.
 __device__ __forceinline__ bool refine_from_planes(const float *__restrict__ dog, long plane, int pitch, int x, int y,
@@ -474,6 +422,57 @@ __device__ __forceinline__ bool refine_from_planes(const float *__restrict__ dog
   r.edgeness = edge;
   return true;
 }
+
+// Per-wave list of candidate POSITIONS in LDS for the two-stage path (the DoG planes are in memory, L2-hot, so a
+// candidate is its position): refined 64 at a time like CandList below -- every lane walks one candidate's ~26 loads
+// and ~150 dependent instructions instead of one or two lanes doing so while the wave waits -- and appended to the
+// image's SiftData with one atomic per batch.
+constexpr int kPosCap = 128;  // < 64 waiting + at most 64 pushed at a time
+struct PosList {
+  unsigned int *buf;  // [kPosCap][2]: x | s << 28, y
+  int n;              // wave-uniform
+  __device__ __forceinline__ void push(bool mine, int x, int y, int s) {  // called by ALL lanes (convergent)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+    if (m == 0) return;
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (mine) {
+      buf[2 * (n + rank)] = (unsigned int)x | ((unsigned int)s << 28);
+      buf[2 * (n + rank) + 1] = (unsigned int)y;
+    }
+    n += __builtin_popcountll(m);
+  }
+  // refines the last min(n, 64) entries and appends the accepted ones to the image's SiftData
+  __device__ __forceinline__ void refine_batch(const float *__restrict__ dog, long plane, int pitch,
+                                               cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
+                                               const FindParams &P, int lane) {
+    const int cnt = n < 64 ? n : 64;  // wave-uniform
+    if (cnt == 0) return;
+    n -= cnt;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's list writes have landed (one wave, in-order LDS)
+    RefinedPoint r;
+    bool accept = false;
+    if (lane < cnt) {
+      const unsigned int xs = buf[2 * (n + lane)], y = buf[2 * (n + lane) + 1];
+      accept = refine_from_planes(dog, plane, pitch, (int)(xs & 0x0fffffffu), (int)y, (int)(xs >> 28), P, r);
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(accept);
+    if (m == 0) return;
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned int)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const unsigned int idx = base + (unsigned int)rank;
+    if (accept && idx < (unsigned int)max_pts) {
+      cusift_point *pt = pts + idx;
+      pt->coords2D[0] = r.x;
+      pt->coords2D[1] = r.y;
+      pt->scale = r.scale;
+      pt->sharpness = r.sharpness;
+      pt->edgeness = r.edgeness;
+      pt->subsampling = P.subsampling;
+    }
+  }
+};
 
 __device__ __forceinline__ void refine_and_append(const float *__restrict__ dog, long plane, int pitch, int x, int y,
                                                    int s, const FindParams &P, cusift_point *__restrict__ pts,
@@ -665,8 +664,8 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
     }
   };
 
-  __shared__ float s_keys[kWavesPerBlock][kKeyListFloats];
-  KeyList keys{s_keys[wv], 0};
+  __shared__ unsigned int s_cands[kWavesPerBlock][2 * kPosCap];
+  PosList cands{s_cands[wv], 0};
   f2 r0[kNumDog], r1[kNumDog], r2[kNumDog], nxt[kNumDog];
   load_row(y0 - 1, r0);
   load_row(y0, r1);
@@ -718,12 +717,8 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
       for (int b = 0; b < 2 * kNumScales; ++b) {
         const int x = c0 + (b & 1), s = b >> 1;
         const bool mine = (cand & (1u << b)) && x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2;
-        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;  // wave-uniform
-        RefinedPoint r;
-        bool accept = false;
-        if (mine) accept = refine_from_planes(dog, plane, pitch, x, y, s, P, r);
-        keys.push(accept, r);
-        if (keys.n > kKeyListCap - 64) keys.flush(points, max_pts, counter, P.subsampling, lane);
+        cands.push(mine, x, y, s);  // at most 64 more entries
+        if (cands.n >= 64) cands.refine_batch(dog, plane, pitch, points, max_pts, counter, P, lane);
       }
     }
 #pragma unroll
@@ -733,7 +728,7 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
       r2[p] = nxt[p];
     }
   }
-  keys.flush(points, max_pts, counter, P.subsampling, lane);  // what the chunk found, with one atomic (see KeyList)
+  cands.refine_batch(dog, plane, pitch, points, max_pts, counter, P, lane);  // what is left (fewer than 64)
 }
 
 // ------------------------------------------------------------------------------------------------
