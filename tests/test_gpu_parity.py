@@ -859,11 +859,14 @@ def test_torch_still_sees_the_gpu_when_imported_after_the_library():
     import subprocess
     import sys
 
+    # allocation + copy only: no torch kernel is launched, so the child does not have to load torch's code objects
+    # (minutes on a box whose page cache is cold)
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from cusift_amd import capi\n"
             "c = capi.Context(0); b = capi.DeviceBuffer(c, 1 << 20)\n"
             "import torch\n"
-            "assert torch.cuda.is_available()\n"
-            "print(float(torch.ones(8, device='cuda').sum()))\n") % ROOT
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+            "assert torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+            "t = torch.empty(8, device='cuda'); t.copy_(torch.full((8,), 1.0)); torch.cuda.synchronize()\n"
+            "print(float(t.cpu().sum()))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("8.0"), out.stdout[-500:] + out.stderr[-1500:]
