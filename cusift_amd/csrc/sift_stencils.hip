@@ -761,7 +761,6 @@ __device__ unsigned int g_det_log[kDetLogWaves][8];  // one row per wave of the 
 
 constexpr int kDetHaloLanes = 2;
 constexpr int kDetStrip = (64 - 2 * kDetHaloLanes) * kBlurCols;  // 240 columns of extremum centres per wave
-constexpr int kCubeCols = 64 * kBlurCols;                        // 256 floats per cube row
 constexpr int kCandWords = 21;                                   // 19 DoG values, x, (y << 3) | scale index
 constexpr int kCandCap = 128;                                    // < 64 waiting + at most 64 pushed at a time
 static_assert(kCandCap * kCandWords == kDetectWaveLdsFloats, "host and kernel agree on the LDS size");
