@@ -964,7 +964,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
 #endif
   f4 win[9];
 #pragma unroll
+#if defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 3  // upper bound for a hidden window fill: nine loads of ONE row (cache hits)
+  for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 5 + (i & 1)));
+#else
   for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 1 - 4 + i));
+#endif
 #ifdef CUSIFT_DET_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   acc_fill = DET_NOW() - t_begin;
