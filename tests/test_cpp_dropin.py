@@ -11,16 +11,18 @@ BIN = os.path.join(CPP, "detector_dropin")
 BIN_MATCH = os.path.join(CPP, "matching_dropin")
 BIN_HOMO = os.path.join(CPP, "homography_dropin")
 BIN_MULTI = os.path.join(CPP, "multigpu_dropin")
+BIN_PIPE = os.path.join(CPP, "pipeline_dropin")
 
 
 def build():
     subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
     assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO) and os.path.exists(BIN_MULTI)
+    assert os.path.exists(BIN_PIPE)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI):
+    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -90,3 +92,23 @@ def test_dropin_multigpu_program_passes_on_one_gpu(tmp_path):
     print(out.stdout[-2000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "PASSED" in out.stdout and "rccl" in out.stdout.lower()
+
+
+@pytest.mark.gpu
+def test_dropin_pipeline_program_runs_on_gpu():
+    """Consecutive batches rotated over several contexts through the C ABI alone (the throughput mode of bench.py,
+    from C++): every context must deliver the same keypoint count for the same images."""
+    import re
+
+    build()
+    pgm = os.path.join(ROOT, "tests", "golden", "gray1.pgm")
+    counts = []
+    for contexts in ("1", "3"):
+        out = subprocess.run([BIN_PIPE, pgm, contexts, "6", "5", "640", "480"], capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        m = re.search(r"pipeline: (\d+) contexts, 6 batches of 5 images 640x480: ([0-9.]+) ms per batch, ([0-9.]+) Gpix/s, "
+                      r"(\d+) keypoints per batch", out.stdout)
+        assert m, out.stdout
+        counts.append(int(m.group(4)))
+    assert counts[0] == counts[1] > 0
