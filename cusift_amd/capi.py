@@ -84,9 +84,27 @@ SIGNATURES = {
     "cusift_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "cusift_comm_library": (C.c_char_p, []),
     "cusift_comm_set_self_p2p": (_i, [_vp, _i]),
-    "cusift_allgatherv_begin": (_i, [_vp, _vp, _vp, _i, _i, _i]),
-    "cusift_allgatherv_finish": (_i, [_vp, _vp, _sz, _vp, _vp]),
-    "cusift_allgatherv": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "cusift_comm_use_library": (_i, [C.c_char_p]),
+    "cusift_comm_ctx": (_vp, [_vp]),
+    "cusift_comm_reserve": (_i, [_vp, _i, _i, _sz]),
+    "cusift_comm_set_fixed_size": (_i, [_vp, _i]),
+    "cusift_comm_host_waits": (C.c_ulonglong, [_vp]),
+    "cusift_allgatherv_begin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz]),
+    "cusift_allgatherv_finish": (_i, [_vp, _vp, _vp]),
+    "cusift_allgatherv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "cusift_compact_gathered": (_i, [_vp, _vp, _sz, _i, _vp, _vp, _sz]),
+    "cusift_tiled_plan": (_i, [_i, _i, _i, _i, _i, _i, _i] + [C.POINTER(_i)] * 9),
+    "cusift_tiled_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _PP, _i]),
+    "cusift_tiled_destroy": (_i, [_vp]),
+    "cusift_tiled_info": (_i, [_vp] + [C.POINTER(_i)] * 4),
+    "cusift_tiled_band": (_i, [_vp, _i, C.POINTER(_vp)] + [C.POINTER(_i)] * 7),
+    "cusift_tiled_load": (_i, [_vp, _vp, _i]),
+    "cusift_tiled_build_octave": (_i, [_vp, _i]),
+    "cusift_tiled_exchange": (_i, [_vp, _i]),
+    "cusift_tiled_exchange_virtual": (_i, [C.POINTER(_vp), _i, _i]),
+    "cusift_tiled_process": (_i, [_vp, _vp, _vp]),
+    "cusift_tiled_extract": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "cusift_tiled_check": (_i, [_vp, C.POINTER(C.c_uint)]),
     "cusift_exchange_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cusift_exchange_halos": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
@@ -119,7 +137,7 @@ SIGNATURES = {
     "cusift_math_eval": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _sz]),
     "cusift_scale_down_band": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f]),
     "cusift_detect_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _i, _vp]),
-    "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp]),
+    "cusift_describe_band": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp]),
     "cusift_match": (_i, [_vp, _vp, _i, _vp, _i, _i]),
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "cusift_find_homography": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, C.POINTER(_i), _vp, _vp]),
@@ -247,6 +265,11 @@ class Context:
     def synchronize(self):
         check(lib().cusift_ctx_synchronize(self.handle))
 
+    def stream_handle(self):
+        """The hipStream_t of the context as an integer (0 = the null stream): torch.cuda.ExternalStream(...) of it puts
+        torch-side work on the stream the kernels run on."""
+        return int(lib().cusift_ctx_stream(self.handle) or 0)
+
     def wait(self, other):
         """cusift_ctx_wait: work enqueued on this context from now on waits for what `other` has enqueued so far."""
         check(lib().cusift_ctx_wait(self.handle, other.handle))
@@ -359,9 +382,9 @@ class Context:
                                        peak_thresh, edge_thresh, subsampling, d_points, max_pts, d_counter))
 
     def describe_band(self, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first, d_counter, subsampling,
-                      tex_frac_bits=8, d_flags=None):
+                      tex_frac_bits=8, d_flags=None, root_sift=0):
         check(lib().cusift_describe_band(self.handle, d_img, w, h, pitch, row0, h_global, d_points, max_pts, d_first,
-                                         d_counter, subsampling, tex_frac_bits, d_flags))
+                                         d_counter, subsampling, tex_frac_bits, root_sift, d_flags))
 
     def math_eval(self, op, d_a, d_b, d_out, d_out2, n):
         """cusift_math_eval: op 0 expf, 1 exp2f, 2 atan2f(a, b), 3 sincosf -> (out, out2); device pointers."""
@@ -422,6 +445,12 @@ class Context:
 UNIQUE_ID_BYTES = 128
 
 
+def comm_use_library(path=None):
+    """cusift_comm_use_library: the library (RCCL, or anything exporting the same nine nccl* entry points) that
+    comm_unique_id() / Comm() bind from now on; None = the default search (next to the process's HIP runtime)."""
+    check(lib().cusift_comm_use_library(path.encode() if path else None))
+
+
 def comm_unique_id():
     """cusift_comm_get_unique_id: 128 opaque bytes; rank 0 makes them, every rank passes them to Comm()."""
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)
@@ -438,9 +467,14 @@ class Comm:
         self._h = C.c_void_p()
         self.ctx = ctx  # keeps the context alive
         self.rank, self.world = rank, world
+        self._slots = []  # n_images_max of the exchanges in flight, oldest first
         check(lib().cusift_comm_create(C.byref(self._h), ctx.handle, unique_id, rank, world))
         if self_p2p:
             check(lib().cusift_comm_set_self_p2p(self._h, 1))
+
+    @property
+    def handle(self):
+        return self._h
 
     def close(self):
         if self._h:
@@ -458,20 +492,38 @@ class Comm:
         p = lib().cusift_comm_library()
         return p.decode() if p else ""
 
-    def allgatherv_begin(self, d_points, d_counters, n_images, max_pts, n_images_max):
-        check(lib().cusift_allgatherv_begin(self._h, d_points, d_counters, n_images, max_pts, n_images_max))
-        self._slots = n_images_max
+    def reserve(self, n_images_max, tickets=4, stage_records=0):
+        check(lib().cusift_comm_reserve(self._h, n_images_max, tickets, stage_records))
 
-    def allgatherv_finish(self, d_gathered, capacity):
-        """Returns (counts uint32 [world, n_images_max], offsets uint64 [world + 1]) -- host arrays."""
-        counts = np.zeros((self.world, self._slots), dtype=np.uint32)
-        offsets = np.zeros(self.world + 1, dtype=np.uint64)
-        check(lib().cusift_allgatherv_finish(self._h, d_gathered, capacity, counts.ctypes.data, offsets.ctypes.data))
-        return counts, offsets
+    def set_fixed_size(self, on=True):
+        check(lib().cusift_comm_set_fixed_size(self._h, 1 if on else 0))
 
-    def allgatherv(self, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, capacity):
-        self.allgatherv_begin(d_points, d_counters, n_images, max_pts, n_images_max)
-        return self.allgatherv_finish(d_gathered, capacity)
+    def host_waits(self):
+        return int(lib().cusift_comm_host_waits(self._h))
+
+    def allgatherv_begin(self, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, region_cap,
+                         producer=None):
+        """`producer`: the Context that extracted d_points (the exchange is ordered after it; None: the caller has)."""
+        check(lib().cusift_allgatherv_begin(self._h, producer.handle if producer is not None else None, d_points,
+                                            d_counters, n_images, max_pts, n_images_max, d_gathered, region_cap))
+        self._slots.append(n_images_max)
+
+    def allgatherv_finish(self):
+        """Completes the OLDEST begin.  Returns (counts uint32 [world, n_images_max], totals uint64 [world]) -- host
+        arrays; rank r's records are d_gathered[r * region_cap : r * region_cap + totals[r]]."""
+        if not self._slots:
+            raise CusiftError("allgatherv: finish() without begin()")
+        counts = np.zeros((self.world, self._slots[0]), dtype=np.uint32)
+        totals = np.zeros(self.world, dtype=np.uint64)
+        try:
+            check(lib().cusift_allgatherv_finish(self._h, counts.ctypes.data, totals.ctypes.data))
+        finally:
+            self._slots.pop(0)
+        return counts, totals
+
+    def allgatherv(self, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, region_cap, producer=None):
+        self.allgatherv_begin(d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, region_cap, producer)
+        return self.allgatherv_finish()
 
     def exchange_rows(self, d_band, pitch, ops):
         """ops: list of (peer, send_row, send_rows, recv_row, recv_rows)."""
@@ -482,6 +534,86 @@ class Comm:
 
     def exchange_halos(self, d_band, pitch, top_halo, own_rows, bottom_halo, send_rows):
         check(lib().cusift_exchange_halos(self._h, d_band, pitch, top_halo, own_rows, bottom_halo, send_rows))
+
+
+def compact_gathered(ctx, d_gathered, region_cap, totals, d_out, capacity):
+    """cusift_compact_gathered: the regions of an all-gatherv back to back in rank order (asynchronous on ctx)."""
+    t = np.ascontiguousarray(totals, dtype=np.uint64)
+    check(lib().cusift_compact_gathered(ctx.handle, d_gathered, region_cap, len(t), t.ctypes.data, d_out, capacity))
+
+
+def tiled_plan(W, H, world, num_octaves, halo=0, rank=0, octave=0):
+    """cusift_tiled_plan (host only): dict of the strip plan's geometry for (rank, octave)."""
+    v = [C.c_int(0) for _ in range(9)]
+    check(lib().cusift_tiled_plan(W, H, world, num_octaves, halo, rank, octave, *[C.byref(x) for x in v]))
+    keys = ("n_octaves", "collapse", "w", "h", "pitch", "own_begin", "own_end", "band_begin", "band_end")
+    return dict(zip(keys, (x.value for x in v)))
+
+
+class Tiled:
+    """cusift_tiled: one rank of the strip-tiled extraction of ONE large image (BASELINE configs[4])."""
+
+    def __init__(self, ctx, comm, rank, world, W, H, params, halo=0):
+        self._h = C.c_void_p()
+        self.ctx, self.comm = ctx, comm  # kept alive
+        self.rank, self.world = rank, world
+        check(lib().cusift_tiled_create(C.byref(self._h), ctx.handle, comm.handle if comm is not None else None, rank,
+                                        world, W, H, C.byref(params), halo))
+        v = [C.c_int(0) for _ in range(4)]
+        check(lib().cusift_tiled_info(self._h, *[C.byref(x) for x in v]))
+        self.n_oct, self.collapse, self.root, self.halo = (x.value for x in v)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def band(self, octave):
+        """(device pointer or None, dict of geometry) of this rank's band of `octave`."""
+        ptr = C.c_void_p()
+        v = [C.c_int(0) for _ in range(7)]
+        check(lib().cusift_tiled_band(self._h, octave, C.byref(ptr), *[C.byref(x) for x in v]))
+        keys = ("w", "h", "pitch", "own_begin", "own_end", "band_begin", "band_end")
+        return ptr.value, dict(zip(keys, (x.value for x in v)))
+
+    def load(self, d_strip, strip_pitch):
+        check(lib().cusift_tiled_load(self._h, d_strip, strip_pitch))
+
+    def build_octave(self, o):
+        check(lib().cusift_tiled_build_octave(self._h, o))
+
+    def exchange(self, o):
+        check(lib().cusift_tiled_exchange(self._h, o))
+
+    def process(self, d_points, d_counter):
+        check(lib().cusift_tiled_process(self._h, d_points, d_counter))
+
+    def extract(self, d_strip, strip_pitch, d_points, d_counter):
+        check(lib().cusift_tiled_extract(self._h, d_strip, strip_pitch, d_points, d_counter))
+
+    def check(self, strict=True):
+        """Blocking.  Number of keypoints whose footprint left the halo; raises if non-zero and strict."""
+        f = C.c_uint(0)
+        rc = lib().cusift_tiled_check(self._h, C.byref(f))
+        if rc != CUSIFT_OK and (strict or f.value == 0):
+            check(rc)
+        return f.value
+
+    def close(self):
+        if self._h:
+            lib().cusift_tiled_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tiled_exchange_virtual(tiles, octave):
+    """cusift_tiled_exchange_virtual: the exchange of `octave` among all ranks' Tiled objects of ONE process."""
+    arr = (C.c_void_p * len(tiles))(*[t.handle for t in tiles])
+    check(lib().cusift_tiled_exchange_virtual(arr, len(tiles), octave))
 
 
 class ExtractGraph:

@@ -974,13 +974,13 @@ extern "C" int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, i
 extern "C" int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0,
                                     int h_global, cusift_point *d_points, int max_pts, const unsigned int *d_first,
                                     const unsigned int *d_counter, float subsampling, int tex_frac_bits,
-                                    unsigned int *d_flags) {
+                                    int root_sift, unsigned int *d_flags) {
   if (row0 < 0 || h < 1 || row0 + h > h_global) return fail(CUSIFT_ERR_INVALID, "Describe (band): bad row geometry");
   const RowWindow rw{row0, h_global};
   TRY(orientations_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
                         tex_frac_bits, 1, rw));
   return descriptors_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
-                          subsampling, tex_frac_bits, 1, rw, 0, d_flags);
+                          subsampling, tex_frac_bits, 1, rw, root_sift, d_flags);
 }
 
 extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts) {
@@ -1017,6 +1017,11 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
   int splits = std::max(1, std::min(idiv_up(4 * ctx->num_cus, row_blocks), idiv_up(num_pts2, 128)));
   if (const char *e = getenv("CUSIFT_MATCH_SPLITS")) splits = std::max(1, std::min(atoi(e), idiv_up(num_pts2, 32)));
   splits = std::min(splits, 65535);
+  // the kernel addresses a split's columns through a buffer resource with 32-bit byte offsets: a split may span at most
+  // 2^31 / 588 records (3.65 M) -- more points than that force further splits
+  constexpr int kMaxColsPerSplit = (int)((0x7fffffffu / sizeof(cusift_point)) / 32 * 32);
+  splits = std::max(splits, idiv_up(num_pts2, kMaxColsPerSplit));
+  if (splits > 65535) return fail(CUSIFT_ERR_INVALID, "MatchSiftData: too many points in image 2 (%d)", num_pts2);
   const int cols_per_split = idiv_up(idiv_up(num_pts2, splits), 32) * 32;
   splits = idiv_up(num_pts2, cols_per_split);
   const int n1_pad = row_blocks * 64;
@@ -1125,13 +1130,21 @@ extern "C" int cusift_memcpy2d_d2h(cusift_ctx *ctx, void *h_dst, size_t dst_pitc
 extern "C" int cusift_sort_points_host(cusift_point *h_points, int num_pts) {
   if (num_pts <= 0) return CUSIFT_OK;
   if (!h_points) return fail(CUSIFT_ERR_INVALID, "sort: h_points is NULL");
-  std::stable_sort(h_points, h_points + num_pts, [](const cusift_point &a, const cusift_point &b) {
-    if (a.subsampling != b.subsampling) return a.subsampling > b.subsampling;
-    if (a.coords2D[1] != b.coords2D[1]) return a.coords2D[1] < b.coords2D[1];
-    if (a.coords2D[0] != b.coords2D[0]) return a.coords2D[0] < b.coords2D[0];
-    if (a.scale != b.scale) return a.scale < b.scale;
+  // every key is compared as a BIT PATTERN mapped to an unsigned integer that orders like the float (negative values
+  // reversed, then offset): a strict weak ordering whatever the values -- a NaN location or scale (1/0 in the
+  // refinement of a degenerate DoG neighbourhood) sorts after every number instead of breaking the sort's contract
+  auto key = [](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  };
+  std::stable_sort(h_points, h_points + num_pts, [&key](const cusift_point &a, const cusift_point &b) {
+    const uint32_t ka[] = {~key(a.subsampling), key(a.coords2D[1]), key(a.coords2D[0]), key(a.scale)};
+    const uint32_t kb[] = {~key(b.subsampling), key(b.coords2D[1]), key(b.coords2D[0]), key(b.scale)};
+    for (int i = 0; i < 4; ++i)
+      if (ka[i] != kb[i]) return ka[i] < kb[i];
     // exact ties of location and scale (two scales of one pixel refined onto the same point): the rest of the
-    // extracted fields as BIT PATTERNS -- a total order even where an orientation is NaN (flat patch)
+    // extracted fields, bytewise -- a total order even where an orientation is NaN (flat patch)
     return memcmp(&a.sharpness, &b.sharpness, 3 * sizeof(float)) < 0;  // sharpness, edgeness, orientation
   });
   return CUSIFT_OK;

@@ -11,16 +11,23 @@
 // RCCL is bound at run time (dlopen), from the directory of the HIP runtime the process already holds: a PyTorch
 // process gets the wheel's librccl.so (built against the wheel's libamdhip64), a plain C++ program the system's
 // /opt/rocm/lib/librccl.so.1.  libcusift_amd.so therefore has no link-time dependency on RCCL, and a program that
-// never creates a communicator never loads it.
+// never creates a communicator never loads it.  cusift_comm_use_library() names another library with the same nine
+// entry points for the communicators created after it -- the tests bind tests/fake_rccl (W ranks as W threads of one
+// process on one GPU) next to the real RCCL in one process.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,7 +50,7 @@ namespace {
     if (rc_ != CUSIFT_OK) return rc_; \
   } while (0)
 
-// ---- RCCL, bound at run time ---------------------------------------------------------------------------------
+// ---- RCCL (or a library with the same entry points), bound at run time ------------------------------------------
 struct Rccl {
   void *handle = nullptr;
   std::string path, error;
@@ -56,15 +63,19 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool complete() const {
+    return handle && GetUniqueId && CommInitRank && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd &&
+           GetErrorString;
+  }
 };
 
-Rccl &rccl_state() {
-  static Rccl r;
-  return r;
-}
+std::mutex g_lib_mu;
+std::map<std::string, std::unique_ptr<Rccl>> g_libs;  // by the name it was asked for ("" = default search)
+std::string g_lib_choice;                             // what cusift_comm_use_library() named last
+std::string g_lib_path;                               // path of the library bound last (cusift_comm_library)
 
 bool try_open(Rccl &r, const std::string &name) {
-  void *h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+  void *h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
   if (!h) {
     r.error += name + ": " + dlerror() + "; ";
     return false;
@@ -74,60 +85,67 @@ bool try_open(Rccl &r, const std::string &name) {
   return true;
 }
 
-int load_rccl() {
-  static std::once_flag once;
-  Rccl &r = rccl_state();
-  std::call_once(once, [&]() {
+// The library the next communicator binds: cusift_comm_use_library()'s, else $CUSIFT_RCCL_LIB, else the librccl next
+// to the HIP runtime of this process.
+int load_rccl(Rccl **out) {
+  std::lock_guard<std::mutex> lock(g_lib_mu);
+  std::string key = g_lib_choice;
+  if (key.empty())
+    if (const char *e = getenv("CUSIFT_RCCL_LIB")) key = e;
+  auto it = g_libs.find(key);
+  if (it == g_libs.end()) {
+    std::unique_ptr<Rccl> r(new Rccl());
     std::vector<std::string> cands;
-    if (const char *e = getenv("CUSIFT_RCCL_LIB")) cands.push_back(e);
-    // next to the HIP runtime this process already uses (a torch wheel ships both; so does /opt/rocm/lib)
-    Dl_info info;
-    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
-      std::string dir(info.dli_fname);
-      const size_t slash = dir.rfind('/');
-      if (slash != std::string::npos) {
-        dir.resize(slash + 1);
-        cands.push_back(dir + "librccl.so.1");
-        cands.push_back(dir + "librccl.so");
+    if (!key.empty()) {
+      cands.push_back(key);
+    } else {
+      // next to the HIP runtime this process already uses (a torch wheel ships both; so does /opt/rocm/lib)
+      Dl_info info;
+      if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+          dir.resize(slash + 1);
+          cands.push_back(dir + "librccl.so.1");
+          cands.push_back(dir + "librccl.so");
+        }
       }
+      cands.push_back("librccl.so.1");
+      cands.push_back("librccl.so");
     }
-    cands.push_back("librccl.so.1");
-    cands.push_back("librccl.so");
     for (const auto &c : cands)
-      if (try_open(r, c)) break;
-    if (!r.handle) return;
-#define BIND(field, sym)                                       \
-  r.field = (decltype(r.field))dlsym(r.handle, sym);           \
-  if (!r.field) r.error += std::string("missing symbol ") + sym + "; ";
-    BIND(GetUniqueId, "ncclGetUniqueId")
-    BIND(CommInitRank, "ncclCommInitRank")
-    BIND(CommDestroy, "ncclCommDestroy")
-    BIND(AllGather, "ncclAllGather")
-    BIND(Send, "ncclSend")
-    BIND(Recv, "ncclRecv")
-    BIND(GroupStart, "ncclGroupStart")
-    BIND(GroupEnd, "ncclGroupEnd")
-    BIND(GetErrorString, "ncclGetErrorString")
+      if (try_open(*r, c)) break;
+    if (r->handle) {
+#define BIND(field, sym)                                        \
+  r->field = (decltype(r->field))dlsym(r->handle, sym);         \
+  if (!r->field) r->error += std::string("missing symbol ") + sym + "; ";
+      BIND(GetUniqueId, "ncclGetUniqueId")
+      BIND(CommInitRank, "ncclCommInitRank")
+      BIND(CommDestroy, "ncclCommDestroy")
+      BIND(AllGather, "ncclAllGather")
+      BIND(Send, "ncclSend")
+      BIND(Recv, "ncclRecv")
+      BIND(GroupStart, "ncclGroupStart")
+      BIND(GroupEnd, "ncclGroupEnd")
+      BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
-  });
-  if (!r.handle) return cusift_fail(CUSIFT_ERR_INVALID, "RCCL not found (%s); set CUSIFT_RCCL_LIB", r.error.c_str());
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart ||
-      !r.GroupEnd || !r.GetErrorString)
-    return cusift_fail(CUSIFT_ERR_INVALID, "RCCL at %s is incomplete: %s", r.path.c_str(), r.error.c_str());
+    }
+    it = g_libs.emplace(key, std::move(r)).first;
+  }
+  Rccl *r = it->second.get();
+  if (!r->handle)
+    return cusift_fail(CUSIFT_ERR_INVALID, "RCCL not found (%s); set CUSIFT_RCCL_LIB or call cusift_comm_use_library",
+                       r->error.c_str());
+  if (!r->complete()) return cusift_fail(CUSIFT_ERR_INVALID, "RCCL at %s is incomplete: %s", r->path.c_str(), r->error.c_str());
+  g_lib_path = r->path;
+  *out = r;
   return CUSIFT_OK;
 }
-
-#define NCCL_TRY(expr)                                                                                              \
-  do {                                                                                                              \
-    ncclResult_t r_ = (expr);                                                                                       \
-    if (r_ != ncclSuccess)                                                                                          \
-      return cusift_fail(CUSIFT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl_state().GetErrorString(r_), __FILE__, \
-                         __LINE__);                                                                                 \
-  } while (0)
 
 static_assert(CUSIFT_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "cusift_comm ids are ncclUniqueId");
 static_assert(sizeof(cusift_point) % 4 == 0, "records travel as 32-bit words");
 constexpr size_t kWordsPerPoint = sizeof(cusift_point) / 4;  // 147
+constexpr int kSeqWords = 32;  // a ticket's arrival flag sits on a 128-byte line of its own
 
 // valid[i] = min(counters[i], max_pts) for the rank's images, 0 for the padding slots up to n_slots
 __global__ void clamp_counts_kernel(const unsigned int *__restrict__ counters, int n_images, int max_pts,
@@ -142,57 +160,174 @@ __global__ void clamp_counts_kernel(const unsigned int *__restrict__ counters, i
   valid[i] = c;
 }
 
+// The gathered counts go to pinned host memory by a kernel, followed by a sequence number the host can poll: no event,
+// no copy engine, no HIP call on the reading side.  One workgroup; `n` is at most world * 256.
+__global__ void __launch_bounds__(256) publish_counts_kernel(const unsigned int *__restrict__ d_all, int n,
+                                                             unsigned int *__restrict__ h_all,
+                                                             unsigned int *__restrict__ h_seq, unsigned int seq) {
+  for (int i = threadIdx.x; i < n; i += 256) __builtin_nontemporal_store(d_all[i], h_all + i);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+// One all-gatherv in flight.
+struct GatherTicket {
+  unsigned int *d_local = nullptr;  // [n_slots]          this rank's clamped counts
+  unsigned int *d_all = nullptr;    // [world * n_slots]  everybody's
+  unsigned int *h_all = nullptr;    // pinned twin of d_all, written by publish_counts_kernel
+  unsigned int *h_seq = nullptr;    // pinned; == seq once h_all is complete
+  unsigned int *dev_h_all = nullptr, *dev_h_seq = nullptr;  // the device's addresses of the two pinned blocks
+  unsigned int seq = 0;
+  cusift_point *d_gathered = nullptr;
+  size_t region_cap = 0;
+  int slots = 0;  // count slots per rank of THIS exchange (<= comm n_slots)
+};
 
 struct cusift_comm {
   cusift_ctx *ctx = nullptr;  // device + stream every exchange is enqueued on (not owned)
   hipStream_t stream = nullptr;
   int device = 0, rank = 0, world = 1;
+  Rccl *lib = nullptr;
   ncclComm_t nccl = nullptr;
   int self_p2p = 0;  // world 1 / tests: route the local shard through ncclSend/ncclRecv to self as well
-  // counts of the all-gatherv in flight
-  int n_slots = 0;                         // count slots per rank of the buffers below
-  unsigned int *d_local = nullptr;         // [n_slots]
-  unsigned int *d_all = nullptr;           // [world * n_slots]
-  unsigned int *h_all = nullptr;           // pinned, [world * n_slots]
-  hipEvent_t counts_ready = nullptr;
-  bool pending = false;
-  const cusift_point *p_points = nullptr;  // arguments of the pending begin()
-  const unsigned int *p_counters = nullptr;
-  int p_images = 0, p_max_pts = 0, p_slots = 0;
-  cusift_point *d_stage = nullptr;         // self_p2p only: the packed local shard before it is "sent"
+  int fixed = 0;     // 1: whole regions travel (region_cap records per peer), posted by begin(); no host read at all
+  // ring of tickets: [head, head + pending) are in flight, oldest first
+  int n_slots = 0, depth = 0, head = 0, pending = 0;
+  unsigned int next_seq = 1;
+  std::vector<GatherTicket> tickets;
+  unsigned int *d_block = nullptr, *h_block = nullptr;
+  cusift_point *d_stage = nullptr;  // self_p2p only: the packed local shard before it is "sent" into its region
   size_t stage_cap = 0;
+  unsigned long long host_waits = 0;  // finish() calls that found their counts not yet arrived (diagnostic)
 };
 
-static int comm_enter(cusift_comm *c) {
+namespace {
+
+#define NCCL_TRY(c, expr)                                                                                            \
+  do {                                                                                                               \
+    ncclResult_t r_ = (expr);                                                                                        \
+    if (r_ != ncclSuccess)                                                                                           \
+      return cusift_fail(CUSIFT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (c)->lib->GetErrorString(r_), __FILE__,     \
+                         __LINE__);                                                                                  \
+  } while (0)
+
+// ncclGroupStart .. ncclGroupEnd with the end guaranteed: an error return between the two must not leave the thread's
+// group open (every later RCCL call of the thread would be queued into it and never run).
+struct GroupScope {
+  Rccl *lib;
+  bool open = false;
+  explicit GroupScope(Rccl *l) : lib(l) {}
+  ncclResult_t start() {
+    ncclResult_t r = lib->GroupStart();
+    open = r == ncclSuccess;
+    return r;
+  }
+  ncclResult_t end() {
+    open = false;
+    return lib->GroupEnd();
+  }
+  ~GroupScope() {
+    if (open) (void)lib->GroupEnd();
+  }
+};
+
+int comm_enter(cusift_comm *c) {
   if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
   HIP_TRY(hipSetDevice(c->device));
   return CUSIFT_OK;
 }
 
-static int ensure_slots(cusift_comm *c, int n_slots) {
-  if (n_slots <= c->n_slots) return CUSIFT_OK;
+void free_tickets(cusift_comm *c) {
+  if (c->d_block) (void)hipFree(c->d_block);
+  if (c->h_block) (void)hipHostFree(c->h_block);
+  c->d_block = c->h_block = nullptr;
+  c->tickets.clear();
+  c->n_slots = c->depth = c->head = c->pending = 0;
+}
+
+// (Re)builds the ticket ring: `depth` tickets of `n_slots` count slots per rank.  Synchronises; call before the loop.
+int reserve_tickets(cusift_comm *c, int n_slots, int depth) {
+  if (n_slots <= c->n_slots && depth <= c->depth) return CUSIFT_OK;
+  if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: cannot re-size the ticket ring with exchanges in flight");
+  n_slots = std::max(n_slots, c->n_slots);
+  depth = std::max(depth, c->depth);
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->d_local) HIP_TRY(hipFree(c->d_local));
-  if (c->d_all) HIP_TRY(hipFree(c->d_all));
-  if (c->h_all) HIP_TRY(hipHostFree(c->h_all));
-  c->d_local = c->d_all = c->h_all = nullptr;
-  c->n_slots = 0;
-  HIP_TRY(hipMalloc((void **)&c->d_local, sizeof(unsigned int) * n_slots));
-  HIP_TRY(hipMalloc((void **)&c->d_all, sizeof(unsigned int) * (size_t)n_slots * c->world));
-  HIP_TRY(hipHostMalloc((void **)&c->h_all, sizeof(unsigned int) * (size_t)n_slots * c->world, hipHostMallocDefault));
+  free_tickets(c);
+  const size_t W = (size_t)c->world;
+  const size_t d_words = (size_t)n_slots * (1 + W);
+  const size_t h_words = (size_t)n_slots * W + kSeqWords;
+  HIP_TRY(hipMalloc((void **)&c->d_block, sizeof(unsigned int) * d_words * depth));
+  HIP_TRY(hipHostMalloc((void **)&c->h_block, sizeof(unsigned int) * h_words * depth,
+                        hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c->h_block, 0, sizeof(unsigned int) * h_words * depth);
+  c->tickets.resize(depth);
+  for (int t = 0; t < depth; ++t) {
+    GatherTicket &k = c->tickets[t];
+    k.d_local = c->d_block + d_words * t;
+    k.d_all = k.d_local + n_slots;
+    k.h_seq = c->h_block + h_words * t;
+    k.h_all = k.h_seq + kSeqWords;
+    HIP_TRY(hipHostGetDevicePointer((void **)&k.dev_h_seq, k.h_seq, 0));
+    k.dev_h_all = k.dev_h_seq + kSeqWords;
+  }
   c->n_slots = n_slots;
+  c->depth = depth;
   return CUSIFT_OK;
 }
+
+int reserve_stage(cusift_comm *c, size_t records) {
+  if (records <= c->stage_cap) return CUSIFT_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->d_stage) HIP_TRY(hipFree(c->d_stage));
+  c->d_stage = nullptr;
+  c->stage_cap = 0;
+  HIP_TRY(hipMalloc((void **)&c->d_stage, sizeof(cusift_point) * records));
+  c->stage_cap = records;
+  return CUSIFT_OK;
+}
+
+// ONE group: every shard goes straight to every peer (and arrives straight from it) over the direct xGMI link.
+// n_records[r] = records rank r contributes (exact mode: its valid total; fixed mode: region_cap for everybody).
+int post_shards(cusift_comm *c, const GatherTicket &k, const size_t *n_records) {
+  const int W = c->world;
+  const int first = c->self_p2p ? 0 : 1;
+  if (first >= W) return CUSIFT_OK;
+  const size_t mine = n_records[c->rank];
+  const cusift_point *src = c->self_p2p ? c->d_stage : k.d_gathered + (size_t)c->rank * k.region_cap;
+  GroupScope g(c->lib);
+  NCCL_TRY(c, g.start());
+  for (int step = first; step < W; ++step) {
+    const int to = (c->rank + step) % W, from = (c->rank - step + W) % W;
+    if (mine > 0) NCCL_TRY(c, c->lib->Send(src, mine * kWordsPerPoint, ncclUint32, to, c->nccl, c->stream));
+    if (n_records[from] > 0)
+      NCCL_TRY(c, c->lib->Recv(k.d_gathered + (size_t)from * k.region_cap, n_records[from] * kWordsPerPoint, ncclUint32,
+                               from, c->nccl, c->stream));
+  }
+  NCCL_TRY(c, g.end());
+  return CUSIFT_OK;
+}
+
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // communicator
 // ------------------------------------------------------------------------------------------------
+extern "C" int cusift_comm_use_library(const char *path) {
+  std::lock_guard<std::mutex> lock(g_lib_mu);
+  g_lib_choice = path ? path : "";
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_comm_get_unique_id(char id[CUSIFT_UNIQUE_ID_BYTES]) {
   if (!id) return cusift_fail(CUSIFT_ERR_INVALID, "id is NULL");
-  TRY(load_rccl());
+  Rccl *lib = nullptr;
+  TRY(load_rccl(&lib));
   ncclUniqueId u;
-  NCCL_TRY(rccl_state().GetUniqueId(&u));
+  ncclResult_t r = lib->GetUniqueId(&u);
+  if (r != ncclSuccess) return cusift_fail(CUSIFT_ERR_HIP, "ncclGetUniqueId failed: %s", lib->GetErrorString(r));
   memcpy(id, u.internal, CUSIFT_UNIQUE_ID_BYTES);
   return CUSIFT_OK;
 }
@@ -203,31 +338,24 @@ extern "C" int cusift_comm_create(cusift_comm **out, cusift_ctx *ctx, const char
   *out = nullptr;
   if (!ctx || !id) return cusift_fail(CUSIFT_ERR_INVALID, "ctx / id is NULL");
   if (world < 1 || rank < 0 || rank >= world) return cusift_fail(CUSIFT_ERR_INVALID, "bad rank %d of %d", rank, world);
-  TRY(load_rccl());
+  Rccl *lib = nullptr;
+  TRY(load_rccl(&lib));
   const int device = cusift_ctx_device(ctx);
   HIP_TRY(hipSetDevice(device));
-  cusift_comm *c = new cusift_comm();
+  std::unique_ptr<cusift_comm> c(new cusift_comm());
   c->ctx = ctx;
   c->stream = (hipStream_t)cusift_ctx_stream(ctx);
   c->device = device;
   c->rank = rank;
   c->world = world;
+  c->lib = lib;
   if (const char *e = getenv("CUSIFT_COMM_SELF_P2P")) c->self_p2p = atoi(e) != 0;
   ncclUniqueId u;
   memcpy(u.internal, id, CUSIFT_UNIQUE_ID_BYTES);
-  ncclResult_t r = rccl_state().CommInitRank(&c->nccl, world, u, rank);
-  if (r != ncclSuccess) {
-    delete c;
-    return cusift_fail(CUSIFT_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world,
-                       rccl_state().GetErrorString(r));
-  }
-  hipError_t e = hipEventCreateWithFlags(&c->counts_ready, hipEventDisableTiming);
-  if (e != hipSuccess) {
-    (void)rccl_state().CommDestroy(c->nccl);
-    delete c;
-    return cusift_fail(CUSIFT_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
-  }
-  *out = c;
+  ncclResult_t r = lib->CommInitRank(&c->nccl, world, u, rank);
+  if (r != ncclSuccess)
+    return cusift_fail(CUSIFT_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, lib->GetErrorString(r));
+  *out = c.release();
   return CUSIFT_OK;
 }
 
@@ -235,11 +363,8 @@ extern "C" int cusift_comm_destroy(cusift_comm *c) {
   if (!c) return CUSIFT_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->nccl) (void)rccl_state().CommDestroy(c->nccl);
-  if (c->counts_ready) (void)hipEventDestroy(c->counts_ready);
-  if (c->d_local) (void)hipFree(c->d_local);
-  if (c->d_all) (void)hipFree(c->d_all);
-  if (c->h_all) (void)hipHostFree(c->h_all);
+  if (c->nccl) (void)c->lib->CommDestroy(c->nccl);
+  free_tickets(c);
   if (c->d_stage) (void)hipFree(c->d_stage);
   delete c;
   return CUSIFT_OK;
@@ -252,102 +377,158 @@ extern "C" int cusift_comm_rank(cusift_comm *c, int *rank, int *world) {
   return CUSIFT_OK;
 }
 
+extern "C" cusift_ctx *cusift_comm_ctx(cusift_comm *c) { return c ? c->ctx : nullptr; }
+
 extern "C" int cusift_comm_set_self_p2p(cusift_comm *c, int on) {
   if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
+  if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: exchanges in flight");
   c->self_p2p = on != 0;
   return CUSIFT_OK;
 }
 
-extern "C" const char *cusift_comm_library(void) { return rccl_state().path.c_str(); }
+extern "C" int cusift_comm_set_fixed_size(cusift_comm *c, int on) {
+  if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
+  if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: exchanges in flight");
+  c->fixed = on != 0;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_comm_reserve(cusift_comm *c, int n_images_max, int tickets, size_t stage_records) {
+  TRY(comm_enter(c));
+  if (n_images_max < 1 || n_images_max > cusift::kMaxFlatImages || tickets < 1 || tickets > 64)
+    return cusift_fail(CUSIFT_ERR_INVALID, "comm_reserve: need 1 <= n_images_max <= %d and 1 <= tickets <= 64",
+                       cusift::kMaxFlatImages);
+  TRY(reserve_tickets(c, n_images_max, tickets));
+  if (c->self_p2p && stage_records) TRY(reserve_stage(c, stage_records));
+  return CUSIFT_OK;
+}
+
+extern "C" unsigned long long cusift_comm_host_waits(cusift_comm *c) { return c ? c->host_waits : 0; }
+
+extern "C" const char *cusift_comm_library(void) {
+  std::lock_guard<std::mutex> lock(g_lib_mu);
+  static thread_local std::string copy;
+  copy = g_lib_path;
+  return copy.c_str();
+}
 
 // ------------------------------------------------------------------------------------------------
 // all-gatherv of SiftData
 // ------------------------------------------------------------------------------------------------
-extern "C" int cusift_allgatherv_begin(cusift_comm *c, const cusift_point *d_points, const unsigned int *d_counters,
-                                       int n_images, int max_pts, int n_images_max) {
+extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, const cusift_point *d_points,
+                                       const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
+                                       cusift_point *d_gathered, size_t region_cap) {
   TRY(comm_enter(c));
-  if (!d_points || !d_counters) return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: missing data");
-  if (n_images < 0 || n_images > cusift::kMaxFlatImages || max_pts < 1 || n_images_max < std::max(1, n_images))
-    return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: need 0 <= n_images <= %d, n_images <= n_images_max, max_pts >= 1",
+  if ((n_images > 0 && (!d_points || !d_counters)) || !d_gathered)
+    return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: missing data");
+  if (n_images < 0 || n_images > cusift::kMaxFlatImages || max_pts < 1 || n_images_max < std::max(1, n_images) ||
+      n_images_max > cusift::kMaxFlatImages || region_cap < 1)
+    return cusift_fail(CUSIFT_ERR_INVALID,
+                       "allgatherv: need 0 <= n_images <= n_images_max <= %d, max_pts >= 1, region_cap >= 1",
                        cusift::kMaxFlatImages);
-  if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: the previous begin() has not been finished");
-  TRY(ensure_slots(c, n_images_max));
+  if (region_cap * kWordsPerPoint > (size_t)0x7fffffff * 4)
+    return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: region_cap too large");
+  // everything that can allocate (and therefore synchronise) happens here, before anything is enqueued; a caller that
+  // called cusift_comm_reserve() never gets past these two ifs
+  if (n_images_max > c->n_slots || c->depth == 0) TRY(reserve_tickets(c, n_images_max, std::max(c->depth, 4)));
+  if (c->self_p2p) TRY(reserve_stage(c, region_cap));
+  if (c->pending == c->depth)
+    return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: %d exchanges in flight already (cusift_comm_reserve sets the depth)",
+                       c->depth);
+  // the records are produced on another stream: order this exchange after everything enqueued there so far
+  if (producer) TRY(cusift_ctx_wait(c->ctx, producer));
+  GatherTicket &k = c->tickets[(c->head + c->pending) % c->depth];
+  k.seq = c->next_seq++;
+  k.d_gathered = d_gathered;
+  k.region_cap = region_cap;
+  k.slots = n_images_max;
   hipLaunchKernelGGL(clamp_counts_kernel, dim3((n_images_max + 255) / 256), dim3(256), 0, c->stream, d_counters,
-                     n_images, max_pts, c->d_local, n_images_max);
+                     n_images, max_pts, k.d_local, n_images_max);
   HIP_TRY(hipGetLastError());
-  NCCL_TRY(rccl_state().AllGather(c->d_local, c->d_all, (size_t)n_images_max, ncclUint32, c->nccl, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, sizeof(unsigned int) * (size_t)n_images_max * c->world,
-                         hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipEventRecord(c->counts_ready, c->stream));
-  c->pending = true;
-  c->p_points = d_points;
-  c->p_counters = d_counters;
-  c->p_images = n_images;
-  c->p_max_pts = max_pts;
-  c->p_slots = n_images_max;
+  // the local shard is packed straight into its region of the gathered buffer and sent from there: once this has run
+  // the caller's d_points / d_counters are free again
+  if (n_images > 0)
+    TRY(cusift_pack_points(c->ctx, d_points, d_counters, n_images, max_pts,
+                           c->self_p2p ? c->d_stage : d_gathered + (size_t)c->rank * region_cap, region_cap, nullptr));
+  NCCL_TRY(c, c->lib->AllGather(k.d_local, k.d_all, (size_t)n_images_max, ncclUint32, c->nccl, c->stream));
+  hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, c->stream, k.d_all, n_images_max * c->world,
+                     k.dev_h_all, k.dev_h_seq, k.seq);
+  HIP_TRY(hipGetLastError());
+  c->pending++;
+  if (c->fixed) {
+    std::vector<size_t> n((size_t)c->world, region_cap);
+    TRY(post_shards(c, k, n.data()));
+  }
   return CUSIFT_OK;
 }
 
-extern "C" int cusift_allgatherv_finish(cusift_comm *c, cusift_point *d_gathered, size_t capacity,
-                                        unsigned int *h_counts, size_t *h_offsets) {
+extern "C" int cusift_allgatherv_finish(cusift_comm *c, unsigned int *h_counts, size_t *h_totals) {
   TRY(comm_enter(c));
   if (!c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: finish() without begin()");
-  if (!d_gathered) return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: d_gathered is NULL");
-  // The one host wait of the exchange: the sizes of ncclSend/ncclRecv are host arguments.  A pipelined caller enqueues
-  // its next extraction between begin() and finish(), by which time this event has long fired.
-  HIP_TRY(hipEventSynchronize(c->counts_ready));
-  c->pending = false;
-  const int W = c->world, S = c->p_slots;
-  std::vector<size_t> off((size_t)W + 1, 0);
+  GatherTicket &k = c->tickets[c->head];
+  // The sizes of ncclSend/ncclRecv are host arguments, so the counts are READ here; they are not WAITED for when the
+  // caller keeps a step or more of other work between begin() and finish() (bench.py: as many as it has streams) --
+  // the flag was set long ago.  No HIP call is involved either way.
+  const volatile unsigned int *seq = k.h_seq;
+  if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != k.seq) {
+    c->host_waits++;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long spins = 0;
+    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != k.seq) {
+      if ((++spins & 1023) == 0) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+          c->head = (c->head + 1) % c->depth;
+          c->pending--;
+          return cusift_fail(CUSIFT_ERR_HIP, "allgatherv: the gathered counts never arrived (a rank missing from the "
+                                             "exchange, or the device is hung)");
+        }
+      }
+    }
+  }
+  c->head = (c->head + 1) % c->depth;
+  c->pending--;
+  const int W = c->world, S = k.slots;
+  std::vector<size_t> n((size_t)W, 0);
+  bool fits = true;
   for (int r = 0; r < W; ++r) {
-    size_t t = 0;
-    for (int i = 0; i < S; ++i) t += c->h_all[(size_t)r * S + i];
-    off[r + 1] = off[r] + t;
+    for (int i = 0; i < S; ++i) n[r] += k.h_all[(size_t)r * S + i];
+    fits = fits && n[r] <= k.region_cap;
   }
-  if (h_counts) memcpy(h_counts, c->h_all, sizeof(unsigned int) * (size_t)W * S);
-  if (h_offsets) memcpy(h_offsets, off.data(), sizeof(size_t) * ((size_t)W + 1));
-  if (off[W] > capacity)
-    return cusift_fail(CUSIFT_ERR_NOMEM, "allgatherv: %zu records gathered but d_gathered holds %zu", off[W], capacity);
-  const size_t mine = off[c->rank + 1] - off[c->rank];
-  // the local shard is packed straight into its place in the gathered buffer and sent from there
-  cusift_point *dst_mine = d_gathered + off[c->rank];
-  cusift_point *pack_to = dst_mine;
-  if (c->self_p2p && mine > 0) {
-    if (mine > c->stage_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      if (c->d_stage) HIP_TRY(hipFree(c->d_stage));
-      c->d_stage = nullptr;
-      c->stage_cap = 0;
-      HIP_TRY(hipMalloc((void **)&c->d_stage, sizeof(cusift_point) * mine));
-      c->stage_cap = mine;
-    }
-    pack_to = c->d_stage;
-  }
-  if (mine > 0 && c->p_images > 0)
-    TRY(cusift_pack_points(c->ctx, c->p_points, c->p_counters, c->p_images, c->p_max_pts, pack_to, mine, nullptr));
-  // ONE group: every shard goes straight to every peer (and arrives straight from it) over the direct xGMI link
-  Rccl &R = rccl_state();
-  bool any = false;
-  for (int step = c->self_p2p ? 0 : 1; step < W; ++step) any = true;
-  if (any) {
-    NCCL_TRY(R.GroupStart());
-    for (int step = c->self_p2p ? 0 : 1; step < W; ++step) {
-      const int to = (c->rank + step) % W, from = (c->rank - step + W) % W;
-      const size_t n_from = off[from + 1] - off[from];
-      if (mine > 0) NCCL_TRY(R.Send(pack_to, mine * kWordsPerPoint, ncclUint32, to, c->nccl, c->stream));
-      if (n_from > 0)
-        NCCL_TRY(R.Recv(d_gathered + off[from], n_from * kWordsPerPoint, ncclUint32, from, c->nccl, c->stream));
-    }
-    NCCL_TRY(R.GroupEnd());
-  }
-  return CUSIFT_OK;
+  if (h_counts) memcpy(h_counts, k.h_all, sizeof(unsigned int) * (size_t)W * S);
+  if (h_totals) memcpy(h_totals, n.data(), sizeof(size_t) * (size_t)W);
+  // every rank sees the same counts, so every rank takes this exit together: nothing is left half posted
+  if (!fits)
+    return cusift_fail(CUSIFT_ERR_NOMEM, "allgatherv: a rank gathered more records than a region of d_gathered holds (%zu)",
+                       k.region_cap);
+  if (c->fixed) return CUSIFT_OK;  // the regions travelled whole, posted by begin()
+  return post_shards(c, k, n.data());
 }
 
-extern "C" int cusift_allgatherv(cusift_comm *c, const cusift_point *d_points, const unsigned int *d_counters,
-                                 int n_images, int max_pts, int n_images_max, cusift_point *d_gathered, size_t capacity,
-                                 unsigned int *h_counts, size_t *h_offsets) {
-  TRY(cusift_allgatherv_begin(c, d_points, d_counters, n_images, max_pts, n_images_max));
-  return cusift_allgatherv_finish(c, d_gathered, capacity, h_counts, h_offsets);
+extern "C" int cusift_allgatherv(cusift_comm *c, cusift_ctx *producer, const cusift_point *d_points,
+                                 const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
+                                 cusift_point *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals) {
+  TRY(cusift_allgatherv_begin(c, producer, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered,
+                              region_cap));
+  return cusift_allgatherv_finish(c, h_counts, h_totals);
+}
+
+extern "C" int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_gathered, size_t region_cap, int world,
+                                       const size_t *h_totals, cusift_point *d_out, size_t capacity) {
+  if (!ctx || !d_gathered || !h_totals || !d_out || world < 1)
+    return cusift_fail(CUSIFT_ERR_INVALID, "compact_gathered: bad argument");
+  HIP_TRY(hipSetDevice(cusift_ctx_device(ctx)));
+  size_t at = 0;
+  for (int r = 0; r < world; ++r) {
+    if (h_totals[r] > region_cap || at + h_totals[r] > capacity)
+      return cusift_fail(CUSIFT_ERR_NOMEM, "compact_gathered: rank %d holds %zu records (region %zu, room %zu)", r,
+                         h_totals[r], region_cap, capacity - at);
+    if (h_totals[r])
+      HIP_TRY(hipMemcpyAsync(d_out + at, d_gathered + (size_t)r * region_cap, sizeof(cusift_point) * h_totals[r],
+                             hipMemcpyDeviceToDevice, (hipStream_t)cusift_ctx_stream(ctx)));
+    at += h_totals[r];
+  }
+  return CUSIFT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,17 +550,17 @@ extern "C" int cusift_exchange_rows(cusift_comm *c, float *d_band, int pitch, in
     any = any || send_rows[i] > 0 || recv_rows[i] > 0;
   }
   if (!any) return CUSIFT_OK;
-  Rccl &R = rccl_state();
-  NCCL_TRY(R.GroupStart());
+  GroupScope g(c->lib);
+  NCCL_TRY(c, g.start());
   for (int i = 0; i < n_ops; ++i) {
     if (send_rows[i] > 0)
-      NCCL_TRY(R.Send(d_band + (size_t)send_row[i] * pitch, (size_t)send_rows[i] * pitch, ncclFloat32, peers[i], c->nccl,
-                      c->stream));
+      NCCL_TRY(c, c->lib->Send(d_band + (size_t)send_row[i] * pitch, (size_t)send_rows[i] * pitch, ncclFloat32, peers[i],
+                               c->nccl, c->stream));
     if (recv_rows[i] > 0)
-      NCCL_TRY(R.Recv(d_band + (size_t)recv_row[i] * pitch, (size_t)recv_rows[i] * pitch, ncclFloat32, peers[i], c->nccl,
-                      c->stream));
+      NCCL_TRY(c, c->lib->Recv(d_band + (size_t)recv_row[i] * pitch, (size_t)recv_rows[i] * pitch, ncclFloat32, peers[i],
+                               c->nccl, c->stream));
   }
-  NCCL_TRY(R.GroupEnd());
+  NCCL_TRY(c, g.end());
   return CUSIFT_OK;
 }
 

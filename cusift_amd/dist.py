@@ -6,9 +6,8 @@ final all-gatherv of the variable-length SiftPoint lists:
 
   1. all_gather of the per-image counts                      (n_local int32 per rank, tiny)
   2. exact-count exchange of the packed 588-byte records, rank to rank.  xGMI is point-to-point
-     (7 links per GPU): the default method posts one send/recv pair per peer in a single group
-     (RCCL grouped p2p), so every shard travels over its own link instead of hopping round a ring.
-     `method="padded"` is the fallback: pad to the largest shard and use one all_gather_into_tensor.
+     (7 links per GPU): one send/recv pair per peer in a single group (RCCL grouped p2p), so every shard
+     travels over its own link instead of hopping round a ring.
 
 On GPUs the exchange is the C ABI's (cusift_comm_* / cusift_allgatherv_*, csrc/sift_comm.hip: RCCL called directly
 from C++) and this module is a thin caller: `make_comm` hands the communicator's unique id to every rank through
@@ -40,38 +39,56 @@ def make_comm(ctx, group=None, self_p2p=False):
 class SiftGatherer:
     """All-gatherv of SiftData on GPUs through the C ABI, with everything allocated once.
 
-        g = SiftGatherer(comm, n_images_max=64, max_pts=32768, capacity=world * 64 * 8192)
-        g.begin(points, counts)                 # asynchronous: counts exchange (enqueued on the comm's stream)
-        ...                                     # enqueue the next extraction meanwhile
-        counts, gathered, offsets = g.finish()  # packs + posts the grouped ncclSend/ncclRecv; `gathered` is a view of
-                                                # an internal ring buffer (n_out deep), valid until n_out finishes later
-    `capacity` = records the gathered buffer holds (default: the worst case world * n_images_max * max_pts)."""
+        g = SiftGatherer(comm, n_images_max=64, max_pts=32768, region_cap=64 * 8192, depth=4)
+        g.begin(points, counts, producer=ex.ctx)   # asynchronous: ordered after the extraction on ex.ctx's stream;
+                                                   # counts exchange + the local shard packed into its region
+        ex.ctx.wait(comm.ctx)                      # (before the NEXT extraction into `points`: the pack reads them)
+        ...                                        # enqueue further extractions meanwhile -- up to `depth` begins may
+                                                   # be outstanding
+        counts, gathered, totals = g.finish()      # of the OLDEST begin: host read of the counts (arrived long ago in a
+                                                   # pipelined loop -> no wait), then the grouped ncclSend/ncclRecv
+    `gathered` is a [world, region_cap, 588] uint8 view of an internal ring buffer (n_out deep, n_out >= depth), valid
+    until n_out begins later; rank r's records are gathered[r, :totals[r]] in image order (`regions()` lists them).
+    `region_cap` = records one rank's region holds (default: the worst case n_images_max * max_pts).
+    The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: order
+    the producer's next write after it with `producer_ctx.wait(comm.ctx)` (no host wait), or synchronise."""
 
-    def __init__(self, comm, n_images_max, max_pts, capacity=None, device=None, n_out=2):
+    def __init__(self, comm, n_images_max, max_pts, region_cap=None, device=None, n_out=2, depth=1, fixed_size=False):
         self.comm, self.n_max, self.max_pts = comm, int(n_images_max), int(max_pts)
-        self.capacity = int(capacity) if capacity else comm.world * self.n_max * self.max_pts
+        self.region_cap = int(region_cap) if region_cap else self.n_max * self.max_pts
         self.device = torch.device("cuda", comm.ctx.device) if device is None else torch.device(device)
-        self.out = [torch.empty((self.capacity, SIFT_POINT_BYTES), dtype=torch.uint8, device=self.device)
-                    for _ in range(max(1, n_out))]
+        self.depth = max(1, int(depth))
+        n_out = max(int(n_out), self.depth)
+        self.out = [torch.empty((comm.world, self.region_cap, SIFT_POINT_BYTES), dtype=torch.uint8, device=self.device)
+                    for _ in range(n_out)]
+        comm.reserve(self.n_max, self.depth, self.region_cap)
+        if fixed_size:
+            comm.set_fixed_size(True)
         self.k = 0
-        self._held = None
+        self._inflight = []  # (output buffer, held producer tensors), oldest first
 
-    def begin(self, points, counts):
+    def begin(self, points, counts, producer=None):
         assert points.is_cuda and points.is_contiguous() and counts.is_cuda and counts.dtype == torch.int32
         n = int(points.shape[0])
-        self._held = (points, counts)  # keep the tensors alive until finish()
-        self.comm.allgatherv_begin(points.data_ptr(), counts.data_ptr(), n, self.max_pts, self.n_max)
-
-    def finish(self):
         buf = self.out[self.k % len(self.out)]
         self.k += 1
-        counts, offsets = self.comm.allgatherv_finish(buf.data_ptr(), self.capacity)
-        self._held = None
-        return counts, buf[: int(offsets[-1])], offsets
+        self.comm.allgatherv_begin(points.data_ptr(), counts.data_ptr(), n, self.max_pts, self.n_max, buf.data_ptr(),
+                                   self.region_cap, producer=producer)
+        self._inflight.append((buf, (points, counts)))  # the tensors stay alive until the exchange has been posted
 
-    def gather(self, points, counts):
-        self.begin(points, counts)
+    def finish(self):
+        buf, _held = self._inflight.pop(0)
+        counts, totals = self.comm.allgatherv_finish()
+        return counts, buf, totals
+
+    def gather(self, points, counts, producer=None):
+        self.begin(points, counts, producer)
         return self.finish()
+
+    @staticmethod
+    def regions(gathered, totals):
+        """List (over ranks) of [totals[r], 588] uint8 views of one gathered buffer."""
+        return [gathered[r, : int(totals[r])] for r in range(gathered.shape[0])]
 
 
 def shard_range(n_total, rank, world):

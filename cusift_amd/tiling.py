@@ -25,9 +25,13 @@ initBlur and subsampling: identical arithmetic, hence identical keypoints).  819
 tiled (1024 .. 64 owned rows per rank), octaves 5 and 6 (256 and 128 rows in total) run on rank 0.
 The merged SiftData is the all-gatherv of the per-rank lists (cusift_allgatherv / cusift_amd.dist).
 
-`StripExtractor` is one rank.  `run_distributed` drives it across processes (exchange = the C ABI communicator, or
-torch.distributed for CPU tensors over gloo -- the host-logic twin used by tests); `run_virtual` drives P extractors in
-one process (exchange = device copies) -- used by the single-GPU tests and to time one rank's work.
+The rank-side driver lives behind the C ABI (csrc/sift_tiled.hip: cusift_tiled_*, mirroring the octave loop of
+cuSIFT.cu:175-202) and this module is a thin caller: `StripExtractor` owns one rank's output buffers and a
+capi.Tiled; `run_distributed` is cusift_tiled_extract (exchange = the C ABI communicator); `run_virtual` steps P
+extractors of one process together (exchange = device copies, cusift_tiled_exchange_virtual) -- used by the
+single-GPU tests and to time one rank's work.  `StripPlan` is the Python twin of the plan (tests/test_tiling_plan.py
+holds it equal to cusift_tiled_plan) used by the gloo host-logic tests, which run the exchange pattern on CPU tensors
+through `exchange_halos`.
 """
 import numpy as np
 import torch
@@ -92,8 +96,9 @@ class StripPlan:
 
 
 class StripExtractor:
-    """One rank of the strip-tiled extraction (needs a GPU).  `comm`: a capi.Comm bound to this extractor's context for
-    the distributed form (run_distributed); None for run_virtual."""
+    """One rank of the strip-tiled extraction (needs a GPU): output buffers + a capi.Tiled.  `comm`: a capi.Comm for
+    the distributed form (run_distributed) -- the extractor then runs on the communicator's context, so kernels and
+    exchanges share one stream; None for run_virtual / world 1 (the context borrows torch's current stream)."""
 
     def __init__(self, rank, world, W, H, params, device=None, halo=HALO, comm=None, strict=True):
         if not torch.cuda.is_available():
@@ -102,140 +107,73 @@ class StripExtractor:
         self.params = params
         self.plan = StripPlan(W, H, world, params.num_octaves, halo)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        pl = self.plan
         with torch.cuda.device(self.device):
-            self.stream = torch.cuda.current_stream()
             if comm is not None:
                 self.ctx, self.owns_ctx = comm.ctx, False
             else:
-                self.ctx, self.owns_ctx = capi.Context(self.device.index, stream=self.stream.cuda_stream), True
+                self.ctx = capi.Context(self.device.index, stream=torch.cuda.current_stream().cuda_stream)
+                self.owns_ctx = True
             self.comm = comm
-            self.bands = []
-            for o in range(min(pl.collapse + 1, pl.n_oct)):
-                lo, hi = pl.band(rank, o)
-                self.bands.append(torch.zeros((hi - lo, pl.pitch[o]), dtype=torch.float32, device=self.device))
-            self.full = None  # the whole collapse octave, on the root
-            if pl.collapse < pl.n_oct and rank == pl.root:
-                oc = pl.collapse
-                self.full = torch.zeros((pl.h[oc], pl.pitch[oc]), dtype=torch.float32, device=self.device)
+            # every torch-side operation on this extractor's tensors goes through the context's own stream
+            h = self.ctx.stream_handle()
+            self.stream = (torch.cuda.ExternalStream(h, device=self.device) if h
+                           else torch.cuda.default_stream(self.device))
+            self.tiled = capi.Tiled(self.ctx, comm, rank, world, W, H, params, halo)
+            assert self.tiled.collapse == self.plan.collapse and self.tiled.n_oct == self.plan.n_oct
             self.max_pts = params.max_pts
-            self.points = torch.zeros((1, self.max_pts, capi.SIFT_POINT_BYTES), dtype=torch.uint8, device=self.device)
-            self.counts = torch.zeros((1,), dtype=torch.int32, device=self.device)
-            self.first = torch.zeros((1,), dtype=torch.int32, device=self.device)
-            self.flags = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        self.blur = octave_blurs(params.init_blur, pl.n_oct)
-        self.sub = [params.subsampling * (2.0 ** o) for o in range(pl.n_oct)]
+            with torch.cuda.stream(self.stream):
+                self.points = torch.zeros((1, self.max_pts, capi.SIFT_POINT_BYTES), dtype=torch.uint8,
+                                          device=self.device)
+                self.counts = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._strip = None
 
-    # ---- data movement ----
-    def load_strip(self, strip):
-        """strip: this rank's owned base rows, (b_{k+1} - b_k, W) float32 on the device."""
+    def _check_strip(self, strip):
         pl = self.plan
         a, b = pl.own(self.rank, 0)
-        lo, _ = pl.band(self.rank, 0)
-        assert tuple(strip.shape) == (b - a, pl.W), (tuple(strip.shape), (b - a, pl.W))
-        with torch.cuda.stream(self.stream):
-            self.bands[0][a - lo: b - lo, : pl.W] = strip
-            self.counts.zero_()
-            self.flags.zero_()
+        assert strip.is_cuda and tuple(strip.shape) == (b - a, pl.W), (tuple(strip.shape), (b - a, pl.W))
+        if strip.dtype != torch.float32 or strip.stride(1) != 1:
+            strip = strip.to(torch.float32).contiguous()
+        # the strip was produced on torch's current stream; the extractor's stream must see it complete
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._strip = strip  # kept alive until the next load
+        return strip.data_ptr(), strip.stride(0)
 
-    def _views(self, o):
-        """(send_up, send_dn, recv_up, recv_dn) row blocks of the band of a tiled octave (None at the image border)."""
-        pl = self.plan
-        a, b = pl.own(self.rank, o)
-        lo, hi = pl.band(self.rank, o)
-        t = self.bands[o]
-        hal = pl.halo
-        send_up = t[a - lo: a - lo + hal] if self.rank > 0 else None            # my first owned rows
-        send_dn = t[b - lo - hal: b - lo] if self.rank < self.world - 1 else None  # my last owned rows
-        recv_up = t[0: a - lo] if self.rank > 0 else None                       # halo above
-        recv_dn = t[b - lo: hi - lo] if self.rank < self.world - 1 else None    # halo below
-        return send_up, send_dn, recv_up, recv_dn
+    def load_strip(self, strip):
+        """strip: this rank's owned base rows, (b_{k+1} - b_k, W) float32 on the device."""
+        self.tiled.load(*self._check_strip(strip))
 
-    def own_rows(self, o):
-        """The owned rows of octave o inside this rank's band (a view)."""
-        pl = self.plan
-        a, b = pl.own(self.rank, o)
-        lo, _ = pl.band(self.rank, o)
-        return self.bands[o][a - lo: b - lo]
+    def extract(self, strip):
+        """The whole rank-side sequence (collective over the communicator); asynchronous."""
+        ptr, pitch = self._check_strip(strip)
+        self.tiled.extract(ptr, pitch, self.points.data_ptr(), self.counts.data_ptr())
+        return self.points, self.counts
 
-    def build_octave(self, o):
-        """ScaleDown the owned rows of octave o from the band of octave o-1 (cuSIFT.cu:185)."""
-        pl = self.plan
-        a, b = pl.own(self.rank, o)
-        lo, _ = pl.band(self.rank, o)
-        slo, shi = pl.band(self.rank, o - 1)
-        if b > a:
-            self.ctx.scale_down_band(self.bands[o].data_ptr(), pl.pitch[o], lo, a, b, self.bands[o - 1].data_ptr(),
-                                     pl.w[o - 1], shi - slo, pl.pitch[o - 1], slo, pl.h[o - 1], 0.5)
-
-    def process_collapsed(self):
-        """Root only: octaves >= collapse as ONE whole-image extraction of the collapse octave (its initBlur, its
-        subsampling, the remaining octave count) -- the ordinary driver, so the ordinary results.  Runs first: the
-        driver zeroes the counter and the coarse octaves lead the list (cuSIFT.cu:190-196)."""
-        pl, p = self.plan, self.params
-        oc = pl.collapse
-        if oc >= pl.n_oct or self.rank != pl.root:
-            return
-        sub = capi.default_params(num_octaves=pl.n_oct - oc, init_blur=self.blur[oc], peak_thresh=p.peak_thresh,
-                                  edge_thresh=p.edge_thresh, lowest_scale=p.lowest_scale, subsampling=self.sub[oc],
-                                  max_pts=p.max_pts, tex_frac_bits=p.tex_frac_bits, fused_detect=p.fused_detect,
-                                  root_sift=p.root_sift)
-        self.ctx.extract_batch(self.full.data_ptr(), 1, pl.w[oc], pl.h[oc], pl.pitch[oc], pl.h[oc] * pl.pitch[oc], sub,
-                               self.points.data_ptr(), self.counts.data_ptr())
-
-    def process_octave(self, o):
-        """ExtractSiftOctave (cuSIFT.cu:204-270) on this rank's band, centres restricted to the owned rows."""
-        pl, p = self.plan, self.params
-        if not (p.lowest_scale < self.sub[o] * 2.0):  # cuSIFT.cu:194
-            return
-        a, b = pl.own(self.rank, o)
-        lo, hi = pl.band(self.rank, o)
-        if b <= a:
-            return
-        with torch.cuda.stream(self.stream):
-            self.first.copy_(self.counts)  # fstPts, cuSIFT.cu:243
-        self.ctx.detect_band(self.bands[o].data_ptr(), pl.w[o], hi - lo, pl.pitch[o], lo, pl.h[o], a, b, self.blur[o],
-                             p.peak_thresh, p.edge_thresh, self.sub[o], self.points.data_ptr(), self.max_pts,
-                             self.counts.data_ptr())
-        self.ctx.describe_band(self.bands[o].data_ptr(), pl.w[o], hi - lo, pl.pitch[o], lo, pl.h[o],
-                               self.points.data_ptr(), self.max_pts, self.first.data_ptr(), self.counts.data_ptr(),
-                               self.sub[o], p.tex_frac_bits, self.flags.data_ptr())
+    def process(self):
+        self.tiled.process(self.points.data_ptr(), self.counts.data_ptr())
 
     def check(self):
         """Blocking: raises if a keypoint's sampling footprint left the halo (its descriptor would differ from the
-        whole image's).  Returns the number of such keypoints' octave launches flagged (0 = all exact)."""
-        f = int(self.flags.item())
-        if f and self.strict:
-            raise capi.CusiftError(
-                "strip tiling: %d keypoint(s) of rank %d sample rows beyond the %d-row halo (scale too large for the "
-                "halo); results would differ from the whole image -- use a larger halo or fewer ranks" %
-                (f, self.rank, self.plan.halo))
-        return f
+        whole image's; strict=False: only counts).  Returns the number of such keypoints (0 = all exact)."""
+        return self.tiled.check(self.strict)
 
     def result(self):
         self.check()
-        n = int(min(int(self.counts.item()), self.max_pts))
-        return self.points[0, :n].cpu().numpy().view(capi.SIFT_POINT_DTYPE).reshape(-1)
+        with torch.cuda.stream(self.stream):
+            n = int(min(int(self.counts.item()), self.max_pts))
+            return self.points[0, :n].cpu().numpy().view(capi.SIFT_POINT_DTYPE).reshape(-1)
 
     def close(self):
+        self.tiled.close()
         if self.owns_ctx:
             self.ctx.close()
 
 
 # ------------------------------------------------------------------------------------------------
-# exchange steps
+# exchange pattern on torch tensors (the gloo host-logic twin of cusift_tiled_exchange)
 # ------------------------------------------------------------------------------------------------
 def exchange_halos(ext, o, group=None):
-    """Tiled octave o: HALO owned rows go to each neighbour, the neighbour's come in.  GPU extractors with a
-    communicator use the C ABI (one ncclGroup); anything else (CPU tensors over gloo: the host-logic twin in
-    tests/tiling_worker.py) torch.distributed P2P ops with the same layout."""
-    comm = getattr(ext, "comm", None)
-    if comm is not None:
-        pl = ext.plan
-        a, b = pl.own(ext.rank, o)
-        lo, hi = pl.band(ext.rank, o)
-        comm.exchange_halos(ext.bands[o].data_ptr(), pl.pitch[o], a - lo, b - a, hi - b, pl.halo)
-        return
+    """Tiled octave o of an object with `_views(o)` (tests/tiling_worker.py's CPU bands): HALO owned rows go to each
+    neighbour, the neighbour's come in, as torch.distributed P2P ops with the layout cusift_exchange_halos uses."""
     send_up, send_dn, recv_up, recv_dn = ext._views(o)
     up, dn = _global_rank(ext.rank - 1, group), _global_rank(ext.rank + 1, group)  # P2POp peers are GLOBAL ranks
     ops = []
@@ -254,74 +192,24 @@ def _global_rank(group_rank, group):
     return group_rank if group is None else dist.get_global_rank(group, group_rank)
 
 
-def gather_collapse_octave(ext, group=None):
-    """Every rank's owned rows of the collapse octave -> the root's whole-octave image."""
-    pl = ext.plan
-    oc = pl.collapse
-    if oc >= pl.n_oct:
-        return
-    comm = getattr(ext, "comm", None)
-    a, b = pl.own(ext.rank, oc)
-    if ext.rank == pl.root:
-        with torch.cuda.stream(ext.stream):
-            ext.full[a:b].copy_(ext.own_rows(oc))
-        ops = []
-        for k in range(ext.world):
-            ka, kb = pl.own(k, oc)
-            if k != pl.root and kb > ka:
-                ops.append((k, 0, 0, ka, kb - ka))
-        if ops:
-            comm.exchange_rows(ext.full.data_ptr(), pl.pitch[oc], ops)
-    elif b > a:
-        lo, _ = pl.band(ext.rank, oc)
-        comm.exchange_rows(ext.bands[oc].data_ptr(), pl.pitch[oc], [(pl.root, a - lo, b - a, 0, 0)])
-
-
-def run_distributed(ext, strip, group=None):
-    """Extract this rank's share of the tiled image; returns (points uint8 [1,max_pts,588], counts int32 [1]).
-    Merge with cusift_amd.dist.SiftGatherer (all-gatherv of SiftData)."""
-    pl = ext.plan
-    ext.load_strip(strip)
-    for o in range(min(pl.collapse + 1, pl.n_oct)):
-        if o > 0:
-            ext.build_octave(o)
-        if pl.tiled(o):
-            if ext.world > 1:
-                exchange_halos(ext, o, group)
-        else:
-            gather_collapse_octave(ext, group)
-    ext.process_collapsed()
-    for o in reversed(range(min(pl.collapse, pl.n_oct))):
-        ext.process_octave(o)
-    return ext.points, ext.counts
+def run_distributed(ext, strip):
+    """Extract this rank's share of the tiled image (cusift_tiled_extract: every rank of the communicator calls it);
+    returns (points uint8 [1,max_pts,588], counts int32 [1]).  Merge with cusift_amd.dist.SiftGatherer."""
+    return ext.extract(strip)
 
 
 def run_virtual(exts, strips):
     """All ranks in one process on one device: the exchanges become device-to-device copies."""
     pl = exts[0].plan
+    tiles = [e.tiled for e in exts]
     for e, s in zip(exts, strips):
         e.load_strip(s)
     for o in range(min(pl.collapse + 1, pl.n_oct)):
         if o > 0:
             for e in exts:
-                e.build_octave(o)
-        if pl.tiled(o):
-            views = [e._views(o) for e in exts]
-            for k, e in enumerate(exts):
-                send_up, send_dn, recv_up, recv_dn = views[k]
-                if recv_up is not None:
-                    recv_up.copy_(views[k - 1][1])   # neighbour above sends its last owned rows down
-                if recv_dn is not None:
-                    recv_dn.copy_(views[k + 1][0])   # neighbour below sends its first owned rows up
-        else:
-            root = exts[pl.root]
-            for k, e in enumerate(exts):
-                a, b = pl.own(k, o)
-                if b > a:
-                    root.full[a:b].copy_(e.own_rows(o))
+                e.tiled.build_octave(o)
+        if len(exts) > 1:
+            capi.tiled_exchange_virtual(tiles, o)
     for e in exts:
-        e.process_collapsed()
-    for o in reversed(range(min(pl.collapse, pl.n_oct))):
-        for e in exts:
-            e.process_octave(o)
+        e.process()
     return [e.result() for e in exts]

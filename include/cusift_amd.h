@@ -213,7 +213,8 @@ int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b
  * cusift_detect_band: fused LaplaceMulti+FindPointsMulti with extremum centres restricted to global rows
  *   [cy_begin, cy_end); keypoint rows are written in global coordinates.  Needs >= 5 halo rows of true data on each
  *   side that is not the image border (4 blur + 1 extremum; CUSIFT_ERR_INVALID otherwise).
- * cusift_describe_band: ComputeOrientations + ExtractSiftDescriptors for keypoints in global coordinates.
+ * cusift_describe_band: ComputeOrientations + ExtractSiftDescriptors for keypoints in global coordinates
+ *   (root_sift as cusift_params.root_sift).
  *   d_flags (may be NULL): one counter, incremented for every keypoint whose sampling footprint (orientation window,
  *   rotated descriptor grid, +-1 px taps, bilinear 2x2) reaches beyond the band on a side that is not the image
  *   border -- such a keypoint samples clamped rows instead of the neighbour's and would differ from the whole image;
@@ -226,7 +227,8 @@ int cusift_detect_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
                        float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counter);
 int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0, int h_global,
                          cusift_point *d_points, int max_pts, const unsigned int *d_first,
-                         const unsigned int *d_counter, float subsampling, int tex_frac_bits, unsigned int *d_flags);
+                         const unsigned int *d_counter, float subsampling, int tex_frac_bits, int root_sift,
+                         unsigned int *d_flags);
 
 /* ---- matcher (first consumer of SiftData) ----------------------------- */
 /* MatchSiftData(data1, data2, distance, ...), extras/matching.cu:232-362: for every point of d_sift1 the best
@@ -267,44 +269,63 @@ int cusift_sort_points_host(cusift_point *h_points, int num_pts);
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI (BASELINE configs[3], [4]) --------------------------------
  * New functionality: the reference is single-GPU, single-image (no collective call sites).
  * A communicator wraps one ncclComm_t bound to a context: every exchange is enqueued on that context's stream.
- * RCCL is loaded at run time from the directory of the process's HIP runtime (or $CUSIFT_RCCL_LIB); a program that
- * never creates a communicator never needs it.
+ * RCCL is loaded at run time from the directory of the process's HIP runtime (or $CUSIFT_RCCL_LIB, or the library
+ * named by cusift_comm_use_library -- any library exporting the nine nccl* entry points used here; the tests bind an
+ * in-process transport that way, next to the real RCCL); a program that never creates a communicator never needs it.
  *   rank 0:  cusift_comm_get_unique_id(id)  -> hand the 128 bytes to every rank (MPI_Bcast, a TCP store, a file ...)
  *   all:     cusift_comm_create(&comm, ctx, id, rank, world)      (collective: ncclCommInitRank)
  */
 #define CUSIFT_UNIQUE_ID_BYTES 128
 typedef struct cusift_comm cusift_comm;
+/* The library cusift_comm_get_unique_id / cusift_comm_create bind from now on (NULL or "": the default search). */
+int cusift_comm_use_library(const char *path);
 int cusift_comm_get_unique_id(char id[CUSIFT_UNIQUE_ID_BYTES]);
 int cusift_comm_create(cusift_comm **out, cusift_ctx *ctx, const char id[CUSIFT_UNIQUE_ID_BYTES], int rank, int world);
 int cusift_comm_destroy(cusift_comm *comm);
 int cusift_comm_rank(cusift_comm *comm, int *rank, int *world);
-/* Path of the RCCL library in use ("" before the first communicator call). */
+cusift_ctx *cusift_comm_ctx(cusift_comm *comm); /* the context (device + stream) the communicator is bound to */
+/* Path of the library bound last ("" before the first communicator call). */
 const char *cusift_comm_library(void);
 /* Tests / world == 1: route the local shard (and rows addressed to this rank) through ncclSend/ncclRecv to self too,
  * so that one GPU exercises the grouped p2p path.  Also settable with CUSIFT_COMM_SELF_P2P=1. */
 int cusift_comm_set_self_p2p(cusift_comm *comm, int on);
+/* Pre-sizes what the all-gatherv needs so that no call of the loop allocates or synchronises: `tickets` exchanges may
+ * be in flight at once (begin() without its finish(); default 4), each with n_images_max count slots per rank;
+ * stage_records only matters with self_p2p (the staging copy of the local shard). */
+int cusift_comm_reserve(cusift_comm *comm, int n_images_max, int tickets, size_t stage_records);
+/* 0 (default): exact sizes -- finish() reads the gathered counts on the host and posts ncclSend/ncclRecv of exactly the
+ * valid records.  1: whole regions travel (region_cap records per peer whatever the counts), posted by begin(): the
+ * exchange needs no host read at all, at the price of the bytes; for small capacities (a tiled image's merge). */
+int cusift_comm_set_fixed_size(cusift_comm *comm, int on);
+/* Diagnostic: how many finish() calls found their counts not yet arrived and had to wait (0 in a pipelined loop). */
+unsigned long long cusift_comm_host_waits(cusift_comm *comm);
 
-/* All-gatherv of SiftData: every rank ends up with the valid records of ALL ranks' images, packed back to back in
- * (rank, image) order.  Two phases so that no host wait sits on a pipelined caller's critical path:
- *   begin  (asynchronous): clamps the per-image counters on the device, ncclAllGather of the counts
- *          (n_images_max slots per rank: the largest image count of any rank, the same value on every rank),
- *          asynchronous copy of the gathered counts to pinned host memory.
- *   finish: waits for that copy (the sizes of ncclSend/ncclRecv are host arguments -- with a step of other work
- *          enqueued in between, the wait has long been satisfied), writes h_counts[world][n_images_max] and
- *          h_offsets[world + 1] (records before each rank's shard; either may be NULL), packs the local shard on the
- *          device straight into d_gathered + h_offsets[rank] and posts ONE ncclGroup of ncclSend/ncclRecv: each shard
- *          travels directly to each peer over its xGMI link.  Asynchronous after the wait.  d_gathered holds
- *          `capacity` records; CUSIFT_ERR_NOMEM (and nothing sent) if the total exceeds it -- size it for the worst
- *          case once (world * n_images_max * max_pts) or for what the scene can yield; no allocation happens here.
- * d_points / d_counters are the outputs of cusift_extract_batch and must stay untouched until finish() has been
- * enqueued and completed.  n_images <= 256.  cusift_allgatherv() = begin + finish. */
-int cusift_allgatherv_begin(cusift_comm *comm, const cusift_point *d_points, const unsigned int *d_counters,
-                            int n_images, int max_pts, int n_images_max);
-int cusift_allgatherv_finish(cusift_comm *comm, cusift_point *d_gathered, size_t capacity, unsigned int *h_counts,
-                             size_t *h_offsets);
-int cusift_allgatherv(cusift_comm *comm, const cusift_point *d_points, const unsigned int *d_counters, int n_images,
-                      int max_pts, int n_images_max, cusift_point *d_gathered, size_t capacity,
-                      unsigned int *h_counts, size_t *h_offsets);
+/* All-gatherv of SiftData: every rank ends up with the valid records of ALL ranks' images.  d_gathered is `world`
+ * REGIONS of region_cap records; region r holds rank r's records packed back to back in image order (h_totals[r] of
+ * them).  Fixed region starts are what lets a rank pack its shard into place before anybody's counts are known.
+ *   begin  (asynchronous, no host wait): orders the exchange after everything enqueued on `producer` so far (the
+ *          context that extracted d_points; NULL: the caller has ordered the streams), clamps the per-image counters on
+ *          the device, packs the local shard straight into region `rank` of d_gathered -- after which d_points /
+ *          d_counters are free again: cusift_ctx_wait(producer, cusift_comm_ctx(comm)) before overwriting them --,
+ *          ncclAllGather of the counts (n_images_max slots per rank: the largest image count of any rank, the same value
+ *          on every rank) and a kernel that publishes them to pinned host memory.
+ *   finish (of the oldest begin): READS the counts on the host -- the sizes of ncclSend/ncclRecv are host arguments --
+ *          which is no wait when the caller has enqueued a step or more of other work since begin() (up to `tickets`
+ *          begins may be outstanding); writes h_counts[world][n_images_max] and h_totals[world] (either may be NULL) and
+ *          posts ONE ncclGroup of ncclSend/ncclRecv: each shard travels directly to each peer over its xGMI link.
+ *          CUSIFT_ERR_NOMEM (on every rank alike, nothing sent) if a rank's total exceeds region_cap.
+ * Nothing here allocates once cusift_comm_reserve() has been called.  n_images <= 256.
+ * cusift_allgatherv() = begin + finish.  cusift_compact_gathered: the regions back to back in rank order (world
+ * asynchronous device copies on ctx's stream), for consumers that want one list. */
+int cusift_allgatherv_begin(cusift_comm *comm, cusift_ctx *producer, const cusift_point *d_points,
+                            const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
+                            cusift_point *d_gathered, size_t region_cap);
+int cusift_allgatherv_finish(cusift_comm *comm, unsigned int *h_counts, size_t *h_totals);
+int cusift_allgatherv(cusift_comm *comm, cusift_ctx *producer, const cusift_point *d_points,
+                      const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
+                      cusift_point *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals);
+int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_gathered, size_t region_cap, int world,
+                            const size_t *h_totals, cusift_point *d_out, size_t capacity);
 
 /* Rows of a pitched float image between ranks, as one ncclGroup: op i sends send_rows[i] rows starting at local row
  * send_row[i] of d_band to peers[i] and receives recv_rows[i] rows from it into local row recv_row[i] (`pitch` floats
@@ -317,6 +338,43 @@ int cusift_exchange_rows(cusift_comm *comm, float *d_band, int pitch, int n_ops,
                          const int *send_rows, const int *recv_row, const int *recv_rows);
 int cusift_exchange_halos(cusift_comm *comm, float *d_band, int pitch, int top_halo, int own_rows, int bottom_halo,
                           int send_rows);
+
+/* ---- one large image strip-tiled over the ranks (BASELINE configs[4]) -------------------------------------------
+ * The rank-side driver of the tiling: plan, bands, per-octave ScaleDown -> halo exchange -> band detection and
+ * description, coarse-octave collapse onto rank 0, footprint check.  Mirrors the octave loop of cuSIFT.cu:175-202 (the
+ * reference itself has no tiling); the union of the ranks' SiftData equals the whole-image extraction bit for bit.
+ * Rank k owns base rows [k*H/world, (k+1)*H/world).  Everything runs on ctx's stream; `comm` (NULL for world == 1 or
+ * for extractors driven with cusift_tiled_exchange_virtual) must be bound to the same context or stream.
+ *   cusift_tiled_create(&t, ctx, comm, rank, world, W, H, &params, 0)     allocates the bands (halo_rows 0 = 48)
+ *   cusift_tiled_extract(t, d_strip, strip_pitch, d_points, d_counter)    collective, asynchronous: my owned base rows
+ *                                                                         in, my SiftData (params.max_pts records) out
+ *   cusift_tiled_check(t, &flagged)                                       blocking; an error if a keypoint's sampling
+ *                                                                         footprint left the halo
+ *   cusift_allgatherv(comm, ...)                                          merged SiftData on every rank
+ * cusift_tiled_extract is cusift_tiled_load, then for each octave o cusift_tiled_build_octave(o) (o > 0) and
+ * cusift_tiled_exchange(o), then cusift_tiled_process; the steps are public so that P extractors of one process can be
+ * stepped together with cusift_tiled_exchange_virtual (device copies instead of RCCL: a plan run on one GPU).
+ * cusift_tiled_plan is the row geometry alone (no GPU): octave sizes, the first collapsed octave (== n_octaves: none),
+ * the rows [own_begin, own_end) rank `rank` owns in `octave` and the rows [band_begin, band_end) its band holds. */
+#define CUSIFT_TILED_DEFAULT_HALO 48
+typedef struct cusift_tiled cusift_tiled;
+int cusift_tiled_plan(int W, int H, int world, int num_octaves, int halo_rows, int rank, int octave, int *n_octaves,
+                      int *collapse_octave, int *w, int *h, int *pitch, int *own_begin, int *own_end, int *band_begin,
+                      int *band_end);
+int cusift_tiled_create(cusift_tiled **out, cusift_ctx *ctx, cusift_comm *comm, int rank, int world, int W, int H,
+                        const cusift_params *p, int halo_rows);
+int cusift_tiled_destroy(cusift_tiled *t);
+int cusift_tiled_info(cusift_tiled *t, int *n_octaves, int *collapse_octave, int *root, int *halo_rows);
+int cusift_tiled_band(cusift_tiled *t, int octave, float **d_band, int *w, int *h_global, int *pitch, int *own_begin,
+                      int *own_end, int *band_begin, int *band_end);
+int cusift_tiled_load(cusift_tiled *t, const float *d_strip, int strip_pitch);
+int cusift_tiled_build_octave(cusift_tiled *t, int octave);
+int cusift_tiled_exchange(cusift_tiled *t, int octave);
+int cusift_tiled_exchange_virtual(cusift_tiled **ranks, int n, int octave);
+int cusift_tiled_process(cusift_tiled *t, cusift_point *d_points, unsigned int *d_counter);
+int cusift_tiled_extract(cusift_tiled *t, const float *d_strip, int strip_pitch, cusift_point *d_points,
+                         unsigned int *d_counter);
+int cusift_tiled_check(cusift_tiled *t, unsigned int *flagged);
 
 /* ---- drivers ------------------------------------------------------------------------------ */
 /* Batch form of ExtractSiftLoop/ExtractSiftOctave (cuSIFT.cu:175-270) on device-resident images.

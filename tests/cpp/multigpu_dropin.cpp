@@ -104,26 +104,30 @@ int main(int argc, char **argv) {
   }
   CHECK(cusift_memcpy_h2d(ctx, d_counts, counts.data(), sizeof(unsigned int) * n_local));
 
-  // ---- all-gatherv of SiftData (two phases; a pipelined caller enqueues its next batch in between) ----
-  const size_t capacity = (size_t)world * n_local * max_pts;
+  // ---- all-gatherv of SiftData (two phases; a pipelined caller enqueues its next batches in between) ----
+  // d_gathered is `world` regions of region_cap records: region r = rank r's records, packed in image order
+  const size_t region_cap = (size_t)n_local * max_pts;
   cusift_point *d_gathered = nullptr;
-  CHECK(cusift_malloc((void **)&d_gathered, sizeof(cusift_point) * capacity));
+  CHECK(cusift_malloc((void **)&d_gathered, sizeof(cusift_point) * region_cap * world));
   std::vector<unsigned int> all_counts((size_t)world * n_local);
-  std::vector<size_t> offsets(world + 1);
-  CHECK(cusift_allgatherv_begin(comm, d_points, d_counts, n_local, max_pts, n_local));
-  CHECK(cusift_allgatherv_finish(comm, d_gathered, capacity, all_counts.data(), offsets.data()));
+  std::vector<size_t> totals(world);
+  CHECK(cusift_comm_reserve(comm, n_local, 2, region_cap));  // nothing below allocates
+  CHECK(cusift_allgatherv_begin(comm, /*producer=*/ctx, d_points, d_counts, n_local, max_pts, n_local, d_gathered,
+                                region_cap));
+  CHECK(cusift_allgatherv_finish(comm, all_counts.data(), totals.data()));
   CHECK(cusift_ctx_synchronize(ctx));
 
-  // ---- checks: my counts came back in my slot, my shard sits at my offset, bit for bit ----
+  // ---- checks: my counts came back in my slot, my shard sits in my region, bit for bit ----
   int failures = 0;
-  size_t mine = 0;
+  size_t mine = 0, everybody = 0;
   for (int i = 0; i < n_local; ++i) {
     if (all_counts[(size_t)rank * n_local + i] != counts[i]) ++failures;
     mine += counts[i];
   }
-  if (offsets[rank + 1] - offsets[rank] != mine) ++failures;
+  for (int r = 0; r < world; ++r) everybody += totals[r];
+  if (totals[rank] != mine) ++failures;
   std::vector<cusift_point> got(mine), want(mine);
-  if (mine) CHECK(cusift_memcpy_d2h(ctx, got.data(), d_gathered + offsets[rank], sizeof(cusift_point) * mine));
+  if (mine) CHECK(cusift_memcpy_d2h(ctx, got.data(), d_gathered + (size_t)rank * region_cap, sizeof(cusift_point) * mine));
   size_t pos = 0;
   for (int i = 0; i < n_local; ++i) {
     if (counts[i])
@@ -131,9 +135,18 @@ int main(int argc, char **argv) {
     pos += counts[i];
   }
   if (mine && std::memcmp(got.data(), want.data(), sizeof(cusift_point) * mine) != 0) ++failures;
+  // every peer's region starts with a record of that peer's first image: finite coordinates inside the image
+  for (int r = 0; r < world; ++r) {
+    if (!totals[r]) continue;
+    cusift_point first;
+    CHECK(cusift_memcpy_d2h(ctx, &first, d_gathered + (size_t)r * region_cap, sizeof(first)));
+    if (!(first.coords2D[0] >= 0.f && first.coords2D[0] < (float)w && first.coords2D[1] >= 0.f &&
+          first.coords2D[1] < (float)h && first.subsampling >= 1.f))
+      ++failures;
+  }
   std::printf("rank %d of %d on GPU %d (%s): %d images, %zu keypoints here, %zu gathered\n", rank, world, device,
-              cusift_comm_library(), n_local, mine, offsets[world]);
-  if (mine < 100 || offsets[world] < mine * (size_t)world / 2) ++failures;
+              cusift_comm_library(), n_local, mine, everybody);
+  if (mine < 100 || everybody < mine * (size_t)world / 2) ++failures;
 
   cusift_free(d_gathered);
   cusift_free(d_points);

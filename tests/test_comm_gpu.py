@@ -30,40 +30,55 @@ def extracted(gray1):
 def test_allgatherv_world1_equals_pack_points(extracted, self_p2p):
     ex, pts, cnt = extracted
     want, valid = pack_points(pts, cnt, ex.max_pts)
+    total = int(valid.sum())
     side = torch.cuda.Stream()
     ctx = capi.Context(0, stream=side.cuda_stream)
     comm = make_comm(ctx, self_p2p=self_p2p)
     assert comm.world == 1 and comm.rank == 0
     assert "rccl" in capi.Comm.library().lower()
     n_max = 8  # more count slots than images: padding slots must come back as zero
-    g = SiftGatherer(comm, n_max, ex.max_pts, capacity=int(valid.sum()) + 10, n_out=2)
-    for rep in range(3):  # the output ring and the count buffers are reused
-        with torch.cuda.stream(side):
-            side.wait_stream(torch.cuda.current_stream())
-            g.begin(pts, cnt)
-            counts, gathered, offsets = g.finish()
+    g = SiftGatherer(comm, n_max, ex.max_pts, region_cap=total + 10, n_out=2, depth=2)
+    for rep in range(3):  # the output ring and the tickets are reused
+        # `producer`: the exchange is ordered after the extraction's stream by begin() itself -- no wait_stream here
+        g.begin(pts, cnt, producer=ex.ctx)
+        counts, gathered, totals = g.finish()
         side.synchronize()
-        assert counts.shape == (1, n_max)
+        assert counts.shape == (1, n_max) and gathered.shape == (1, total + 10, 588)
         np.testing.assert_array_equal(counts[0, :5], valid.cpu().numpy())
         assert not counts[0, 5:].any()
-        assert offsets[0] == 0 and offsets[1] == int(valid.sum())
-        assert torch.equal(gathered.cpu(), want.cpu()), rep
+        assert int(totals[0]) == total
+        assert torch.equal(gathered[0, :total].cpu(), want.cpu()), rep
+    # two exchanges in flight, finished oldest first
+    g.begin(pts, cnt, producer=ex.ctx)
+    g.begin(pts, cnt, producer=ex.ctx)
+    with pytest.raises(capi.CusiftError, match="in flight"):
+        g.begin(pts, cnt, producer=ex.ctx)
+    for _ in range(2):
+        counts, gathered, totals = g.finish()
+        side.synchronize()
+        assert torch.equal(gathered[0, :total].cpu(), want.cpu())
     # saturated counters are clamped on the device
     cnt2 = cnt.clone()
     cnt2[1] = 10 ** 6
-    g2 = SiftGatherer(comm, 5, ex.max_pts, capacity=5 * ex.max_pts)
-    with torch.cuda.stream(side):
-        side.wait_stream(torch.cuda.current_stream())
-        counts, gathered, offsets = g2.gather(pts, cnt2)
+    torch.cuda.synchronize()
+    g2 = SiftGatherer(comm, 5, ex.max_pts)
+    counts, gathered, totals = g2.gather(pts, cnt2, producer=ex.ctx)
     side.synchronize()
-    assert counts[0, 1] == ex.max_pts and gathered.shape[0] == int(counts.sum())
-    # a buffer that is too small is an error, not an overrun
-    g3 = SiftGatherer(comm, 5, ex.max_pts, capacity=7)
-    with pytest.raises(capi.CusiftError, match="gathered"):
-        g3.gather(pts, cnt)
-    # finish without begin / begin twice
+    assert counts[0, 1] == ex.max_pts and int(totals[0]) == int(counts.sum())
+    # a region that is too small is an error, not an overrun
+    g3 = SiftGatherer(comm, 5, ex.max_pts, region_cap=7)
+    with pytest.raises(capi.CusiftError, match="region"):
+        g3.gather(pts, cnt, producer=ex.ctx)
+    # finish without begin
     with pytest.raises(capi.CusiftError):
-        comm.allgatherv_finish(g.out[0].data_ptr(), g.capacity)
+        comm.allgatherv_finish()
+    # cusift_compact_gathered: regions back to back
+    counts, gathered, totals = g2.gather(pts, cnt, producer=ex.ctx)
+    flat = torch.zeros((total, 588), dtype=torch.uint8, device="cuda")
+    capi.compact_gathered(ctx, gathered.data_ptr(), g2.region_cap, totals, flat.data_ptr(), total)
+    side.synchronize()
+    assert torch.equal(flat.cpu(), want.cpu())
+    assert comm.host_waits() >= 0
     comm.close()
     ctx.close()
 

@@ -12,17 +12,18 @@ BIN_MATCH = os.path.join(CPP, "matching_dropin")
 BIN_HOMO = os.path.join(CPP, "homography_dropin")
 BIN_MULTI = os.path.join(CPP, "multigpu_dropin")
 BIN_PIPE = os.path.join(CPP, "pipeline_dropin")
+BIN_TILED = os.path.join(CPP, "tiled_dropin")
 
 
 def build():
     subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
     assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO) and os.path.exists(BIN_MULTI)
-    assert os.path.exists(BIN_PIPE)
+    assert os.path.exists(BIN_PIPE) and os.path.exists(BIN_TILED)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE):
+    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -112,3 +113,24 @@ def test_dropin_pipeline_program_runs_on_gpu():
         assert m, out.stdout
         counts.append(int(m.group(4)))
     assert counts[0] == counts[1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,octaves,world", [
+    (1024, 2048, 5, 1),    # one rank: the band entry points on the whole image, no communicator
+    (1024, 2048, 7, 4),    # four ranks as four threads over the in-process transport; octaves 4..6 collapse onto rank 0
+    (1000, 1531, 6, 3),    # uneven strips, ragged octave widths
+])
+def test_dropin_tiled_program_equals_whole_image(W, H, octaves, world):
+    """The C++ tiled driver (cusift_tiled_* + cusift_allgatherv, plain g++ over include/cusift_amd.h): every rank's merged
+    SiftData == the whole-image extraction, bit for bit."""
+    from fake_transport import fake_rccl_path
+
+    build()
+    cmd = [BIN_TILED, os.path.join(ROOT, "tests", "golden", "gray1.pgm"), str(W), str(H), str(octaves), str(world)]
+    if world > 1:
+        cmd.append(fake_rccl_path())
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "PASSED" in out.stdout and "identical" in out.stdout
