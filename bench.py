@@ -4,6 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+(the first form with N > 1 starts the second one itself, as a child process, before anything touches a GPU)
 
 Workload (BASELINE.json configs[2]/[3]): a batch of 64 synthetic 1920x1080 8-bit-valued images per GPU
 (seeded `tile` images pre-blurred to sigma 1.0), 5 octaves, initBlur=1.0, thresh=3.0, edge=10.
@@ -25,8 +26,12 @@ leg says otherwise), `--legs` selects them:
              algorithmic bytes / HIP-event time vs 8 TB/s, the north-star gate)
   host       SiftData made host-visible: packed records copied to pinned memory on a copy stream, overlapped with
              the next step (`keypoints_per_s_host_visible`; SURVEY.md section 8d's end-to-end definition)
-  content    the same pipeline on other image content (`blobs`, un-pre-blurred `tile`): keypoints/step and the
-             fraction of octave-0 wave-rows the threshold pre-test skips -- how much of the rate is the images
+  repeat     the timed region four more times: min / median / max ms per step (the spread of `ms_per_step`)
+  content    the same pipeline on other image content (`blobs`, un-pre-blurred `tile`), single stream AND pipelined
+             like the timed region: keypoints/step, the fraction of octave-0 wave-rows the threshold pre-test skips,
+             `value_blobs_mpix_per_s` / `value_tile_raw_mpix_per_s` -- how much of the rate is the images
+  initblur0  the timed images with initBlur = 0.0 declared (the only value the reference's own test uses,
+             test/detector.cpp:43): no identity levels in octave 0; `value_initblur0_mpix_per_s`
   ragged     64 x 1366x768 (no octave width is a multiple of 4): per-pixel rate next to 1080p's
   match      MatchSiftData (section 8 row f1) on 16384 x 16384 descriptors: TFLOP/s vs the fp32 MFMA peak
   cpu        `cpu_baseline`: the CPU oracle on this box's host cores over a bounded sample; OpenCV if importable
@@ -49,7 +54,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 FP32_VALU_PEAK_TF = 157.3  # ibid. "Peak FP32 (vector)": 256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz
-ALL_LEGS = ("single", "two_stage", "host", "content", "ragged", "match", "cpu")
+ALL_LEGS = ("single", "repeat", "two_stage", "host", "content", "initblur0", "ragged", "match", "cpu")
 
 
 def octave_dims(w, h, n_oct):
@@ -160,6 +165,73 @@ def opencv_baseline(imgs, threads, budget_s):
         return {"available": False, "note": "opencv: present but SIFT failed (%s)" % e}
 
 
+def spawn_ranks(n, argv):
+    """One rank per GPU as child processes (torch.distributed.run on 127.0.0.1, a free port); rank 0's JSON line is
+    passed through on stdout, everything else the children print goes to stderr.  Returns the launcher's exit code
+    (non-zero if any rank failed).  Never an exec: this process stays the parent."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        t = out.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+
+def dry_launch(args):
+    """What the ranks do around the timed region, without a GPU: rendezvous (gloo), shard, barrier, max-over-ranks."""
+    import torch
+    import torch.distributed as dist
+
+    from cusift_amd.dist import shard_range
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(world * args.batch, rank, world)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0 + 1e-6 * rank], dtype=torch.float64)
+    n_img = torch.tensor([hi - lo], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n_img, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "Mpix/s pyramid + keypoints/s end-to-end, 1920x1080 batch", "value": None,
+                          "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_launch": True, "images_total": int(n_img.item()), "data": "none (launch rehearsal)"}),
+              flush=True)
+    return 0
+
+
 def load_profile_json(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -193,7 +265,16 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gatherv of SiftData even with one rank (self send/recv: exercises the RCCL path "
                          "on one GPU)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the launch only: ranks rendezvous over gloo on the CPU, shard the batch, barrier, "
+                         "reduce a time and rank 0 prints a line -- no GPU, no extraction (tests the --gpus N spawn)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a plain command: this process has not touched a GPU (no torch import, no HIP
+        # call so far) and never will -- it starts the N ranks as CHILDREN and relays rank 0's line
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_launch:
+        raise SystemExit(dry_launch(args))
     legs = set() if args.legs in ("none", "") else set(x for x in args.legs.split(",") if x)
     unknown = legs - set(ALL_LEGS)
     if unknown:
@@ -241,7 +322,7 @@ def main():
     # One extractor (context + arena + output slots) per stream; step i runs on stream i % E.  A step is still one
     # whole pass of the hot path over one batch -- consecutive steps merely overlap on the device.
     E = max(1, args.streams)
-    n_slots = 2 if use_dist else 1  # a slot is read by the gather of its step while the next steps are extracted
+    n_slots = 2 if use_dist else 1  # a slot is read by the pack of its step's gather while the next steps are extracted
     pipe = PipelinedExtractor(B, w, h, n_streams=E, n_slots=n_slots,
                               fused_detect=0 if args.two_stage else 1, **prm_kw)
     exs = pipe.extractors
@@ -257,68 +338,78 @@ def main():
     seeds = [1000 + rank * B + i for i in range(B)]
     d_imgs = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, args.init_blur), seeds))
 
-    # N > 1: the all-gatherv of step i runs on a side stream (its own context + communicator) while step i+1 is
-    # extracted; its one host read (the counts) happens one step later, when they have long arrived
+    # N > 1: the all-gatherv of step i runs on a side stream (its own context + communicator).  begin(i) -- counts
+    # exchange + the local shard packed into its region -- is enqueued right after step i; finish(i) -- the one host READ
+    # of the counts, then the grouped ncclSend/ncclRecv -- after step i + LAG has been enqueued, by which time the counts
+    # have long arrived: no host wait anywhere in the loop (config.gather_host_waits counts the exceptions).
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream() if use_dist else None
+    LAG = E
     gatherer = None
     gather_impl = None
     comm = side_ctx = None
+    region_cap = B * args.gather_capacity
     if use_dist:
-        # The exchange is the C ABI's (RCCL called from libcusift_amd.so).  It has never met more than one rank on the
-        # build box (RCCL refuses two ranks per GPU), so a failure to bring the communicator up is not allowed to cost
-        # the run: all ranks then agree to fall back to the torch.distributed twin of the same exchange, and the JSON
-        # line says which one ran (config.gather_impl).
+        # The exchange is the C ABI's (RCCL called from libcusift_amd.so).  On the build box it has met more than one
+        # rank only over the in-process test transport (tests/test_multirank_gpu.py; RCCL refuses two ranks per GPU),
+        # so a failure to bring the communicator up is not allowed to cost the run: all ranks then agree to fall back to
+        # the torch.distributed twin of the same exchange, and the JSON line says which one ran (config.gather_impl).
         err = ""
         try:
             side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
             comm = make_comm(side_ctx, self_p2p=(world == 1))
-            gatherer = SiftGatherer(comm, B, args.max_pts, capacity=world * B * args.gather_capacity, device=dev, n_out=2)
+            gatherer = SiftGatherer(comm, B, args.max_pts, region_cap=region_cap, device=dev, n_out=LAG + 2,
+                                    depth=LAG + 1)
         except Exception as e:  # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
-            gather_impl = "C ABI (cusift_allgatherv_*): ncclAllGather of counts + one ncclGroup of ncclSend/ncclRecv"
+            gather_impl = ("C ABI (cusift_allgatherv_*): ncclAllGather of counts + one ncclGroup of ncclSend/ncclRecv, "
+                           "finish lags begin by %d steps" % LAG)
         else:
             print("bench.py: C-ABI communicator unavailable (%s); using the torch.distributed exchange" % err,
                   file=sys.stderr)
             gatherer = None
+            LAG = 1
             gather_impl = "torch.distributed fallback (C ABI communicator failed: %s)" % (err or "on another rank")
     pending = []
     state = {"gathered": None}
-    slot_free = {}  # (stream index, slot) -> event after which the slot's last gather no longer reads it
+    slot_free = {}  # (stream index, slot) -> event after which the slot's records have been packed (it may be rewritten)
     packer = ex.make_packer(side_stream) if (use_dist and gatherer is None) else None
 
     def finish_one():
         key, ticket = pending.pop(0)
         with torch.cuda.stream(side_stream):
             if gatherer is not None:
-                state["gathered"] = gatherer.finish()
+                counts_h, buf, totals = gatherer.finish()
+                state["gathered"] = (counts_h, buf, totals)
             else:
                 ac, ga, off = finish_allgather(ticket, method="p2p", packer=packer)
-                state["gathered"] = (ac, ga, off.numpy())
-            done = torch.cuda.Event()
-            done.record(side_stream)
-        slot_free[key] = done
+                state["gathered"] = (ac, ga, np.diff(off.numpy()))
+                done = torch.cuda.Event()
+                done.record(side_stream)
+                slot_free[key] = done
 
     def step():
-        key = (pipe.submitted % E, (pipe.submitted // E) % pipe.n_slots)
+        e = pipe.submitted % E
+        key = (e, (pipe.submitted // E) % pipe.n_slots)
         pts, cnt, ev = pipe.submit(d_imgs, ready=slot_free.pop(key, None))
         if use_dist:
-            # the previous step's exchange is completed first (its counts arrived while this step was being enqueued),
-            # then this step's counts exchange is started
-            if pending:
-                finish_one()
             ticket = None
             with torch.cuda.stream(side_stream):
-                side_stream.wait_event(ev)
                 if gatherer is not None:
-                    gatherer.begin(pts, cnt)
+                    gatherer.begin(pts, cnt, producer=exs[e].ctx)  # ordered after the extraction by begin() itself
+                    packed = torch.cuda.Event()
+                    packed.record(side_stream)
+                    slot_free[key] = packed  # the slot is free again once its records sit in the gathered buffer
                 else:
+                    side_stream.wait_event(ev)
                     ticket = begin_allgather(pts, cnt, ex.max_pts, n_images_max=B)
             pending.append((key, ticket))
+            if len(pending) > LAG:
+                finish_one()
 
     def drain():
         while pending:
@@ -369,7 +460,7 @@ def main():
         dist.all_reduce(kp, op=dist.ReduceOp.SUM)
     total_kp = int(kp.item())
     if use_dist:
-        total_gathered = int(gathered[2][-1])
+        total_gathered = int(np.asarray(gathered[2], dtype=np.int64).sum())
         assert total_gathered == total_kp, (total_gathered, total_kp)
 
     K = args.steps
@@ -395,7 +486,8 @@ def main():
                             "%d octaves, initBlur=%.1f, thresh=%.1f, edge=10, maxPts=%d; full SIFT extraction "
                             "(pyramid+DoG, extrema, orientation, 128-D descriptor), SiftData left in HBM%s"
                             % (B, w, h, world, args.octaves, args.init_blur, args.thresh, args.max_pts,
-                               "; + all-gatherv of SiftData (C ABI over RCCL: counts all-gather + grouped send/recv)"
+                               "; + all-gatherv of SiftData every step (C ABI over RCCL: counts all-gather + grouped "
+                               "send/recv)"
                                if use_dist else ""),
                 "images_per_gpu": B,
                 "parallelism": "image-sharded x%d" % world,
@@ -408,6 +500,9 @@ def main():
         if use_dist:
             out["config"]["gather_impl"] = gather_impl
             out["config"]["rccl_library"] = capi.Comm.library()
+            out["config"]["gather_region_records"] = region_cap
+            if comm is not None:
+                out["config"]["gather_host_waits"] = comm.host_waits()
 
     # ================================================================================================================
     # Extra legs (rank 0's GPU only; not part of `value`).  With N > 1 the other ranks wait at the final barrier.
@@ -415,6 +510,7 @@ def main():
     blur_b, down_b, find_b = algorithmic_bytes(w, h, args.octaves, B)
     traffic = load_profile_json("traffic.json")
     valu = load_profile_json("valu.json")
+    isa_mix = load_profile_json("isa_mix.json")
 
     def stage_table(st, steps):
         return {k: round(st[k][0] / steps, 4) for k in ("scale_down", "detect_multi", "describe_all", "laplace_multi",
@@ -437,9 +533,38 @@ def main():
         extractor.ctx.timing_enable(False)
         return ms, st
 
+    def run_pipelined(imgs, steps, warm=None, **param_overrides):
+        """`steps` extractions rotated over the E streams exactly as in the timed region (no gather); returns ms/step.
+        param_overrides are set on every extractor for the duration."""
+        warm = E if warm is None else warm
+        saved = [{k: getattr(x.params, k) for k in param_overrides} for x in exs]
+        for x in exs:
+            x.params.concurrent_batches = E
+            for k, v in param_overrides.items():
+                setattr(x.params, k, v)
+        try:
+            for _ in range(warm):
+                pipe.submit(imgs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                pipe.submit(imgs)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / steps * 1e3
+        finally:
+            for x, sv in zip(exs, saved):
+                for k, v in sv.items():
+                    setattr(x.params, k, v)
+
     if rank == 0 and legs:
         torch.cuda.synchronize()
-        ex.params.concurrent_batches = 1  # the legs below run one batch at a time on one stream
+        if "repeat" in legs and not use_dist:
+            reps = sorted(run_pipelined(d_imgs, K, warm=0) for _ in range(4))
+            allr = sorted(reps + [elapsed / K * 1e3])
+            out["ms_per_step_spread"] = {"min": round(allr[0], 4), "median": round(allr[len(allr) // 2], 4),
+                                         "max": round(allr[-1], 4), "regions": len(allr),
+                                         "note": "the timed region (`ms_per_step`) and 4 repeats of it, K steps each"}
+        ex.params.concurrent_batches = 1  # the single-stream legs below run one batch at a time on one stream
         if stage_overlapped is not None and E > 1:
             out["timed_region_kernel_spans_ms_per_step"] = stage_table(stage_overlapped, K)
 
@@ -468,19 +593,31 @@ def main():
                 # 157.3 TFLOP/s peak (32 lanes x 2 flop per SIMD-clock), so frac = vector issue slots used
                 insts_per_step = info["valu_wave_insts_per_launch"] * (n / K)
                 ach = insts_per_step * 64 * 2 / (ms / K * 1e-3) / 1e12
-                return {"kernel": kernel, "bound": "valu", "achieved": round(ach, 2), "peak": FP32_VALU_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": round(ach / FP32_VALU_PEAK_TF, 4),
-                        "valu_wave_insts_per_step": int(insts_per_step), "launches_per_step": n // K,
-                        "ms_per_step": round(ms / K, 4),
-                        "valu_busy_pmc": info.get("valu_busy"),
-                        "hbm_traffic_bytes_per_launch": traffic.get(kernel, {}).get("hbm_bytes_per_launch"),
-                        "note": note}
+                r = {"kernel": kernel, "bound": "valu", "achieved": round(ach, 2), "peak": FP32_VALU_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": round(ach / FP32_VALU_PEAK_TF, 4),
+                     "valu_wave_insts_per_step": int(insts_per_step), "launches_per_step": n // K,
+                     "ms_per_step": round(ms / K, 4),
+                     "hbm_traffic_bytes_per_launch": traffic.get(kernel, {}).get("hbm_bytes_per_launch"),
+                     "note": note}
+                # The spec peak prices every wave-instruction at 4 cycles per SIMD; this kernel's instructions cost more
+                # (packed fp32 ~6.9, two-VGPR-source and DPP ~4.7: tools/microbench/valu_rate.hip).  Issue bound = PMC
+                # instruction count x the mix-weighted cycles per instruction (static mix of the hot loop blocks from the
+                # ISA, tools/isa_mix.py) / (1024 SIMDs x 2.4 GHz): the time the SIMDs need just to ISSUE the kernel.
+                mix = isa_mix.get(kernel)
+                if mix:
+                    cpi = mix["cycles_per_instruction_mix_weighted"]
+                    bound_ms = insts_per_step * cpi / (1024 * 2.4e9) * 1e3
+                    r["issue_bound"] = {"cycles_per_wave_instruction": cpi, "mix": mix["mix"],
+                                        "waves_per_simd": mix["waves_per_simd"], "bound_ms_per_step": round(bound_ms, 4),
+                                        "frac_of_issue_bound": round(bound_ms / (ms / K), 4),
+                                        "note": "bound_ms / measured ms: 1.0 = the vector pipes issue back to back; "
+                                                "the mix is a static estimate (profiles/isa_mix.json)"}
+                return r
 
             rk = []
             r = valu_roofline("detect_fused_kernel", "detect_multi",
                               "achieved = PMC SQ_INSTS_VALU (profiles/valu.json, same command) x 64 lanes x 2 flop / "
-                              "HIP-event time of this run; valu_busy_pmc = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x "
-                              "GRBM_GUI_ACTIVE / 8)")
+                              "HIP-event time of this run")
             if r:
                 rk.append(r)
             r = valu_roofline("describe_all_kernel", "describe_all", "as above; %d keypoints per step"
@@ -564,19 +701,53 @@ def main():
         if "content" in legs:
             cl = {}
             cl["tile_preblurred (the timed workload)"] = content_stats(torch, capi, ex, d_imgs, None, w, h, B, args, K)
+            def pipelined_rate(d, imgs):
+                ex.params.concurrent_batches = E
+                ms = run_pipelined(imgs, max(8, K // 2))
+                ex.params.concurrent_batches = 1
+                d["ms_per_step_pipelined"] = round(ms, 4)
+                d["Mpix_per_s_pipelined"] = round(B * w * h / (ms * 1e-3) / 1e6, 1)
+                d["keypoints_per_s_pipelined"] = round(d["keypoints_per_step"] / (ms * 1e-3), 1)
+                return d["Mpix_per_s_pipelined"]
+
             raw = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, 0.0), seeds))
-            cl["tile_raw (no pre-blur; initBlur=%.1f still declared)" % args.init_blur] = content_stats(
-                torch, capi, ex, raw, run_single_stream, w, h, B, args, max(4, K // 2))
+            name = "tile_raw (SURVEY 8d primary generator as written: no pre-blur; initBlur=%.1f still declared)" % args.init_blur
+            cl[name] = content_stats(torch, capi, ex, raw, run_single_stream, w, h, B, args, max(4, K // 2))
+            out["value_tile_raw_mpix_per_s"] = pipelined_rate(cl[name], raw)
             del raw
             blob = ex.images_from_numpy(make_images(lambda s: synth.blobs(s, w, h), seeds))
-            cl["blobs (SURVEY 8d secondary generator)"] = content_stats(torch, capi, ex, blob, run_single_stream, w, h,
-                                                                        B, args, max(4, K // 2))
+            name = "blobs (SURVEY 8d secondary generator)"
+            cl[name] = content_stats(torch, capi, ex, blob, run_single_stream, w, h, B, args, max(4, K // 2))
+            out["value_blobs_mpix_per_s"] = pipelined_rate(cl[name], blob)
             del blob
             if stage is not None:
                 cl["tile_preblurred (the timed workload)"].update(
                     {"ms_per_step_single_stream": out["single_stream_leg"]["ms_per_step"],
                      "keypoints_per_step": local_kp})
             out["content_legs"] = cl
+
+        # ---- initBlur = 0 leg: the timed images with no blur declared (test/detector.cpp:43) ----
+        if "initblur0" in legs:
+            saved_blur = ex.params.init_blur
+            ex.params.init_blur = 0.0
+            i_ms, i_st = run_single_stream(ex, d_imgs, max(4, K // 2))
+            i_kp = int(ex.valid_counts().sum().item())
+            raw_cnt = torch.clamp(ex.counts, min=0)
+            ex.params.init_blur = saved_blur
+            ex.params.concurrent_batches = E
+            p_ms = run_pipelined(d_imgs, max(8, K // 2), init_blur=0.0)
+            ex.params.concurrent_batches = 1
+            n_steps = max(4, K // 2)
+            out["initblur0_leg"] = {
+                "workload": "the timed images, initBlur = 0.0 declared: all 8 levels of octave 0 are filtered (no "
+                            "identity pass-through), the detector sees more and finer structure",
+                "ms_per_step_single_stream": round(i_ms, 4), "ms_per_step_pipelined": round(p_ms, 4),
+                "Mpix_per_s_pipelined": round(B * w * h / (p_ms * 1e-3) / 1e6, 1), "keypoints_per_step": i_kp,
+                "keypoints_per_s_pipelined": round(i_kp / (p_ms * 1e-3), 1),
+                "images_saturating_max_pts": int((raw_cnt >= ex.max_pts).sum().item()),
+                "stage_ms_per_step": {k: round(i_st[k][0] / n_steps, 4) for k in ("scale_down", "detect_multi",
+                                                                                  "describe_all")}}
+            out["value_initblur0_mpix_per_s"] = out["initblur0_leg"]["Mpix_per_s_pipelined"]
 
         # ---- ragged-width leg ----
         if "ragged" in legs:

@@ -96,3 +96,138 @@ def test_strips_8192_equal_whole_image(ctx, n_oct):
         np.testing.assert_array_equal(got[f], want[f], err_msg=f)
     for e in exts:
         e.close()
+
+
+def _extract_batch(ctx, stack, prm, canary_records=64):
+    """cusift_extract_batch over `stack` (n, h, w); returns (raw counters, records [n, max_pts], canary intact?)."""
+    n, h, w = stack.shape
+    p = capi.ialign_up(w, 128)
+    d_imgs = DeviceBuffer.from_numpy(ctx, pitched(stack, p) if p != w else stack)
+    # the output block is followed by `canary_records` records of 0xA5: nothing may be written past slot max_pts - 1
+    # of the last image (and, by the same indexing, of any image: image i + 1's records would be clobbered)
+    d_pts = DeviceBuffer(ctx, (n * prm.max_pts + canary_records) * 588)
+    ctx.memset(d_pts.ptr, 0xA5, d_pts.nbytes)
+    d_cnt = DeviceBuffer(ctx, 4 * n)
+    ctx.extract_batch(d_imgs.ptr, n, w, h, p, h * p, prm, d_pts.ptr, d_cnt.ptr)
+    ctx.synchronize()
+    cnt = d_cnt.to_numpy(np.uint32, (n,))
+    raw = d_pts.to_numpy(np.uint8, (n * prm.max_pts + canary_records, 588))
+    canary_ok = bool((raw[n * prm.max_pts:] == 0xA5).all())
+    rec = raw[: n * prm.max_pts].copy().view(SIFT_POINT_DTYPE).reshape(n, prm.max_pts)
+    for b in (d_imgs, d_pts, d_cnt):
+        b.free()
+    return cnt, rec, canary_ok
+
+
+def test_blobs_batch8_1080p_matches_oracle(ctx, oracle):
+    """The `blobs` content bench.py times (SURVEY.md section 8d's secondary generator, 9-10 k keypoints per image, 3.5 x
+    the headline content): a batch of 8 x 1080p through cusift_extract_batch against the oracle, every keypoint."""
+    n, w, h = 8, 1920, 1080
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        host = list(pool.map(lambda s: synth.blobs(s, w, h), [1000 + i for i in range(n)]))
+        prm = capi.default_params(**BENCH_KW)
+        kw = dict(BENCH_KW)
+        want = list(pool.map(lambda im: oracle.extract(im, **kw), host))
+    cnt, rec, canary_ok = _extract_batch(ctx, np.stack(host), prm)
+    assert canary_ok
+    assert cnt.min() > 3000 and cnt.max() < prm.max_pts
+    for i in range(n):
+        got = rec[i, : cnt[i]]
+        assert np.all(np.diff(got["subsampling"]) <= 0)
+        compare_sets(want[i], got)
+
+
+def test_bench_images_with_initblur0_match_oracle(ctx, oracle):
+    """bench.py's `initblur0` leg: the headline images with initBlur = 0.0 declared (the only value the reference's own
+    test uses, test/detector.cpp:43) -- no identity levels in octave 0.  Two images of the batch, every keypoint."""
+    w, h = 1920, 1080
+    kw = dict(BENCH_KW, init_blur=0.0)
+    prm = capi.default_params(**kw)
+    host = [synth.tile(1000 + i, w, h, 1.0) for i in (0, 37)]
+    cnt, rec, canary_ok = _extract_batch(ctx, np.stack(host), prm)
+    assert canary_ok and cnt.max() < prm.max_pts
+    for i, im in enumerate(host):
+        compare_sets(oracle.extract(im, **kw), rec[i, : cnt[i]])
+
+
+def test_counter_overflow_batch_is_a_subset_of_the_oracle(ctx, oracle):
+    """bench.py's raw-tile leg: un-pre-blurred tiles with initBlur = 1.0 declared saturate maxPts = 32768 on every image.
+    The reference truncates (numPts = min(counter, maxPts), cuSIFT.cu:110) after letting every overflowing append land
+    in slot maxPts - 1 (cuSIFT_D.cu:512-514); this build drops them.  Demanded: the counter keeps counting, exactly
+    maxPts records are valid, the coarse-octave blocks are complete and equal the oracle's keypoint by keypoint, the
+    octave-0 rows that fitted are a SUBSET of the oracle's octave-0 keypoints (each with the oracle's values), and
+    nothing is written past slot maxPts - 1."""
+    n, w, h = 2, 1920, 1080
+    host = [synth.tile(1000 + i, w, h, 0.0) for i in range(n)]
+    prm = capi.default_params(**BENCH_KW)
+    cnt, rec, canary_ok = _extract_batch(ctx, np.stack(host), prm)
+    assert canary_ok, "records were written past the end of the output block"
+    big = dict(BENCH_KW, max_pts=400000)  # the oracle with room for everything
+    for i in range(n):
+        want = oracle.extract(host[i], **big)
+        assert len(want) > prm.max_pts, "the content no longer overflows: pick another"
+        assert int(cnt[i]) == len(want), (int(cnt[i]), len(want))  # the counter counts every accepted keypoint
+        got = rec[i]  # all max_pts slots are valid records
+        assert np.all(np.diff(got["subsampling"]) <= 0)  # coarsest octave first, octave 0 last
+        coarse_w, coarse_g = want[want["subsampling"] > 1.0], got[got["subsampling"] > 1.0]
+        compare_sets(coarse_w, coarse_g)  # octaves 4..1: complete
+        fine_g = got[got["subsampling"] == 1.0]
+        assert len(coarse_g) + len(fine_g) == prm.max_pts and len(fine_g) > 1000
+        # octave-0 rows: distinct, and each is one of the oracle's octave-0 keypoints with the oracle's values
+        fine_w = want[want["subsampling"] == 1.0]
+        key = lambda p: np.ascontiguousarray(np.stack([p["coords2D"][:, 0], p["coords2D"][:, 1], p["scale"]], 1)).view(  # noqa: E731
+            np.dtype((np.void, 12))).ravel()
+        kw_, kg_ = key(fine_w), key(fine_g)
+        assert len(np.unique(kg_)) == len(kg_)
+        order = np.argsort(kw_)
+        pos = np.searchsorted(kw_[order], kg_)
+        assert (pos < len(kw_)).all() and (kw_[order][np.minimum(pos, len(kw_) - 1)] == kg_).all()
+        compare_sets(fine_w[order][pos], fine_g)
+
+
+def test_strips_8192_distributed_over_the_transport(ctx):
+    """configs[4] at full size with the halos and the collapse gather moved by cusift_exchange_halos / cusift_exchange_rows
+    between 8 RANKS (threads, one context + communicator each, tests/fake_rccl) instead of virtual ranks' device copies:
+    cusift_tiled_extract on every rank, then the all-gatherv merge; every rank's merged SiftData == the whole image."""
+    from cusift_amd.dist import SiftGatherer
+    from cusift_amd.tiling import run_distributed
+    from test_multirank_gpu import _same_extracted, run_ranks
+
+    W = H = 8192
+    P, n_oct = 8, 7
+    img = synth.tile(4242, W, H, preblur=1.0)
+    prm = capi.default_params(num_octaves=n_oct, init_blur=1.0, peak_thresh=3.0, max_pts=1 << 18)
+    d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
+    h_pts = np.zeros(prm.max_pts, dtype=SIFT_POINT_DTYPE)
+    n = ctx.extract_host(img, prm, d_pts.ptr, h_pts)
+    want = canonical_order(h_pts[:n])
+    d_pts.free()
+    dev = torch.device("cuda", 0)
+    full = torch.from_numpy(img).to(dev)
+    torch.cuda.synchronize()
+    rows = H // P
+    sprm = capi.default_params(num_octaves=n_oct, init_blur=1.0, peak_thresh=3.0, max_pts=1 << 16)
+
+    def rank_fn(rank, make_comm):
+        with torch.cuda.device(dev):
+            c = capi.Context(0)
+            comm = make_comm(c)
+            ext = StripExtractor(rank, P, W, H, sprm, device=dev, comm=comm)
+            pts, cnt = run_distributed(ext, full[rank * rows:(rank + 1) * rows])
+            ext.check()
+            g = SiftGatherer(comm, 1, sprm.max_pts, region_cap=sprm.max_pts, device=dev)
+            counts, gathered, totals = g.gather(pts, cnt)
+            c.synchronize()
+            merged = None
+            if rank in (0, 5):  # two ranks bring their merged copy to the host (8 x 150 MB otherwise)
+                merged = np.concatenate([x.cpu().numpy() for x in SiftGatherer.regions(gathered, totals)])
+                merged = merged.view(SIFT_POINT_DTYPE).reshape(-1)
+            ext.close()
+            comm.close()
+            c.close()
+            return merged, [int(t) for t in totals]
+
+    res = run_ranks(P, rank_fn, timeout=600)
+    assert all(r[1] == res[0][1] for r in res) and sum(res[0][1]) == n
+    for k in (0, 5):
+        assert _same_extracted(canonical_order(res[k][0]), want)

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Static VALU instruction mix of the two kernels that own the benchmark step, from the gfx950 assembly hipcc emits for
+the product's flags -- the weights of the mix-weighted ISSUE BOUND bench.py prints in `roofline_kernels` next to the
+157.3 TFLOP/s vector peak.
+
+    python tools/isa_mix.py            # writes profiles/isa_mix.json (runs here: hipcc cross-compiles without a GPU)
+
+Why: the spec peak prices every VALU instruction at one issue slot per 4 cycles per SIMD... which no instruction of
+these kernels reaches.  tools/microbench/valu_rate.hip (profiles/r02_valu_rate_microbench.txt) measures, per SIMD at
+the kernels' occupancy: an instruction with at most one VGPR source ~3.0 cycles, with two or more VGPR sources (max3,
+most real arithmetic) or a DPP modifier ~4.6, a packed fp32 instruction (v_pk_*_f32) ~6.9, and transcendental /
+division helpers run at quarter rate (~4x a plain one).  The bound for a kernel that retires N wave-instructions of
+a given mix on S SIMDs at clock f is  N * sum_c(frac_c * cycles_c) / (S * f).
+
+Classes are counted over the basic blocks that sit INSIDE A LOOP (between a label and a later backward branch to it):
+the prologue, the window fill and other once-per-wave code do not weigh in.  For the fused detection that is still not
+the hot path: its loop holds 60 inlined copies of the 122-instruction candidate refinement (one per scale and column,
+cold: ~1 % of the dynamic instructions) beside the three 592-instruction blocks of the x3-unrolled row loop (blur + DoG
++ threshold pre-test, which branch back to themselves when the pre-test finds nothing) -- there only the blocks that
+contain packed instructions are counted, i.e. exactly those three.  The count is static -- every counted block weighs
+one -- so it is an estimate of the dynamic mix, not a trace; the PMC total it is applied to is exact.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cusift_amd import build as B  # noqa: E402
+
+KERNELS = {  # name -> (source, mangled-name needle, block selector)
+    "detect_fused_kernel": ("sift_stencils.hip", "detect_fused_kernelILb1E", "packed"),  # <kIdent0>: the benchmark's octave 0
+    "detect_fused_kernel<false>": ("sift_stencils.hip", "detect_fused_kernelILb0E", "packed"),
+    "describe_all_kernel": ("sift_keypoints.hip", "describe_all_kernel", "loop"),
+    "laplace_multi_fast_kernel": ("sift_stencils.hip", "laplace_multi_fast_kernelILi2E", "loop"),
+}
+# cycles per wave-instruction per SIMD (profiles/r02_valu_rate_microbench.txt), by waves resident per SIMD
+CYCLES = {
+    2: {"one_vgpr_src": 2.96, "multi_vgpr_src": 4.72, "dpp": 4.63, "packed": 6.85, "quarter_rate": 4 * 2.96},
+    4: {"one_vgpr_src": 2.70, "multi_vgpr_src": 4.33, "dpp": 4.35, "packed": 6.34, "quarter_rate": 4 * 2.70},
+}
+WAVES = {"detect_fused_kernel": 2, "detect_fused_kernel<false>": 2, "describe_all_kernel": 4,
+         "laplace_multi_fast_kernel": 4}
+QUARTER = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_", "v_div_fmas", "v_div_scale",
+           "v_div_fixup", "v_rcp_iflag")
+
+
+def assembly(src):
+    flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    cmd = [B.find_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", "-", os.path.join(B.CSRC, src)]
+    return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+
+
+def kernel_body(asm, needle):
+    lines = asm.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and needle in l and l.rstrip().split(":")[0].startswith("_Z"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+    return lines[start + 1:end]
+
+
+def classify(line):
+    t = line.strip()
+    if not t.startswith("v_"):
+        return None
+    op = t.split()[0]
+    if op.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_nop")):
+        return None
+    if op.startswith("v_pk_"):
+        return "packed"
+    if any(op.startswith(q) for q in QUARTER):
+        return "quarter_rate"
+    if re.search(r"\b(row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|wave_rol|quad_perm|row_bcast|row_mirror|"
+                 r"row_half_mirror|row_share|row_xmask|dpp8)\b", t) or "_dpp" in op:
+        return "dpp"
+    ops = t[len(op):].split(";")[0]
+    parts = [p.strip() for p in ops.split(",")]
+    srcs = parts if op.startswith("v_cmp") else parts[1:]
+    n = sum(1 for p in srcs if re.match(r"^-?\|?v(\d+|\[\d+:\d+\])", p))
+    return "multi_vgpr_src" if n >= 2 else "one_vgpr_src"
+
+
+def loop_mix(body, selector):
+    """Class counts over the basic blocks inside any loop (label .. backward branch to that label); selector "packed":
+    only those of them that contain packed instructions."""
+    label_at = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB[0-9_]+):", l)
+        if m:
+            label_at[m.group(1)] = i
+    in_loop = [False] * len(body)
+    for i, l in enumerate(body):
+        m = re.search(r"\bs_c?branch\w*\s+(?:\S+,\s*)?(\.LBB[0-9_]+)", l)
+        if m and m.group(1) in label_at and label_at[m.group(1)] <= i:
+            for j in range(label_at[m.group(1)], i + 1):
+                in_loop[j] = True
+    starts = sorted(set([0] + list(label_at.values()))) + [len(body)]
+    counts, total_all, n_blocks = {}, 0, 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        blk = {}
+        for i in range(a, b):
+            c = classify(body[i])
+            if c is not None:
+                total_all += 1
+                if in_loop[i]:
+                    blk[c] = blk.get(c, 0) + 1
+        if not blk or (selector == "packed" and not blk.get("packed")):
+            continue
+        n_blocks += 1
+        for k, v in blk.items():
+            counts[k] = counts.get(k, 0) + v
+    return counts, total_all, n_blocks
+
+
+def main():
+    out = {"_source": "python tools/isa_mix.py: static VALU class counts over the loop blocks of each kernel (hipcc -S with "
+                      "the product's flags), cycles per class from profiles/r02_valu_rate_microbench.txt",
+           "_cycles_per_wave_instruction_per_simd": CYCLES}
+    cache = {}
+    for name, (src, needle, selector) in KERNELS.items():
+        if src not in cache:
+            cache[src] = assembly(src)
+        counts, total_all, n_blocks = loop_mix(kernel_body(cache[src], needle), selector)
+        n = sum(counts.values())
+        cyc = CYCLES[WAVES[name]]
+        frac = {k: round(v / n, 4) for k, v in sorted(counts.items())}
+        avg = sum(counts[k] / n * cyc[k] for k in counts)
+        out[name] = {"counted_valu_instructions_static": n, "counted_blocks": n_blocks,
+                     "blocks": "loop blocks holding packed instructions" if selector == "packed" else "all loop blocks",
+                     "kernel_valu_instructions_static": total_all,
+                     "waves_per_simd": WAVES[name], "mix": frac, "cycles_per_instruction_mix_weighted": round(avg, 3)}
+        print("%-28s loop VALU %5d of %5d  %s  -> %.2f cycles/inst" % (name, n, total_all, frac, avg))
+    dst = os.path.join(ROOT, "profiles", "isa_mix.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main()
