@@ -103,8 +103,45 @@ struct TimedSpan {
   int stage;
 };
 
+// Tuning overrides for experiments (tools/ab_*.sh, tools/probe_rows.py), read from the environment ONCE, when a
+// context is created -- nothing on a launch path looks at the environment.  0 / negative = "not set".
+enum { kKnobScaleDown = 0, kKnobLaplace, kKnobFindPoints, kKnobDetect, kKnobStages };
+struct Knobs {
+  int rows_per_wave = 0;                             // CUSIFT_ROWS_PER_WAVE: every stencil stage
+  int rows_lo[kKnobStages] = {0}, rows_hi[kKnobStages] = {0};  // CUSIFT_<STAGE>_ROWS_LO / _HI
+  double detect_rows_coef = 0.0;                     // CUSIFT_DETECT_ROWS_COEF
+  int detect_waves = 0, laplace_waves = 0;           // CUSIFT_DETECT_WAVES, CUSIFT_LAPLACE_WAVES (waves per workgroup)
+  int laplace_aux = -1;                              // CUSIFT_LAPLACE_AUX: cache policy of the DoG stores
+  bool no_ident = false, force_generic = false;      // CUSIFT_NO_IDENT, CUSIFT_FORCE_GENERIC
+  int match_splits = 0;                              // CUSIFT_MATCH_SPLITS
+};
+
+static Knobs read_knobs() {
+  auto text = [](const char *name) -> const char * { return getenv(name); };
+  auto num = [&](const char *name, int unset) { const char *e = text(name); return e ? atoi(e) : unset; };
+  Knobs k;
+  k.rows_per_wave = num("CUSIFT_ROWS_PER_WAVE", 0);
+  static const char *const stage[kKnobStages] = {"SCALEDOWN", "LAPLACE", "FINDPOINTS", "DETECT"};
+  for (int i = 0; i < kKnobStages; ++i) {
+    char name[64];
+    snprintf(name, sizeof(name), "CUSIFT_%s_ROWS_LO", stage[i]);
+    k.rows_lo[i] = num(name, 0);
+    snprintf(name, sizeof(name), "CUSIFT_%s_ROWS_HI", stage[i]);
+    k.rows_hi[i] = num(name, 0);
+  }
+  if (const char *e = text("CUSIFT_DETECT_ROWS_COEF")) k.detect_rows_coef = atof(e);
+  k.detect_waves = num("CUSIFT_DETECT_WAVES", 0);
+  k.laplace_waves = num("CUSIFT_LAPLACE_WAVES", 0);
+  k.laplace_aux = num("CUSIFT_LAPLACE_AUX", -1);
+  k.no_ident = text("CUSIFT_NO_IDENT") != nullptr;
+  k.force_generic = text("CUSIFT_FORCE_GENERIC") != nullptr;
+  k.match_splits = num("CUSIFT_MATCH_SPLITS", 0);
+  return k;
+}
+
 struct cusift_ctx {
   int device = 0;
+  Knobs knobs;
   int num_cus = 256;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
@@ -255,11 +292,8 @@ int ensure_arena(cusift_ctx *ctx, size_t bytes) {
 
 // rows each wave marches: as large as possible (less halo re-read) while the launch still has
 // >= ~2 waves per SIMD on 256 CUs.
-int pick_rows(int h, int strips, int n_images, int lo, int hi) {
-  if (const char *e = getenv("CUSIFT_ROWS_PER_WAVE")) {  // tuning/experiments only
-    const int r = atoi(e);
-    if (r > 0) return r;
-  }
+int pick_rows(const cusift_ctx *ctx, int h, int strips, int n_images, int lo, int hi) {
+  if (ctx->knobs.rows_per_wave > 0) return ctx->knobs.rows_per_wave;  // tuning/experiments only
   const long target_waves = 256L * 4 * 2 * 2;
   long r = (long)h * strips * n_images / target_waves;
   if (r < lo) r = lo;
@@ -267,13 +301,10 @@ int pick_rows(int h, int strips, int n_images, int lo, int hi) {
   return (int)r;
 }
 
-// [lo, hi] of pick_rows for a stage, overridable for tuning experiments: CUSIFT_<STAGE>_ROWS_LO / _HI
-void rows_bounds(const char *stage, int &lo, int &hi) {
-  char name[64];
-  snprintf(name, sizeof(name), "CUSIFT_%s_ROWS_HI", stage);
-  if (const char *e = getenv(name)) hi = std::max(1, atoi(e));
-  snprintf(name, sizeof(name), "CUSIFT_%s_ROWS_LO", stage);
-  if (const char *e = getenv(name)) lo = std::max(1, atoi(e));
+// [lo, hi] of pick_rows for a stage, overridable for tuning experiments (Knobs)
+void rows_bounds(const cusift_ctx *ctx, int stage, int &lo, int &hi) {
+  if (ctx->knobs.rows_hi[stage] > 0) hi = ctx->knobs.rows_hi[stage];
+  if (ctx->knobs.rows_lo[stage] > 0) lo = ctx->knobs.rows_lo[stage];
   lo = std::min(lo, hi);
 }
 
@@ -411,6 +442,7 @@ static int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool 
   HIP_TRY(hipSetDevice(device));
   cusift_ctx *ctx = new cusift_ctx();
   ctx->device = device;
+  ctx->knobs = read_knobs();
   (void)hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device);
   if (ctx->num_cus < 1) ctx->num_cus = 256;
   if (borrow) {
@@ -698,7 +730,7 @@ static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t 
   const bool fast = w >= 4 && (src_pitch % 4 == 0) && (((uintptr_t)d_src % 16) == 0) &&
                     (src_stride % 4 == 0) && (dst_pitch % 2 == 0) && (((uintptr_t)d_dst % 8) == 0) &&
                     (dst_stride % 2 == 0) && ((size_t)h * src_pitch * sizeof(float) < (1ull << 31)) &&
-                    (band || !getenv("CUSIFT_FORCE_GENERIC"));
+                    (band || !ctx->knobs.force_generic);
   if (band && !fast)
     return fail(CUSIFT_ERR_INVALID, "ScaleDown (band): needs w >= 4, 16-byte aligned source rows, band < 2 GiB");
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
@@ -707,14 +739,14 @@ static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t 
     // measured (tools/probe_rows.py, 64 images): 1920x1080 -> 960x540 streams from HBM and likes short chunks
     // (r = 4: 0.137 ms, r = 32: 0.150 ms); the smaller levels are served by the Infinity Cache and like tall ones
     int rlo = 4, rhi = (long)oh * strips * n_images > 200000 ? 4 : 32;
-    rows_bounds("SCALEDOWN", rlo, rhi);
-    const int rows = pick_rows(oh, strips, n_images, rlo, rhi);
+    rows_bounds(ctx, kKnobScaleDown, rlo, rhi);
+    const int rows = pick_rows(ctx, oh, strips, n_images, rlo, rhi);
     dim3 grid(idiv_up(strips, kWavesPerBlock), idiv_up(oh, rows), n_images);
     hipLaunchKernelGGL(scale_down_fast_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride,
                        d_src, w, h, src_pitch, (long)src_stride, rows, T, src_rw, dst_row0, r_begin, r_end);
   } else {
     const int strips = idiv_up(ow, 64);
-    const int rows = pick_rows(oh, strips, n_images, 4, 16);
+    const int rows = pick_rows(ctx, oh, strips, n_images, 4, 16);
     dim3 grid(strips, idiv_up(idiv_up(oh, rows), kWavesPerBlock), n_images);
     hipLaunchKernelGGL(scale_down_kernel, grid, dim3(256), 0, ctx->stream, d_dst, dst_pitch, (long)dst_stride, d_src,
                        w, h, src_pitch, (long)src_stride, rows, T);
@@ -764,12 +796,11 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
   // many short waves write than when few long ones do (tools/ab_laplace_rows.sh with non-temporal stores, 64x1080p, all
   // octaves at one r: r = 3 0.263 ms per launch, 6: 0.242, 8: 0.234, 12: 0.239, 16: 0.243, 32: 0.270)
   int rlo = 3, rhi = 8;
-  rows_bounds("LAPLACE", rlo, rhi);
-  const int rows = pick_rows(h, strips, n_images, rlo, rhi);
+  rows_bounds(ctx, kKnobLaplace, rlo, rhi);
+  const int rows = pick_rows(ctx, h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
   // fast path: 16-byte aligned rows (any width >= 4), 32-bit buffer offsets
-  const bool fast = vec_ok && w >= 4 && ((size_t)h * pitch * sizeof(float) < (1ull << 31)) &&
-                    !getenv("CUSIFT_FORCE_GENERIC");
+  const bool fast = vec_ok && w >= 4 && ((size_t)h * pitch * sizeof(float) < (1ull << 31)) && !ctx->knobs.force_generic;
   StageTimer t(ctx, CUSIFT_STAGE_LAPLACE);
   if (fast) {
     LaplaceTapsPk TP;
@@ -779,13 +810,12 @@ extern "C" int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, 
         TP.k[q][j].y = taps[16 * (2 * q + 1) + j];
       }
     int wpb = kWavesPerBlock;
-    if (const char *e = getenv("CUSIFT_LAPLACE_WAVES")) wpb = std::max(1, std::min(4, atoi(e)));  // experiments only
+    if (ctx->knobs.laplace_waves > 0) wpb = std::min(4, ctx->knobs.laplace_waves);  // experiments only
     dim3 fgrid(strips, idiv_up(idiv_up(h, rows), wpb), n_images);
     // DoG planes are written once and read much later (by FindPointsMulti): non-temporal stores keep them from
     // displacing the source rows' halo in L2 -- measured on one box (tools/ab_laplace_aux.sh): 4.35 -> 4.63 TB/s for
     // this kernel and 3.87 -> 4.18 TB/s for the FindPointsMulti that follows
-    int aux = 2;
-    if (const char *e = getenv("CUSIFT_LAPLACE_AUX")) aux = atoi(e);  // experiments: cache policy of the DoG stores
+    const int aux = ctx->knobs.laplace_aux >= 0 ? ctx->knobs.laplace_aux : 2;  // experiments: cache policy of the stores
 #define LAUNCH_LAPLACE(A)                                                                                         \
   hipLaunchKernelGGL(laplace_multi_fast_kernel<A>, fgrid, dim3(64 * wpb), 0, ctx->stream, d_img, d_dog, w, h, pitch, \
                      (long)img_stride, (long)dog_stride, rows, TP)
@@ -815,11 +845,11 @@ extern "C" int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int
                      (((size_t)h * pitch) % 2 == 0);
   const int strips = idiv_up(w, kFindStrip);
   int rlo = 4, rhi = 16;  // tools/probe_rows.py, 64x1080p: r = 16 0.770 ms, r = 32 0.803 ms
-  rows_bounds("FINDPOINTS", rlo, rhi);
-  const int rows = pick_rows(h, strips, n_images, rlo, rhi);
+  rows_bounds(ctx, kKnobFindPoints, rlo, rhi);
+  const int rows = pick_rows(ctx, h, strips, n_images, rlo, rhi);
   dim3 grid(strips, idiv_up(idiv_up(h, rows), kWavesPerBlock), n_images);
   const bool fast = vec_ok && w >= 2 &&
-                    ((size_t)kNumDog * h * pitch * sizeof(float) < (1ull << 31)) && !getenv("CUSIFT_FORCE_GENERIC");
+                    ((size_t)kNumDog * h * pitch * sizeof(float) < (1ull << 31)) && !ctx->knobs.force_generic;
   StageTimer t(ctx, CUSIFT_STAGE_FINDPOINTS);
   if (fast) {
     dim3 fgrid(idiv_up(strips, kWavesPerBlock), idiv_up(h, rows), n_images);  // 4 waves = 4 adjacent strips
@@ -870,16 +900,16 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   // streams 0.05 -> 1.451, 0.08 -> 1.414 ms per step; four streams 0.05 -> 1.414, 0.08 -> 1.370, 0.1 -> 1.379,
   // 0.13 -> 1.382.  The caller says which case it is (cusift_params.concurrent_batches).
   int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 64;
-  rows_bounds("DETECT", rows_lo, rows_hi);
+  rows_bounds(ctx, kKnobDetect, rows_lo, rows_hi);
   const double wave_rows = (double)rows_total * strips * n_images;
   double coef = concurrent >= 2 ? 0.09 : 0.05;
-  if (const char *e = getenv("CUSIFT_DETECT_ROWS_COEF")) coef = atof(e);  // tuning experiments only
+  if (ctx->knobs.detect_rows_coef > 0.0) coef = ctx->knobs.detect_rows_coef;  // tuning experiments only
   const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
   // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
   // threshold pre-test makes the waves' run times uneven -- measured 64x1080p, r = 16: 4 waves per workgroup 0.693 ms,
   // 2: 0.645 ms, 1: 0.630 ms (tools/probe_rows.py with CUSIFT_DETECT_WAVES).
   int wpb = 1;
-  if (const char *e = getenv("CUSIFT_DETECT_WAVES")) wpb = std::max(1, std::min(4, atoi(e)));  // experiments only
+  if (ctx->knobs.detect_waves > 0) wpb = std::min(4, ctx->knobs.detect_waves);  // experiments only
   dim3 grid(strips, idiv_up(idiv_up(rows_total, rows), wpb), n_images);
   const size_t cube_bytes = (size_t)wpb * kDetectWaveLdsFloats * sizeof(float);  // the wave's candidate list
   // levels 0 and 1 both identity (initBlur >= their sigma)?  then the kernel passes them through
@@ -887,7 +917,7 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   for (int lv = 0; lv < 2; ++lv)
     for (int j = 0; j < 9; ++j) ident0 = ident0 && (taps[16 * lv + j] == (j == kBlurRadius ? 1.0f : 0.0f));
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
-  if (ident0 && !getenv("CUSIFT_NO_IDENT"))
+  if (ident0 && !ctx->knobs.no_ident)
     hipLaunchKernelGGL(detect_fused_kernel<true>, grid, dim3(64 * wpb), cube_bytes, ctx->stream, d_img, w, h, pitch,
                        (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   else
@@ -1015,7 +1045,7 @@ extern "C" int cusift_match(cusift_ctx *ctx, cusift_point *d_sift1, int num_pts1
   // Column splits: aim at >= 4 workgroups per CU, keep >= 4 LDS tiles (128 columns) per split.
   const int row_blocks = idiv_up(num_pts1, 64);
   int splits = std::max(1, std::min(idiv_up(4 * ctx->num_cus, row_blocks), idiv_up(num_pts2, 128)));
-  if (const char *e = getenv("CUSIFT_MATCH_SPLITS")) splits = std::max(1, std::min(atoi(e), idiv_up(num_pts2, 32)));
+  if (ctx->knobs.match_splits > 0) splits = std::min(ctx->knobs.match_splits, idiv_up(num_pts2, 32));
   splits = std::min(splits, 65535);
   // the kernel addresses a split's columns through a buffer resource with 32-bit byte offsets: a split may span at most
   // 2^31 / 588 records (3.65 M) -- more points than that force further splits
@@ -1169,10 +1199,10 @@ extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points,
 // ------------------------------------------------------------------------------------------------
 // Bytes of DoG planes the two-stage path needs: the largest searched octave that does not take the fused detection
 // (0 when every octave does).  `arena_base`: where octaves >= 1 live (their alignment is what matters).
-static size_t two_stage_dog_bytes(const Plan &pl, const cusift_params *prm, const float *d_imgs, size_t image_stride,
-                                  const char *arena_base, int n_images) {
+static size_t two_stage_dog_bytes(const cusift_ctx *ctx, const Plan &pl, const cusift_params *prm, const float *d_imgs,
+                                  size_t image_stride, const char *arena_base, int n_images) {
   size_t need = 0;
-  const bool generic = getenv("CUSIFT_FORCE_GENERIC") != nullptr;
+  const bool generic = ctx->knobs.force_generic;
   for (int o = 0; o < pl.n_oct; ++o) {
     if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;
     const float *b = o == 0 ? d_imgs : (const float *)(arena_base + pl.base_off[o]);
@@ -1192,7 +1222,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   Plan pl;
   TRY(make_plan(pl, n_images, w, h, pitch, prm));
   TRY(ensure_arena(ctx, pl.total));
-  if (const size_t dog_need = two_stage_dog_bytes(pl, prm, d_imgs, image_stride, ctx->arena, n_images))
+  if (const size_t dog_need = two_stage_dog_bytes(ctx, pl, prm, d_imgs, image_stride, ctx->arena, n_images))
     TRY(ensure_dog(ctx, dog_need));  // sized once for the largest two-stage octave, before anything is enqueued
 
   StageTimer total(ctx, CUSIFT_STAGE_TOTAL);
@@ -1217,7 +1247,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   // kernel is chosen per octave: the fused one wherever it applies (16-byte aligned rows, w >= 4, h >= 3), the
   // two-stage pair for an octave where it does not (a 2x1 coarsest octave, a caller's odd pitch) -- one such octave
   // no longer demotes the others.
-  const bool generic = getenv("CUSIFT_FORCE_GENERIC") != nullptr;
+  const bool generic = ctx->knobs.force_generic;
   const bool flat = prm->fused_detect && n_images <= kMaxFlatImages && !generic;
   // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
   for (int o = pl.n_oct - 1; o >= 0; --o) {
@@ -1304,7 +1334,7 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
   // everything that allocates or synchronises happens before the capture starts
   TRY(ensure_arena(ctx, pl.total));
   // the DoG planes of every octave that takes the two-stage path (see cusift_extract_batch), sized up front
-  const size_t dog_need = two_stage_dog_bytes(pl, prm, d_imgs, image_stride, ctx->arena, n_images);
+  const size_t dog_need = two_stage_dog_bytes(ctx, pl, prm, d_imgs, image_stride, ctx->arena, n_images);
   if (dog_need) TRY(ensure_dog(ctx, dog_need));
   if (ctx->describe_grid == 0) {
     int per_cu = 0, cus = 0;

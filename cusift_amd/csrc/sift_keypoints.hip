@@ -7,31 +7,8 @@
 // bit-identical to the oracle's, descriptors differ only by the summation order of the histogram (~1e-7).
 #include "sift_device.h"
 
-// Cost-attribution experiments (tools/exp_describe_phases.sh): -DCUSIFT_EXP=<n> removes one phase of the keypoint body
-// (results are then wrong on purpose); never defined in the product build.
-#ifndef CUSIFT_EXP
-#define CUSIFT_EXP 0
-#endif
-
-// -DCUSIFT_EXP=10: phase stamps (s_memtime) of every keypoint, written into unused fields of its own record (score,
-// ambiguity, match_*, empty, coords3D) and read back by tools/exp_describe_stamps.py
-#if CUSIFT_EXP >= 10
-#define KP_STAMP(st, i)                                                  \
-  do {                                                                   \
-    if (st) (st)[i] = (unsigned int)__builtin_amdgcn_s_memtime();        \
-  } while (0)
-#else
-#define KP_STAMP(st, i) ((void)0)
-#endif
-
 namespace cusift {
 
-#if CUSIFT_EXP == 4
-#define sm_atan2f(y, x) ((y) * 0.5f + (x))
-#endif
-#if CUSIFT_EXP == 5
-#define sqrtf(x) ((x) * 0.5f)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Software model of the CUDA texture fetch the reference relies on:
@@ -97,13 +74,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
       (void *)(img + (long)row_first * pitch), 0, (int)(left < 0x7fffffffL ? left : 0x7fffffffL), kBufFlags);
   // byte offset of patch row i, computed by lane i for all rows at once (ph <= 64) and handed to the loads with
   // v_readlane (on the scalar unit the two clamps and the multiply are ~22 dependent instructions per row)
-#if CUSIFT_EXP == 13  // every row load reads the patch's first row (stamps only: what does a row load cost when it hits?)
-  const int row_off = 0 * lane;
-#elif CUSIFT_EXP == 14  // rows 128 bytes apart instead of one pitch apart: same number of lines, one or two pages
-  const int row_off = lane * 128;
-#else
   const int row_off = (local_row(y0 + lane, h, rw) - row_first) * (pitch * 4);
-#endif
   if (lane < pw) {
     for (int r = 0; r < ph; ++r) {
       const int off = __builtin_amdgcn_readlane(row_off, r);
@@ -219,7 +190,6 @@ struct alignas(16) KpShared {
   // shared by the two stages (they never overlap in time):
   //   orientation: wmat() = [2 halves][8 rows][32 bins] one-hot weights of the samples being summed
   //   descriptor : grad() / angraw() = weighted gradient magnitude and 4/pi*atan2 + 4 of the 16x16 samples, stored
-  //                at desc_slot(y, tx) -- a skewed layout, see there
   //                at desc_slot(y, tx) -- a skewed layout, see there; the two arrays lie kAngOffset = 5 x 64 floats
   //                apart, so one ds_read2st64_b32 / ds_write2st64_b32 moves a sample's pair
   float scratch[kAngOffset + kDescSlots];
@@ -291,8 +261,7 @@ __device__ __forceinline__ float tree_sum64(float x) {
 }
 
 template <typename SH, typename TEX>
-__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx,
-                                                unsigned int *st = nullptr) {
+__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
   if (tx < 11) S.gauss[tx] = sm_expf(i2sigma2 * (tx - 5) * (tx - 5));
   const float xp = kx - 5.0f;
@@ -331,7 +300,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   // Both samples are computed without a branch between them (lanes 57..63 repeat sample 120; their second weight is
   // never posted), so that the two gradient / atan2f / sqrtf chains -- each a long run of dependent operations --
   // interleave instead of running one after the other.
-  constexpr int kReps = CUSIFT_EXP == 6 ? 1 : 2;
+  constexpr int kReps = 2;
   int xd[2], yd[2];
   float dx[2], dy[2];
 #pragma unroll
@@ -378,7 +347,6 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     sbin[rep] = bin;
     swgt[rep] = grad * S.gauss[xd[rep]] * S.gauss[yd[rep]];
   }
-  KP_STAMP(st, 2);  // orientation samples done
   {
     // Histogram without LDS atomics and without a compare per (bin, sample) pair.  Bins are lanes (tx & 31); the
     // lower half-wave sums samples 0..63 in index order, the upper half-wave samples 64..120, then hist = lower +
@@ -408,7 +376,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     float acc = 0.0f;
     asm volatile("" ::: "memory");
 #pragma unroll 4
-    for (int k = 0; k < (CUSIFT_EXP == 1 ? 1 : 8); ++k) {
+    for (int k = 0; k < 8; ++k) {
       const bool owner = (tx >> 3) == k;
       float *p0 = owner ? w0p : junk;
       float *p1 = (owner && has1) ? w1p : junk;
@@ -427,7 +395,6 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     if (tx < 32) S.hist[tx] = acc + S.hist[tx + 32];
   }
   wave_sync();
-  KP_STAMP(st, 3);  // histogram done
   const int x1m = (tx >= 1 ? tx - 1 : tx + 31);
   const int x1p = (tx <= 30 ? tx + 1 : tx - 31);
   if (tx < 32) {
@@ -453,7 +420,6 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * mv - val1 - val2);
   const float ori = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
   wave_sync();  // every lane has read hist before the caller reuses the buffers
-  KP_STAMP(st, 4);  // smoothing, peak
   return ori;
 }
 
@@ -524,21 +490,10 @@ __device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float 
   *p2 = h2 + v2;
 }
 
-// Sensitivity experiments (tools/exp_describe_ballast.sh): 200 extra independent v_fma_f32 per keypoint, placed in the
-// sampling phase (CUSIFT_EXP == 7), in the gather (8) or at the end of the keypoint (9)
-__device__ __forceinline__ void valu_ballast(float &sink) {
-  float a = sink, b = sink + 1.0f, c = sink + 2.0f, d = sink + 3.0f;
-#pragma unroll
-  for (int i = 0; i < 50; ++i)
-    asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-  sink = (a + b) + (c + d);
-}
-
 template <typename TEX>
 __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const DescLaneConsts &C, float px,
                                               float py, float kp_scale, float orientation, int lane, float &out0,
-                                              float &out1, unsigned int *st = nullptr) {
+                                              float &out1) {
   const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
   float *myhist = S.hist8() + lane;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
@@ -550,7 +505,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
 
   // ---- phase 1: samples ----
 #pragma unroll
-  for (int step = 0; step < (CUSIFT_EXP == 2 ? 1 : 4); ++step) {
+  for (int step = 0; step < 4; ++step) {
     const int idx = lane + 64 * step;
     const int y = idx >> 4, tx = C.tx1;
     const float gy = C.gy1[step], gx = C.gx1;
@@ -563,15 +518,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     S.grad()[slot] = grad;
     S.angraw()[slot] = 4.0f / 3.1415f * sm_atan2f(dy, dx) + 4.0f;
   }
-#if CUSIFT_EXP == 7
-  {
-    float sink = px;
-    valu_ballast(sink);
-    if (sink == 12345.678f) S.grad()[0] = sink;
-  }
-#endif
   wave_sync();
-  KP_STAMP(st, 5);  // descriptor samples done
   // the patch is dead from here on: its storage becomes the histogram buffers and the samples' slot offsets
 #pragma unroll
   for (int b = 0; b < 9; ++b) myhist[b * 64] = 0.0f;
@@ -585,7 +532,6 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     S.angpk()[slot] = pk;
   }
   wave_sync();
-  KP_STAMP(st, 6);  // angle split done
 
   // ---- phase 2: gather into the lane-private histogram ----
   // Four samples of a row are read first, then accumulated: the compiler cannot move a sample read above the
@@ -599,7 +545,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       const float verf = (y - 1.5f) / 4.0f - veri;
       const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
 #pragma unroll
-      for (int half = 0; half < (CUSIFT_EXP == 3 ? 1 : 2); ++half) {  // four samples at a time: register budget
+      for (int half = 0; half < 2; ++half) {  // four samples at a time: register budget
         float sg[4], sf[4];
         unsigned int sp[4];
 #pragma unroll
@@ -624,13 +570,6 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       }
     }
   }
-#if CUSIFT_EXP == 8
-  {
-    float sink = px;
-    valu_ballast(sink);
-    if (sink == 12345.678f) myhist[0] = sink;
-  }
-#endif
   if (hi == 0 && vi >= 1) {
     // the reference's right-hand adds of column 14 (hori+1 == 4) land in cell (row+1, 0)
 #pragma unroll
@@ -647,7 +586,6 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     }
   }
   wave_sync();
-  KP_STAMP(st, 7);  // gather done
 
   // ---- phase 3: cell sums (fixed order) and normalisation ----
   float bsum[2];
@@ -673,14 +611,6 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       if (b1 > 0.2f) b1 = 0.2f;
     }
   }
-#if CUSIFT_EXP == 9
-  {
-    float sink = px;
-    valu_ballast(sink);
-    if (sink == 12345.678f) b0 = sink;
-  }
-#endif
-  KP_STAMP(st, 8);  // cell sums, normalisation
   out0 = b0;
   out1 = b1;
 }
@@ -762,9 +692,6 @@ __device__ __forceinline__ void finish_descriptor(KpShared &S, cusift_point *pt,
     wave_sync();
     rootsift_lanes(v, lane, b0, b1);
   }
-#if CUSIFT_EXP == 12
-  if (b0 == 12345.0f)
-#endif
   {
     pt->data[lane] = b0;
     pt->data[lane + 64] = b1;
@@ -842,10 +769,10 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
 template <typename TEX>
 __device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, const DescLaneConsts &C,
                                                   cusift_point *pt, float px, float py, float kscale, float sub,
-                                                  int lane, int root_sift, unsigned int *st = nullptr) {
-  const float ori = kp_orientation(S, tex, px, py, kscale, lane, st);
+                                                  int lane, int root_sift) {
+  const float ori = kp_orientation(S, tex, px, py, kscale, lane);
   float b0, b1;
-  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1, st);
+  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
   if (lane == 0) pt->orientation = ori;
   finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
 }
@@ -908,13 +835,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     rec = fetch_head(pt);
   }
   while (g < total) {
-#if CUSIFT_EXP >= 10
-    unsigned int stamps[11] = {};
-    unsigned int *st = stamps;
-#else
-    unsigned int *st = nullptr;
-#endif
-    KP_STAMP(st, 0);
     unsigned int nxt = 0;
     if (lane == 0) nxt = shard + kQueueShards * (atomicAdd(cursor, 1u) + per_shard);
     const float px = head(0), py = head(1), kscale = head(2), sub = head(kSubIndex);
@@ -929,10 +849,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     PatchGeom pg;
     int pw, ph;
     const bool use_patch = patch_for_reach(px, py, reach, pg, pw, ph);
-    KP_STAMP(st, 10);  // record read, geometry known
     if (use_patch) stage_patch(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
     wave_sync();
-    KP_STAMP(st, 1);  // patch staged
     // the patch loads have been waited for, so has the atomic issued before them: fetch the next record now.
     // (Tried on top of this and dropped, tools/exp_describe_stamps.sh: forming the next keypoint's geometry between the
     // stages -- the ~600 cycles it saves here come back, and more, in the descriptor stage; touching the next patch's
@@ -946,32 +864,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (use_patch) {
       if (q > 0.0f)
         describe_keypoint(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
-                          sub, lane, root_sift, st);
+                          sub, lane, root_sift);
       else
         describe_keypoint(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
-                          sub, lane, root_sift, st);
+                          sub, lane, root_sift);
     } else {
-      describe_keypoint(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift,
-                        st);
+      describe_keypoint(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift);
     }
     wave_sync();
-#if CUSIFT_EXP >= 10
-    KP_STAMP(st, 9);
-    if (lane == 0) {  // durations of the nine segments, in shader cycles
-      float *f = &pt->score;
-      f[0] = (float)(stamps[1] - stamps[0]);      // score: record + patch staging
-      f[1] = (float)(stamps[2] - stamps[1]);      // ambiguity: orientation samples
-      pt->match_xpos = (float)(stamps[3] - stamps[2]);   // orientation histogram
-      pt->match_ypos = (float)(stamps[4] - stamps[3]);   // smoothing + peak
-      pt->match_error = (float)(stamps[5] - stamps[4]);  // descriptor samples (incl. sincos)
-      pt->empty[0] = (float)(stamps[6] - stamps[5]);     // angle split + histogram zeroing
-      pt->empty[1] = (float)(stamps[7] - stamps[6]);     // gather
-      pt->empty[2] = (float)(stamps[8] - stamps[7]);     // cell sums + normalisation
-      pt->coords3D[0] = (float)(stamps[9] - stamps[8]);  // record stores
-      pt->coords3D[1] = (float)(stamps[10] - stamps[0]);  // of the first segment: until the geometry is known
-      pt->coords3D[2] = (float)(pw * 100 + ph);
-    }
-#endif
     pt = pt_next;
   }
 }

@@ -18,9 +18,6 @@
 // for exact-score near-ties (tests bound both).
 #include "sift_device.h"
 
-#ifndef CUSIFT_MATCH_EXP
-#define CUSIFT_MATCH_EXP 0  // cost-attribution experiments (tools/exp_match.sh); results are wrong on purpose when != 0
-#endif
 
 namespace cusift {
 
@@ -126,17 +123,13 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
   if (col_begin < col_end) fetch(col_begin);
   const float *brow = sB + r * kBStride + 4 * g;
   for (int c0 = col_begin; c0 < col_end; c0 += kMatchTileCols) {
-#if CUSIFT_MATCH_EXP != 2
     __syncthreads();  // the previous tile has been consumed
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = threadIdx.x + 256 * i;
       *reinterpret_cast<u4 *>(sB + (c >> 5) * kBStride + 4 * (c & 31)) = stage[i];
     }
-#if CUSIFT_MATCH_EXP != 2
     __syncthreads();
-#endif
     if (c0 + kMatchTileCols < col_end) fetch(c0 + kMatchTileCols);  // in flight while this tile is multiplied
 
     // two independent 16x16 accumulators (columns c0 + r and c0 + 16 + r), each a k-ordered chain; the B fragments
@@ -152,27 +145,17 @@ __global__ void __launch_bounds__(256) match_kernel(cusift_point *__restrict__ s
         n0 = *reinterpret_cast<const f4 *>(brow + 16 * (u + 1));
         n1v = *reinterpret_cast<const f4 *>(brow + 16 * kBStride + 16 * (u + 1));
       }
-#if CUSIFT_MATCH_EXP == 3
-      acc0 += b0 * a[u][0];
-      acc1 += b1 * a[u][1];
-#else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b0[j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b1[j], acc1, 0, 0, 0);
       }
-#endif
       b0 = n0;
       b1 = n1v;
     }
     __builtin_amdgcn_s_setprio(0);
     // acc[q] = <descriptor p1_base + 4g + q, descriptor p2>.  (Deferring this update into the next tile's MFMA gaps
     // -- one score per step u -- was built and measured: no change, 110-112 TFLOP/s at 16k either way.)
-#if CUSIFT_MATCH_EXP == 1
-#pragma unroll
-    for (int q = 0; q < 4; ++q) best[q] = fminf(best[q], acc0[q] + acc1[q]);
-    if (false)
-#endif
     {
       const bool full = c0 + kMatchTileCols <= col_end;  // wave-uniform: only a split's last tile can be partial
 #pragma unroll

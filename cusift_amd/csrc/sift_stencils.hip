@@ -378,27 +378,27 @@ struct RefinedPoint {
   float x, y, scale, sharpness, edgeness;
 };
 
-// refinement of one candidate from the DoG planes in global memory (L2-hot): cuSIFT_D.cu:478-521, evaluated operation
-// by operation exactly as oracle_find_points_multi.  Returns whether it passes the edge test; fields go to `r`.
-__device__ __forceinline__ bool refine_from_planes(const float *__restrict__ dog, long plane, int pitch, int x, int y,
-                                                   int s, const FindParams &P, RefinedPoint &r) {
-  const float *d1 = dog + (long)(s + 1) * plane + (long)y * pitch + x;
-  const float val = d1[0];
-  const float dxx = 2.0f * val - d1[-1] - d1[1];
-  const float dyy = 2.0f * val - d1[-pitch] - d1[pitch];
-  const float dxy = 0.25f * (d1[pitch + 1] + d1[-pitch - 1] - d1[-pitch + 1] - d1[pitch - 1]);
+// THE refinement of a candidate (cuSIFT_D.cu:478-521), from the 19 DoG values it reads: c[3*(dy+1) + (dx+1)] = centre
+// plane, lo[] / hi[] = planes below / above at {(0,0), (-1,0), (+1,0), (0,-1), (0,+1)} as (dx,dy).  Evaluated operation
+// by operation exactly as oracle_find_points_multi.  Returns whether the candidate passes the edge test; the record
+// fields go to `r`.  Every detection kernel ends here: the fused one hands over values it holds in registers, the
+// two-stage ones load them from the DoG planes first (load_candidate).
+__device__ __forceinline__ bool refine_from_values(const float (&c)[9], const float (&lo)[5], const float (&hi)[5], int x,
+                                                   int y, int s, const FindParams &P, RefinedPoint &r) {
+  const float val = c[4];
+  const float dxx = 2.0f * val - c[3] - c[5];
+  const float dyy = 2.0f * val - c[1] - c[7];
+  const float dxy = 0.25f * (c[8] + c[0] - c[2] - c[6]);
   const float tra = dxx + dyy;
   const float det = dxx * dyy - dxy * dxy;
   if (!(tra * tra < P.edge_limit * det)) return false;
   const float edge = (tra * tra) / det;
-  const float dx = 0.5f * (d1[1] - d1[-1]);
-  const float dy = 0.5f * (d1[pitch] - d1[-pitch]);
-  const float *d0 = d1 - plane;
-  const float *d2 = d1 + plane;
-  const float ds = 0.5f * (d0[0] - d2[0]);
-  const float dss = 2.0f * val - d2[0] - d0[0];
-  const float dxs = 0.25f * (d2[1] + d0[-1] - d0[1] - d2[-1]);
-  const float dys = 0.25f * (d2[pitch] + d0[-pitch] - d2[-pitch] - d0[pitch]);
+  const float dx = 0.5f * (c[5] - c[3]);
+  const float dy = 0.5f * (c[7] - c[1]);
+  const float ds = 0.5f * (lo[0] - hi[0]);
+  const float dss = 2.0f * val - hi[0] - lo[0];
+  const float dxs = 0.25f * (hi[2] + lo[1] - lo[2] - hi[1]);
+  const float dys = 0.25f * (hi[4] + lo[3] - hi[3] - lo[4]);
   const float idxx = dyy * dss - dys * dys;
   const float idxy = dys * dxs - dxy * dss;
   const float idxs = dxy * dys - dyy * dxs;
@@ -421,6 +421,27 @@ __device__ __forceinline__ bool refine_from_planes(const float *__restrict__ dog
   r.sharpness = val + dval;
   r.edgeness = edge;
   return true;
+}
+
+// the 19 values of a candidate from the DoG planes in global memory (L2-hot)
+__device__ __forceinline__ void load_candidate(const float *__restrict__ dog, long plane, int pitch, int x, int y, int s,
+                                               float (&c)[9], float (&lo)[5], float (&hi)[5]) {
+  const float *d1 = dog + (long)(s + 1) * plane + (long)y * pitch + x;
+  const float *d0 = d1 - plane;
+  const float *d2 = d1 + plane;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[3 * r + k] = d1[(r - 1) * pitch + (k - 1)];
+  lo[0] = d0[0], lo[1] = d0[-1], lo[2] = d0[1], lo[3] = d0[-pitch], lo[4] = d0[pitch];
+  hi[0] = d2[0], hi[1] = d2[-1], hi[2] = d2[1], hi[3] = d2[-pitch], hi[4] = d2[pitch];
+}
+
+__device__ __forceinline__ bool refine_from_planes(const float *__restrict__ dog, long plane, int pitch, int x, int y,
+                                                   int s, const FindParams &P, RefinedPoint &r) {
+  float c[9], lo[5], hi[5];
+  load_candidate(dog, plane, pitch, x, y, s, c, lo, hi);
+  return refine_from_values(c, lo, hi, x, y, s, P, r);
 }
 
 // Per-wave list of candidate POSITIONS in LDS for the two-stage path (the DoG planes are in memory, L2-hot, so a
@@ -477,48 +498,16 @@ struct PosList {
 __device__ __forceinline__ void refine_and_append(const float *__restrict__ dog, long plane, int pitch, int x, int y,
                                                    int s, const FindParams &P, cusift_point *__restrict__ pts,
                                                    int max_pts, unsigned int *counter) {
-  // cuSIFT_D.cu:478-521, evaluated operation by operation exactly as oracle_find_points_multi
-  const float *d1 = dog + (long)(s + 1) * plane + (long)y * pitch + x;
-  const float val = d1[0];
-  const float dxx = 2.0f * val - d1[-1] - d1[1];
-  const float dyy = 2.0f * val - d1[-pitch] - d1[pitch];
-  const float dxy = 0.25f * (d1[pitch + 1] + d1[-pitch - 1] - d1[-pitch + 1] - d1[pitch - 1]);
-  const float tra = dxx + dyy;
-  const float det = dxx * dyy - dxy * dxy;
-  if (!(tra * tra < P.edge_limit * det)) return;
-  const float edge = (tra * tra) / det;
-  const float dx = 0.5f * (d1[1] - d1[-1]);
-  const float dy = 0.5f * (d1[pitch] - d1[-pitch]);
-  const float *d0 = d1 - plane;
-  const float *d2 = d1 + plane;
-  const float ds = 0.5f * (d0[0] - d2[0]);
-  const float dss = 2.0f * val - d2[0] - d0[0];
-  const float dxs = 0.25f * (d2[1] + d0[-1] - d0[1] - d2[-1]);
-  const float dys = 0.25f * (d2[pitch] + d0[-pitch] - d2[-pitch] - d0[pitch]);
-  const float idxx = dyy * dss - dys * dys;
-  const float idxy = dys * dxs - dxy * dss;
-  const float idxs = dxy * dys - dyy * dxs;
-  const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
-  const float idyy = dxx * dss - dxs * dxs;
-  const float idys = dxy * dxs - dxx * dys;
-  const float idss = dxx * dyy - dxy * dxy;
-  float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
-  float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
-  float pds = idet * (idxs * dx + idys * dy + idss * ds);
-  if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
-    pdx = dx / dxx;
-    pdy = dy / dyy;
-    pds = ds / dss;
-  }
-  const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
+  RefinedPoint r;
+  if (!refine_from_planes(dog, plane, pitch, x, y, s, P, r)) return;
   const unsigned int idx = atomicAdd(counter, 1u);
   if (idx >= (unsigned int)max_pts) return;
   cusift_point *pt = pts + idx;
-  pt->coords2D[0] = (float)x + pdx;
-  pt->coords2D[1] = (float)y + pdy;
-  pt->scale = P.scales[s] * sm_exp2f(pds * P.factor);
-  pt->sharpness = val + dval;
-  pt->edgeness = edge;
+  pt->coords2D[0] = r.x;
+  pt->coords2D[1] = r.y;
+  pt->scale = r.scale;
+  pt->sharpness = r.sharpness;
+  pt->edgeness = r.edgeness;
   pt->subsampling = P.subsampling;
 }
 
@@ -746,19 +735,10 @@ __global__ void __launch_bounds__(256) find_points_fast_kernel(const float *__re
 //   * a wave owns rows [y0,y1) as extremum CENTRES: it blurs rows y0-1 .. y1 (2 extra rows per chunk).
 //     Image-border pixels are never extrema in the reference (a clamped neighbour equals the centre), so
 //     centres are restricted to 1..h-2 / 1..w-2 and no clamped DoG row is ever needed.
-//   * refinement (rare): the three planes x three rows a scale needs are dumped to a wave-private LDS
-//     cube, so the detecting lane can read its 3x3x3 neighbourhood (incl. neighbour lanes' columns) with
-//     the same code as the unfused kernel reads it from global memory.
+//   * refinement (rare): the detecting lane parks the 19 DoG values its refinement reads -- all in its own registers
+//     but the column beyond its float4 (five DPP moves) -- in a per-wave LDS list, and the wave refines 64 candidates
+//     at a time (CandList below).
 // ------------------------------------------------------------------------------------------------
-// -DCUSIFT_DET_STAMPS=1 (fill and total only) / =2 (per row: intrusive, 3x slower): s_memtime attribution of a wave's cycles (tools/exp_detect_stamps.sh); sums over all waves in
-// g_det_cycles = {window fill, blur + DoG, pre-test + extrema analysis, refinement + key list, window shift (waits for
-// the row loaded two steps ago), wave total, wave-rows, waves}
-#ifdef CUSIFT_DET_STAMPS
-constexpr int kDetLogWaves = 1 << 17;
-__device__ unsigned int g_det_log[kDetLogWaves][8];  // one row per wave of the LAST launch (slot = linear block index)
-#define DET_NOW() ((unsigned int)__builtin_amdgcn_s_memtime())
-#endif
-
 constexpr int kDetHaloLanes = 2;
 constexpr int kDetStrip = (64 - 2 * kDetHaloLanes) * kBlurCols;  // 240 columns of extremum centres per wave
 constexpr int kCandWords = 21;                                   // 19 DoG values, x, (y << 3) | scale index
@@ -815,50 +795,6 @@ __device__ __forceinline__ void blur_dog_row(const f4 (&win)[9], const LaplaceTa
 #pragma unroll
     for (int j = 0; j < 4; ++j) prev_hi[j] = L[j].y;
   }
-}
-
-// Refinement of one candidate from the 19 DoG values it reads (cuSIFT_D.cu:478-521): c[3*(dy+1) + (dx+1)] = centre
-// plane, lo[] / hi[] = planes below / above at {(0,0), (-1,0), (+1,0), (0,-1), (0,+1)} as (dx,dy).  Arithmetic:
-// refine_from_planes / oracle_find_points_multi, operation by operation.  Returns whether the candidate passes the edge
-// test; the record fields go to `r`.
-__device__ __forceinline__ bool refine_from_values(const float (&c)[9], const float (&lo)[5], const float (&hi)[5], int x,
-                                                   int y, int s, const FindParams &P, RefinedPoint &r) {
-  const float val = c[4];
-  const float dxx = 2.0f * val - c[3] - c[5];
-  const float dyy = 2.0f * val - c[1] - c[7];
-  const float dxy = 0.25f * (c[8] + c[0] - c[2] - c[6]);
-  const float tra = dxx + dyy;
-  const float det = dxx * dyy - dxy * dxy;
-  if (!(tra * tra < P.edge_limit * det)) return false;
-  const float edge = (tra * tra) / det;
-  const float dx = 0.5f * (c[5] - c[3]);
-  const float dy = 0.5f * (c[7] - c[1]);
-  const float ds = 0.5f * (lo[0] - hi[0]);
-  const float dss = 2.0f * val - hi[0] - lo[0];
-  const float dxs = 0.25f * (hi[2] + lo[1] - lo[2] - hi[1]);
-  const float dys = 0.25f * (hi[4] + lo[3] - hi[3] - lo[4]);
-  const float idxx = dyy * dss - dys * dys;
-  const float idxy = dys * dxs - dxy * dss;
-  const float idxs = dxy * dys - dyy * dxs;
-  const float idet = 1.0f / (idxx * dxx + idxy * dxy + idxs * dxs);
-  const float idyy = dxx * dss - dxs * dxs;
-  const float idys = dxy * dxs - dxx * dys;
-  const float idss = dxx * dyy - dxy * dxy;
-  float pdx = idet * (idxx * dx + idxy * dy + idxs * ds);
-  float pdy = idet * (idxy * dx + idyy * dy + idys * ds);
-  float pds = idet * (idxs * dx + idys * dy + idss * ds);
-  if (pdx < -0.5f || pdx > 0.5f || pdy < -0.5f || pdy > 0.5f || pds < -0.5f || pds > 0.5f) {
-    pdx = dx / dxx;
-    pdy = dy / dyy;
-    pds = ds / dss;
-  }
-  const float dval = 0.5f * (dx * pdx + dy * pdy + ds * pds);
-  r.x = (float)x + pdx;
-  r.y = (float)y + pdy;
-  r.scale = P.scales[s] * sm_exp2f(pds * P.factor);
-  r.sharpness = val + dval;
-  r.edgeness = edge;
-  return true;
 }
 
 // Per-wave list of CANDIDATES in LDS, refined 64 at a time.  Measured (tools/exp_detect_parts.sh, 64 x 1080p): refining
@@ -958,24 +894,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
   };
   auto fix = [&](f4 v) -> f4 { return edge(v); };
 
-#ifdef CUSIFT_DET_STAMPS
-  unsigned int acc_fill = 0, acc_blur = 0, acc_ext = 0, acc_ref = 0, acc_shift = 0, n_rows = 0;
-  const unsigned int t_begin = DET_NOW();
-#endif
   f4 win[9];
 #pragma unroll
-#if defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 3  // upper bound for a hidden window fill: nine loads of ONE row (cache hits)
-  for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 5 + (i & 1)));
-#else
   for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 1 - 4 + i));
-#endif
-#ifdef CUSIFT_DET_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  acc_fill = DET_NOW() - t_begin;
-#if CUSIFT_DET_STAMPS == 4
-  acc_fill = 0;
-#endif
-#endif
 
   // DoG rows yy-2, yy-1, yy live in three register sets whose roles rotate; the row loop is unrolled by
   // three so the rotation costs no moves.
@@ -985,17 +906,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
 
   f4 ahead = load_raw(ya - 1 + 5);  // row yy+5 of the first iteration; the loop keeps two rows in flight
   auto row_step = [&](int yy, f4 (&D0)[kNumDog], f4 (&D1)[kNumDog], f4 (&D2)[kNumDog]) {
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
-    const unsigned int s0 = DET_NOW();
-#endif
     const f4 nxt = ahead;        // requested one iteration ago (raw)
     ahead = load_raw(yy + 6);    // needed two iterations from now
     blur_dog_row<kIdent0>(win, T, D2);
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
-    const unsigned int s1 = DET_NOW();
-    unsigned int s2 = s1, s3 = s1;
-    bool had_event = false;
-#endif
 
     if (yy >= ya + 1) {
       const int y = yy - 1;  // centre row: D0 = y-1, D1 = y, D2 = y+1
@@ -1017,12 +930,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
       // halo lanes and lanes right of the image hold no centres (and their DoG values are not meaningful)
       const bool big = vmax > P.thr_pos && lane_valid && c0 < w;
       unsigned int cand = 0;  // bit (4*s + j)
-#if defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 2
-      if (big && vmax == 12345.0f) cand = 0x000fffffu;
-      if (false) {
-#else
       if (__builtin_amdgcn_ballot_w64(big) != 0) {  // wave-uniform
-#endif
         // per plane: 3-row column min/max, then the 3x3 min/max (h*) and the left/right neighbours' columns
         f4 hmn[kNumDog], hmx[kNumDog];
         f4 lmn[kNumScales], rmn[kNumScales], lmx[kNumScales], rmx[kNumScales];  // for the 5 centre planes 1..5
@@ -1066,35 +974,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
           }
         }
       }
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
-      s2 = DET_NOW();
-      s3 = s2;
-#endif
       if (!lane_valid) cand = 0;
       // border pixels are never extrema in the reference (clamped neighbour == centre)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (c0 + j < 1 || c0 + j > w - 2) cand &= ~(0x11111u << j);
-#if defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 1  // no refinement at all: what would a free refinement save?
-      if (cand == 0x000fffffu) counter[0] = 1;
-      if (false) {
-#elif defined(CUSIFT_DET_EXP) && CUSIFT_DET_EXP == 2  // no extrema analysis either (pre-test kept)
-      if (cand == 0x000fffffu) counter[0] = 1;
-      if (false) {
-#else
       if (__builtin_amdgcn_ballot_w64(cand != 0) != 0) {  // wave-uniform, rare
-#endif
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
-        had_event = true;
-#endif
 #pragma unroll 1
         for (int s = 0; s < kNumScales; ++s) {
           const unsigned int m = (cand >> (4 * s)) & 0xfu;
           if (__builtin_amdgcn_ballot_w64(m != 0) == 0) continue;  // wave-uniform
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
-          const unsigned int e0 = DET_NOW();
-          unsigned int t_ref = 0;
-#endif
           // A candidate's refinement reads 19 DoG values: the 3x3 of its own plane, and the centre with its four
           // neighbours in the planes below and above.  All of them are in the registers of the detecting lane, except
           // the column beyond its float4 (from the lane before for column 0, the lane after for column 3: five DPP
@@ -1131,14 +1020,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
                 e[20] = __builtin_bit_cast(float, ((y + rw.row0) << 3) | k);
               }
               if (cands.n >= 64) {
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
-                const unsigned int r0s = DET_NOW();
-#endif
                 cands.refine_batch(points, max_pts, counter, P, lane);
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
-                t_ref += DET_NOW() - r0s;
-                acc_shift += 1;  // batches
-#endif
               }
             };
             column(std::integral_constant<int, 0>{});
@@ -1153,46 +1035,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
             case 3: emit(std::integral_constant<int, 3>{}); break;
             default: emit(std::integral_constant<int, 4>{}); break;
           }
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS == 4
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const unsigned int e2 = DET_NOW();
-          acc_blur += 1;                   // scale-events
-          acc_ref += (e2 - e0) - t_ref;    // entries written
-          acc_fill += t_ref;               // batch refinement
-#endif
         }
       }
     }
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
-    if (yy >= ya + 1) s3 = DET_NOW();
-#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
     win[8] = fix(nxt);
-#if defined(CUSIFT_DET_STAMPS) && CUSIFT_DET_STAMPS >= 2
-    const unsigned int s4 = DET_NOW();
-#if CUSIFT_DET_STAMPS == 4
-    (void)s0, (void)s4;
-#elif CUSIFT_DET_STAMPS == 3  // split the refinement segment: rows with a candidate vs rows without
-    if (yy >= ya + 1) {
-      if (had_event) {
-        acc_blur += 1;         // number of rows with at least one candidate
-        acc_ext += s3 - s2;    // cycles of the segment on those rows
-      } else {
-        acc_ref += s3 - s2;    // ... and on the others
-      }
-    }
-    acc_shift += s4 - s3;
-#else
-    acc_blur += s1 - s0;
-    acc_ext += s2 - s1;
-    acc_ref += s3 - s2;
-    acc_shift += s4 - s3;
-#endif
-#endif
-#ifdef CUSIFT_DET_STAMPS
-    ++n_rows;
-#endif
   };
 
   for (int yy = ya - 1; yy <= yb; yy += 3) {
@@ -1203,36 +1051,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
     row_step(yy + 2, DC, DA, DB);
   }
   cands.refine_batch(points, max_pts, counter, P, lane);  // what is left of the chunk's candidates (fewer than 64)
-#ifdef CUSIFT_DET_STAMPS
-  if (lane == 0) {
-    const unsigned int slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (slot < (unsigned int)kDetLogWaves) {
-      unsigned int *o = g_det_log[slot];
-      o[0] = acc_fill, o[1] = acc_blur, o[2] = acc_ext, o[3] = acc_ref, o[4] = acc_shift;
-      o[5] = DET_NOW() - t_begin, o[6] = n_rows, o[7] = 1u;
-    }
-  }
-#endif
 }
 
-#ifdef CUSIFT_DET_STAMPS
-}  // namespace cusift
-// sums over the waves of the last launch(es) since the last reset
-extern "C" int cusift_debug_det_cycles(unsigned long long out[8], int reset) {
-  static unsigned int host[cusift::kDetLogWaves][8];
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(cusift::g_det_log), sizeof(host)) != hipSuccess) return 1;
-  for (int k = 0; k < 8; ++k) out[k] = 0;
-  for (int i = 0; i < cusift::kDetLogWaves; ++i)
-    for (int k = 0; k < 8; ++k) out[k] += host[i][k];
-  if (reset) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(cusift::g_det_log)) != hipSuccess) return 1;
-    if (hipMemset(p, 0, sizeof(host)) != hipSuccess) return 1;
-  }
-  return 0;
-}
-namespace cusift {
-#endif
 
 template __global__ void detect_fused_kernel<false>(const float *, int, int, int, long, cusift_point *, int,
                                                     unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, int, int);

@@ -1,0 +1,53 @@
+"""`python bench.py --gpus N` as a plain command: the parent must start the N ranks itself (children, before anything
+touches a GPU) and relay rank 0's line.  --dry-launch rehearses exactly that path on the CPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          timeout=300, env=e)
+
+
+def test_gpus_2_spawns_its_own_ranks_and_prints_one_line():
+    out = run_bench("--gpus", "2", "--dry-launch", "--steps", "3", "--warmup", "1")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout  # exactly ONE line on stdout: everything else went to stderr
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_launch"] is True and d["images_total"] == 128 and d["steps"] == 3
+
+
+def test_a_failing_rank_fails_the_command():
+    # --gpus 2 but the children are told a batch the dry run rejects: make a rank exit non-zero through a bad flag
+    out = run_bench("--gpus", "2", "--dry-launch", "--no-such-flag")
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_parent_never_imports_torch_or_the_extension():
+    """The spawning parent must not touch a GPU: it may not even import torch or load libcusift_amd.so."""
+    code = ("import sys, runpy\n"
+            "sys.argv = ['bench.py', '--gpus', '2', '--dry-launch']\n"
+            "import subprocess\n"
+            "real = subprocess.Popen\n"
+            "class P(real):\n"
+            "    def __init__(self, *a, **k):\n"
+            "        assert 'torch' not in sys.modules and 'cusift_amd.capi' not in sys.modules, 'parent loaded torch'\n"
+            "        print('SPAWN-OK', file=sys.stderr)\n"
+            "        super().__init__(*a, **k)\n"
+            "subprocess.Popen = P\n"
+            "runpy.run_path(%r, run_name='__main__')\n" % os.path.join(ROOT, "bench.py"))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e)
+    assert "SPAWN-OK" in out.stderr and out.returncode == 0, out.stderr[-2000:]

@@ -50,3 +50,24 @@ def test_plan_rejects_what_cannot_be_tiled():
     with pytest.raises(ValueError):
         StripPlan(64, 64, 2, 2, halo=4)
     assert StripPlan(64, 64, 1, 9).n_oct == 7  # 64 -> 1: the driver's integer halving stops at 1 px
+
+
+def test_python_plan_equals_the_c_abi_plan():
+    """cusift_tiled_plan (csrc/sift_tiled.hip: the plan the GPU ranks run) == StripPlan (the twin the gloo host-logic
+    tests run) for every rank and octave of a grid of shapes, incl. uneven strips, collapse and narrow octaves."""
+    from cusift_amd import capi
+
+    cases = [(8192, 8192, 8, 7, 48), (8192, 8192, 8, 5, 48), (1000, 1531, 3, 6, 48), (640, 300, 8, 4, 48),
+             (1024, 2048, 4, 7, 48), (512, 1024, 2, 2, 8), (64, 4096, 5, 9, 16), (4096, 3001, 7, 6, 32),
+             (256, 768, 1, 3, 48), (33, 2000, 3, 8, 48)]
+    for W, H, P, n_oct, halo in cases:
+        py = StripPlan(W, H, P, n_oct, halo)
+        for k in range(P):
+            for o in range(py.n_oct):
+                c = capi.tiled_plan(W, H, P, n_oct, halo, k, o)
+                assert (c["n_octaves"], c["collapse"]) == (py.n_oct, py.collapse), (W, H, P, n_oct)
+                assert (c["w"], c["h"], c["pitch"]) == (py.w[o], py.h[o], py.pitch[o])
+                assert (c["own_begin"], c["own_end"]) == py.own(k, o)
+                assert (c["band_begin"], c["band_end"]) == py.band(k, o), (W, H, P, k, o)
+    with pytest.raises(capi.CusiftError):
+        capi.tiled_plan(100, 3, 8, 4)  # fewer rows than ranks

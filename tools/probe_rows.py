@@ -33,7 +33,7 @@ def main():
         if stage == "find":
             capi.check(lib.cusift_laplace_multi(ctx.handle, img.ptr, w, h, p, h * p, 1.0, dog.ptr, 7 * h * p, n))
 
-        def launch():
+        def launch(ctx):
             if stage == "laplace":
                 capi.check(lib.cusift_laplace_multi(ctx.handle, img.ptr, w, h, p, h * p, 1.0, dog.ptr, 7 * h * p, n))
             elif stage == "detect":
@@ -54,13 +54,14 @@ def main():
             for r in rows_list:
                 os.environ["CUSIFT_%s_ROWS_LO" % env] = str(r)
                 os.environ["CUSIFT_%s_ROWS_HI" % env] = str(r)
-                launch()
-                ctx.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(8):
-                    launch()
-                ctx.synchronize()
-                best[r].append((time.perf_counter() - t0) / 8 * 1e3)
+                with capi.Context(0) as tuned:  # the tuning knobs are read once, when a context is created
+                    launch(tuned)
+                    tuned.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(8):
+                        launch(tuned)
+                    tuned.synchronize()
+                    best[r].append((time.perf_counter() - t0) / 8 * 1e3)
         for r in rows_list:
             v = np.array(best[r])
             print("%s %dx%dx%d rows=%-3d  median %.4f ms  min %.4f  max %.4f" % (stage, n, w, h, r, np.median(v), v.min(),
