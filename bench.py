@@ -695,6 +695,11 @@ def main():
             out["host_visible_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank, dev,
                                                        total_local_kp=local_kp)
             out["keypoints_per_s_host_visible"] = out["host_visible_leg"]["keypoints_per_s"]
+            # the optional 160-byte wire record (exact header fields, 8-bit descriptor with one step per record):
+            # D2H no longer bounds the step; the exact 588-byte path above stays the default
+            out["host_visible_compact_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank,
+                                                               dev, total_local_kp=local_kp, compact=True)
+            out["keypoints_per_s_host_visible_compact"] = out["host_visible_compact_leg"]["keypoints_per_s"]
             ex.params.concurrent_batches = 1
 
         # ---- content legs ----
@@ -826,7 +831,7 @@ def match_leg(capi, ctx, n):
             "self_match_ok": ok}
 
 
-def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp):
+def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact=False):
     """Steps as in the timed region, but each step's SiftData is packed on the device (pack stream) and copied to pinned
     host memory (copy stream) while the next steps are extracted; the region ends when the last record is on the host.
     The copy size is a host argument, so a step's counts travel first (4 bytes x images) and its records one step
@@ -836,10 +841,11 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     cctx = capi.Context(device_index, stream=pack_stream.cuda_stream)
     cap = int(max(1.5 * total_local_kp, 4096))  # records per step the staging buffers hold
     depth = 4
-    packed = [torch.empty((cap, capi.SIFT_POINT_BYTES), dtype=torch.uint8, device=dev) for _ in range(depth)]
+    rec_bytes = capi.COMPACT_POINT_BYTES if compact else capi.SIFT_POINT_BYTES
+    packed = [torch.empty((cap, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]
     offs = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
     h_offs = [torch.zeros(B + 1, dtype=torch.int32).pin_memory() for _ in range(depth)]
-    h_rec = [torch.empty((cap, capi.SIFT_POINT_BYTES), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+    h_rec = [torch.empty((cap, rec_bytes), dtype=torch.uint8).pin_memory() for _ in range(depth)]
     ev_counts = [torch.cuda.Event() for _ in range(depth)]
     ev_copied = [None] * depth  # staging buffer j may be packed into again after this
     ev_slot = {}
@@ -857,7 +863,7 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
             ev_copied[j] = torch.cuda.Event()
             ev_copied[j].record(copy_stream)
         got["records"] += total
-        got["bytes"] += total * capi.SIFT_POINT_BYTES + 4 * (B + 1)
+        got["bytes"] += total * rec_bytes + 4 * (B + 1)
 
     def one(i):
         j = i % depth
@@ -867,7 +873,8 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
             pack_stream.wait_event(ev)
             if ev_copied[j] is not None:
                 pack_stream.wait_event(ev_copied[j])
-            cctx.pack_points(pts.data_ptr(), cnt.data_ptr(), B, max_pts, packed[j].data_ptr(), cap, offs[j].data_ptr())
+            (cctx.pack_points_compact if compact else cctx.pack_points)(
+                pts.data_ptr(), cnt.data_ptr(), B, max_pts, packed[j].data_ptr(), cap, offs[j].data_ptr())
             done = torch.cuda.Event()
             done.record(pack_stream)  # the slot's records have been packed: the slot may be overwritten
             h_offs[j].copy_(offs[j], non_blocking=True)
@@ -891,11 +898,12 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # spot check: the last step's host records are real (first record of image 0 has a finite, in-range location)
-    rec = h_rec[(K - 1) % depth][:1].numpy().view(capi.SIFT_POINT_DTYPE)
+    rec = h_rec[(K - 1) % depth][:1].numpy().view(capi.COMPACT_POINT_DTYPE if compact else capi.SIFT_POINT_DTYPE)
     assert np.isfinite(rec["coords2D"]).all() and rec["subsampling"][0] >= 1.0
     cctx.close()
     return {"ms_per_step": round(dt / K * 1e3, 4), "keypoints_per_s": round(got["records"] / dt, 1),
             "d2h_GBps": round(got["bytes"] / dt / 1e9, 2), "d2h_bytes_per_step": int(got["bytes"] / K),
+            "record_bytes": rec_bytes,
             "note": "device-resident input -> SiftData records in pinned host memory (packed on the device, copied on "
                     "a copy stream, overlapped with the following steps); bounded by the D2H copy when d2h_bytes_per_step "
                     "/ PCIe rate exceeds the extraction time"}

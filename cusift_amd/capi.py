@@ -39,6 +39,12 @@ SIFT_POINT_DTYPE = np.dtype(
 SIFT_POINT_BYTES = 588
 assert SIFT_POINT_DTYPE.itemsize == SIFT_POINT_BYTES
 
+# cusift_compact_point (include/cusift_amd.h): the optional 160-byte wire record
+COMPACT_POINT_DTYPE = np.dtype([("coords2D", "<f4", (2,)), ("scale", "<f4"), ("sharpness", "<f4"), ("edgeness", "<f4"),
+                                ("orientation", "<f4"), ("subsampling", "<f4"), ("desc_step", "<f4"), ("q", "u1", (128,))])
+COMPACT_POINT_BYTES = 160
+assert COMPACT_POINT_DTYPE.itemsize == COMPACT_POINT_BYTES
+
 
 class Params(C.Structure):
     """cusift_params (include/cusift_amd.h); the public parameter fields of SiftData, cuSIFT.h:44-51."""
@@ -142,6 +148,8 @@ SIGNATURES = {
     "cusift_memcpy2d_d2h": (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "cusift_find_homography": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, C.POINTER(_i), _vp, _vp]),
     "cusift_pack_points": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "cusift_pack_points_compact": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "cusift_expand_points_host": (_i, [_vp, _sz, _vp]),
     "cusift_sort_points_host": (_i, [_vp, _i]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
     "cusift_graph_create": (_i, [_vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
@@ -398,6 +406,10 @@ class Context:
                                        d_offsets))
 
     # ---- matcher ----
+    def pack_points_compact(self, d_points, d_counters, n_images, max_pts, d_packed, capacity, d_offsets=None):
+        check(lib().cusift_pack_points_compact(self.handle, d_points, d_counters, n_images, max_pts, d_packed, capacity,
+                                               d_offsets))
+
     def match(self, d_sift1, n1, d_sift2, n2, distance=1):
         """MatchSiftData on device records: distance 1 = L2 (2 - 2 x.y), 0 = dot product."""
         check(lib().cusift_match(self.handle, d_sift1, n1, d_sift2, n2, distance))
@@ -691,6 +703,15 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def expand_points(compact):
+    """cusift_expand_points_host: COMPACT_POINT_DTYPE array -> SIFT_POINT_DTYPE array (host)."""
+    compact = np.ascontiguousarray(compact)
+    assert compact.dtype == COMPACT_POINT_DTYPE
+    out = np.zeros(len(compact), dtype=SIFT_POINT_DTYPE)
+    check(lib().cusift_expand_points_host(compact.ctypes.data, len(compact), out.ctypes.data))
+    return out
 
 
 def sort_points(points):

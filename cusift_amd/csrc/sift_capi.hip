@@ -49,6 +49,8 @@ __global__ void gaussian3x3_kernel(float *, int, long, const float *, int, int, 
 __global__ void math_eval_kernel(int, const float *, const float *, float *, float *, long);
 __global__ void pack_points_kernel(const cusift_point *, const unsigned int *, int, int, cusift_point *, unsigned int,
                                    unsigned int *);
+__global__ void pack_points_compact_kernel(const cusift_point *, const unsigned int *, int, int, cusift_compact_point *,
+                                           unsigned int, unsigned int *);
 }  // namespace cusift
 
 using namespace cusift;
@@ -1192,6 +1194,41 @@ extern "C" int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points,
   hipLaunchKernelGGL(pack_points_kernel, grid, dim3(64), 0, ctx->stream, d_points, d_counters, n_images, max_pts,
                      d_packed, (unsigned int)cap, d_offsets);
   return check_launch("pack_points");
+}
+
+static_assert(sizeof(cusift_compact_point) == 160, "the compact wire record is 160 bytes");
+
+extern "C" int cusift_pack_points_compact(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
+                                          int n_images, int max_pts, cusift_compact_point *d_packed, size_t capacity,
+                                          unsigned int *d_offsets) {
+  TRY(enter(ctx));
+  if (!d_points || !d_counters || !d_packed) return fail(CUSIFT_ERR_INVALID, "pack (compact): missing data");
+  if (n_images < 1 || n_images > kMaxFlatImages || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "pack (compact): n_images must be in [1, %d]", kMaxFlatImages);
+  const size_t cap = std::min(capacity, (size_t)0xffffffffu);
+  dim3 grid((unsigned int)std::max<size_t>(1, std::min<size_t>(std::max<size_t>(cap, 1), 256 * 32)));
+  hipLaunchKernelGGL(pack_points_compact_kernel, grid, dim3(64), 0, ctx->stream, d_points, d_counters, n_images, max_pts,
+                     d_packed, (unsigned int)cap, d_offsets);
+  return check_launch("pack_points_compact");
+}
+
+extern "C" int cusift_expand_points_host(const cusift_compact_point *h_compact, size_t n, cusift_point *h_points) {
+  if (n == 0) return CUSIFT_OK;
+  if (!h_compact || !h_points) return fail(CUSIFT_ERR_INVALID, "expand: NULL argument");
+  for (size_t i = 0; i < n; ++i) {
+    const cusift_compact_point &c = h_compact[i];
+    cusift_point &p = h_points[i];
+    memset(&p, 0, sizeof(p));
+    p.coords2D[0] = c.coords2D[0];
+    p.coords2D[1] = c.coords2D[1];
+    p.scale = c.scale;
+    p.sharpness = c.sharpness;
+    p.edgeness = c.edgeness;
+    p.orientation = c.orientation;
+    p.subsampling = c.subsampling;
+    for (int k = 0; k < 128; ++k) p.data[k] = (float)c.q[k] * c.desc_step;
+  }
+  return CUSIFT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -942,6 +942,83 @@ __global__ void __launch_bounds__(64) pack_points_kernel(const cusift_point *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compact wire format of extracted SiftData (new: the reference copies whole 588-byte records, cuSIFT.cu:52-59).
+// Same walk as pack_points_kernel, but a record leaves as a cusift_compact_point (160 B): the seven fields extraction
+// writes, exactly, and the descriptor as 128 bytes with one step per record -- q[i] = min(255, floor(data[i] / step +
+// 0.5)), step = max(data) / 255 (IEEE operations, so a host restatement gives the same bytes).  A descriptor that is
+// not finite and positive somewhere (flat patch: NaN) travels as step = its maximum as computed (NaN or 0), q = 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) pack_points_compact_kernel(const cusift_point *__restrict__ points,
+                                                                const unsigned int *__restrict__ counters,
+                                                                int n_images, int max_pts,
+                                                                cusift_compact_point *__restrict__ packed,
+                                                                unsigned int capacity,
+                                                                unsigned int *__restrict__ offsets) {
+  __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_images; i += 64) {
+    const unsigned int c = counters[i];
+    s_prefix[i + 1] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
+  }
+  wave_sync();
+  if (lane == 0) {
+    unsigned int acc = 0;
+    s_prefix[0] = 0;
+    for (int i = 1; i <= n_images; ++i) {
+      acc += s_prefix[i];
+      s_prefix[i] = acc;
+    }
+  }
+  wave_sync();
+  if (blockIdx.x == 0 && offsets)
+    for (int i = lane; i <= n_images; i += 64) offsets[i] = s_prefix[i];
+  const unsigned int total = min(s_prefix[n_images], capacity);
+  for (unsigned int g = blockIdx.x; g < total; g += gridDim.x) {
+    int lo = 0, hi_ = n_images;
+    while (hi_ - lo > 1) {
+      const int mid = (lo + hi_) >> 1;
+      if (s_prefix[mid] <= g) lo = mid; else hi_ = mid;
+    }
+    const cusift_point *src = points + (long)lo * max_pts + (g - s_prefix[lo]);
+    cusift_compact_point *dst = packed + g;
+    const float d0 = src->data[lane], d1 = src->data[lane + 64];
+    // maximum over the 128 elements; a NaN anywhere makes it NaN (fmaxf would drop it)
+    float m = (d0 > d1 || d0 != d0) ? d0 : d1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float o = __shfl_xor(m, off);
+      m = (m > o || m != m) ? m : o;
+    }
+    const bool ok = m > 0.0f && m < __builtin_inff();
+    const float step = ok ? m / 255.0f : m;
+    unsigned int q0 = 0, q1 = 0;
+    if (ok) {
+      q0 = (unsigned int)fminf(fmaxf(floorf(d0 / step + 0.5f), 0.0f), 255.0f);
+      q1 = (unsigned int)fminf(fmaxf(floorf(d1 / step + 0.5f), 0.0f), 255.0f);
+    }
+    // word k of q[] = elements 4k .. 4k+3: from lanes 4k.. (first half) or 4(k-16).. (second half)
+    const int k = lane & 31, base = 4 * (k & 15);
+    unsigned int word = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int a = (unsigned int)__shfl((int)q0, base + j), b = (unsigned int)__shfl((int)q1, base + j);
+      word |= ((k < 16) ? a : b) << (8 * j);
+    }
+    if (lane < 32) reinterpret_cast<unsigned int *>(dst->q)[k] = word;
+    if (lane == 0) {
+      dst->coords2D[0] = src->coords2D[0];
+      dst->coords2D[1] = src->coords2D[1];
+      dst->scale = src->scale;
+      dst->sharpness = src->sharpness;
+      dst->edgeness = src->edgeness;
+      dst->orientation = src->orientation;
+      dst->subsampling = src->subsampling;
+      dst->desc_step = step;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The written-out transcendental functions of sift_math.h evaluated on the device, array form (cusift_math_eval):
 // lets a test compare the device's results with the host's bit for bit.  op 0 expf(a), 1 exp2f(a), 2 atan2f(a, b),
 // 3 sincosf(a) -> (out, out2).

@@ -261,6 +261,32 @@ int cusift_find_homography(cusift_ctx *ctx, const cusift_point *d_sift, int num_
 int cusift_pack_points(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters, int n_images,
                        int max_pts, cusift_point *d_packed, size_t capacity, unsigned int *d_offsets);
 
+/* Compact wire format for SiftData that has to cross PCIe or a network (new; optional -- the exact 588-byte records
+ * stay the default everywhere).  Extraction writes 7 header fields + the 128-float descriptor of a record; the other 12
+ * floats are left as they were (SURVEY: cuSIFT.cu:24,29).  A compact record carries the 7 fields EXACTLY and the
+ * descriptor as 128 bytes with one quantisation step per record: data[i] ~= q[i] * desc_step, desc_step =
+ * max(data) / 255, q[i] = min(255, floor(data[i] / desc_step + 0.5)) -- 160 B instead of 588, |error| <= desc_step / 2
+ * per element (<= 1e-3 for a SIFT descriptor, whose elements are <= ~0.5: an L2 distance of a few 1e-3, NOT within the
+ * 1e-4 parity bar, which is why this is a wire format and not the SiftData).  A descriptor without a finite positive
+ * maximum (flat patch: NaN) travels as desc_step = that maximum (NaN or 0) and q = 0.
+ * cusift_pack_points_compact: as cusift_pack_points, compacting on the way (d_packed holds `capacity` compact records).
+ * cusift_expand_points_host: compact records -> SiftPoint records on the host (data[i] = q[i] * desc_step; a NaN step
+ *   gives the NaN descriptor back; the 12 fields extraction never writes are zeroed). */
+typedef struct cusift_compact_point {
+  float coords2D[2];
+  float scale;
+  float sharpness;
+  float edgeness;
+  float orientation;
+  float subsampling;
+  float desc_step;
+  unsigned char q[128];
+} cusift_compact_point; /* 160 bytes */
+int cusift_pack_points_compact(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
+                               int n_images, int max_pts, cusift_compact_point *d_packed, size_t capacity,
+                               unsigned int *d_offsets);
+int cusift_expand_points_host(const cusift_compact_point *h_compact, size_t n, cusift_point *h_points);
+
 /* Canonical order of extracted records, on the HOST copy: octave blocks coarsest first (as emitted), inside an octave
  * by y, x, scale.  The append order inside an octave is that of an atomic counter -- racy in the reference as well
  * (atomicInc, cuSIFT_D.cu:512) -- so callers that need run-to-run identical arrays, not just identical sets, sort. */
