@@ -262,6 +262,9 @@ def main():
                          "the launch tails of one batch overlap the VALU-bound kernels of the next")
     ap.add_argument("--gather-capacity", type=int, default=8192,
                     help="N > 1: records per image the gathered SiftData buffer is sized for")
+    ap.add_argument("--gather-compact", action="store_true",
+                    help="N > 1: exchange 160-byte compact records (exact header fields, 8-bit descriptor) instead of the "
+                         "exact 588-byte SiftPoint records -- NOT the default: the metric is the all-gatherv of SiftData")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gatherv of SiftData even with one rank (self send/recv: exercises the RCCL path "
                          "on one GPU)")
@@ -359,7 +362,7 @@ def main():
             side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
             comm = make_comm(side_ctx, self_p2p=(world == 1))
             gatherer = SiftGatherer(comm, B, args.max_pts, region_cap=region_cap, device=dev, n_out=LAG + 2,
-                                    depth=LAG + 1)
+                                    depth=LAG + 1, compact=args.gather_compact)
         except Exception as e:  # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
@@ -501,6 +504,7 @@ def main():
             out["config"]["gather_impl"] = gather_impl
             out["config"]["rccl_library"] = capi.Comm.library()
             out["config"]["gather_region_records"] = region_cap
+            out["config"]["gather_record_bytes"] = 160 if (args.gather_compact and gatherer is not None) else 588
             if comm is not None:
                 out["config"]["gather_host_waits"] = comm.host_waits()
 

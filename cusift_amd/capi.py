@@ -94,6 +94,7 @@ SIGNATURES = {
     "cusift_comm_ctx": (_vp, [_vp]),
     "cusift_comm_reserve": (_i, [_vp, _i, _i, _sz]),
     "cusift_comm_set_fixed_size": (_i, [_vp, _i]),
+    "cusift_comm_set_wire_format": (_i, [_vp, _i]),
     "cusift_comm_host_waits": (C.c_ulonglong, [_vp]),
     "cusift_allgatherv_begin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz]),
     "cusift_allgatherv_finish": (_i, [_vp, _vp, _vp]),
@@ -509,6 +510,9 @@ class Comm:
 
     def set_fixed_size(self, on=True):
         check(lib().cusift_comm_set_fixed_size(self._h, 1 if on else 0))
+
+    def set_wire_format(self, compact=True):
+        check(lib().cusift_comm_set_wire_format(self._h, 1 if compact else 0))
 
     def host_waits(self):
         return int(lib().cusift_comm_host_waits(self._h))

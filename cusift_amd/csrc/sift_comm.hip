@@ -143,7 +143,7 @@ int load_rccl(Rccl **out) {
 }
 
 static_assert(CUSIFT_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "cusift_comm ids are ncclUniqueId");
-static_assert(sizeof(cusift_point) % 4 == 0, "records travel as 32-bit words");
+static_assert(sizeof(cusift_point) % 4 == 0 && sizeof(cusift_compact_point) % 4 == 0, "records travel as 32-bit words");
 constexpr size_t kWordsPerPoint = sizeof(cusift_point) / 4;  // 147
 constexpr int kSeqWords = 32;  // a ticket's arrival flag sits on a 128-byte line of its own
 
@@ -181,8 +181,9 @@ struct GatherTicket {
   unsigned int *h_seq = nullptr;    // pinned; == seq once h_all is complete
   unsigned int *dev_h_all = nullptr, *dev_h_seq = nullptr;  // the device's addresses of the two pinned blocks
   unsigned int seq = 0;
-  cusift_point *d_gathered = nullptr;
-  size_t region_cap = 0;
+  char *d_gathered = nullptr;
+  size_t region_cap = 0;   // records per region
+  size_t rec_bytes = 0;    // 588 (cusift_point) or 160 (cusift_compact_point)
   int slots = 0;  // count slots per rank of THIS exchange (<= comm n_slots)
 };
 
@@ -194,6 +195,7 @@ struct cusift_comm {
   ncclComm_t nccl = nullptr;
   int self_p2p = 0;  // world 1 / tests: route the local shard through ncclSend/ncclRecv to self as well
   int fixed = 0;     // 1: whole regions travel (region_cap records per peer), posted by begin(); no host read at all
+  int compact = 0;   // 1: records travel as cusift_compact_point (160 B) instead of cusift_point (588 B)
   // ring of tickets: [head, head + pending) are in flight, oldest first
   int n_slots = 0, depth = 0, head = 0, pending = 0;
   unsigned int next_seq = 1;
@@ -296,15 +298,16 @@ int post_shards(cusift_comm *c, const GatherTicket &k, const size_t *n_records) 
   const int first = c->self_p2p ? 0 : 1;
   if (first >= W) return CUSIFT_OK;
   const size_t mine = n_records[c->rank];
-  const cusift_point *src = c->self_p2p ? c->d_stage : k.d_gathered + (size_t)c->rank * k.region_cap;
+  const size_t words = k.rec_bytes / 4, region_bytes = k.region_cap * k.rec_bytes;
+  const char *src = c->self_p2p ? (const char *)c->d_stage : k.d_gathered + (size_t)c->rank * region_bytes;
   GroupScope g(c->lib);
   NCCL_TRY(c, g.start());
   for (int step = first; step < W; ++step) {
     const int to = (c->rank + step) % W, from = (c->rank - step + W) % W;
-    if (mine > 0) NCCL_TRY(c, c->lib->Send(src, mine * kWordsPerPoint, ncclUint32, to, c->nccl, c->stream));
+    if (mine > 0) NCCL_TRY(c, c->lib->Send(src, mine * words, ncclUint32, to, c->nccl, c->stream));
     if (n_records[from] > 0)
-      NCCL_TRY(c, c->lib->Recv(k.d_gathered + (size_t)from * k.region_cap, n_records[from] * kWordsPerPoint, ncclUint32,
-                               from, c->nccl, c->stream));
+      NCCL_TRY(c, c->lib->Recv(k.d_gathered + (size_t)from * region_bytes, n_records[from] * words, ncclUint32, from,
+                               c->nccl, c->stream));
   }
   NCCL_TRY(c, g.end());
   return CUSIFT_OK;
@@ -393,6 +396,13 @@ extern "C" int cusift_comm_set_fixed_size(cusift_comm *c, int on) {
   return CUSIFT_OK;
 }
 
+extern "C" int cusift_comm_set_wire_format(cusift_comm *c, int compact) {
+  if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
+  if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: exchanges in flight");
+  c->compact = compact != 0;
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_comm_reserve(cusift_comm *c, int n_images_max, int tickets, size_t stage_records) {
   TRY(comm_enter(c));
   if (n_images_max < 1 || n_images_max > cusift::kMaxFlatImages || tickets < 1 || tickets > 64)
@@ -417,7 +427,7 @@ extern "C" const char *cusift_comm_library(void) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, const cusift_point *d_points,
                                        const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
-                                       cusift_point *d_gathered, size_t region_cap) {
+                                       void *d_gathered, size_t region_cap) {
   TRY(comm_enter(c));
   if ((n_images > 0 && (!d_points || !d_counters)) || !d_gathered)
     return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: missing data");
@@ -439,7 +449,8 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
   if (producer) TRY(cusift_ctx_wait(c->ctx, producer));
   GatherTicket &k = c->tickets[(c->head + c->pending) % c->depth];
   k.seq = c->next_seq++;
-  k.d_gathered = d_gathered;
+  k.rec_bytes = c->compact ? sizeof(cusift_compact_point) : sizeof(cusift_point);
+  k.d_gathered = (char *)d_gathered;
   k.region_cap = region_cap;
   k.slots = n_images_max;
   hipLaunchKernelGGL(clamp_counts_kernel, dim3((n_images_max + 255) / 256), dim3(256), 0, c->stream, d_counters,
@@ -447,9 +458,14 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
   HIP_TRY(hipGetLastError());
   // the local shard is packed straight into its region of the gathered buffer and sent from there: once this has run
   // the caller's d_points / d_counters are free again
-  if (n_images > 0)
-    TRY(cusift_pack_points(c->ctx, d_points, d_counters, n_images, max_pts,
-                           c->self_p2p ? c->d_stage : d_gathered + (size_t)c->rank * region_cap, region_cap, nullptr));
+  if (n_images > 0) {
+    char *dst = c->self_p2p ? (char *)c->d_stage : k.d_gathered + (size_t)c->rank * region_cap * k.rec_bytes;
+    if (c->compact)
+      TRY(cusift_pack_points_compact(c->ctx, d_points, d_counters, n_images, max_pts, (cusift_compact_point *)dst,
+                                     region_cap, nullptr));
+    else
+      TRY(cusift_pack_points(c->ctx, d_points, d_counters, n_images, max_pts, (cusift_point *)dst, region_cap, nullptr));
+  }
   NCCL_TRY(c, c->lib->AllGather(k.d_local, k.d_all, (size_t)n_images_max, ncclUint32, c->nccl, c->stream));
   hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, c->stream, k.d_all, n_images_max * c->world,
                      k.dev_h_all, k.dev_h_seq, k.seq);
@@ -507,7 +523,7 @@ extern "C" int cusift_allgatherv_finish(cusift_comm *c, unsigned int *h_counts, 
 
 extern "C" int cusift_allgatherv(cusift_comm *c, cusift_ctx *producer, const cusift_point *d_points,
                                  const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
-                                 cusift_point *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals) {
+                                 void *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals) {
   TRY(cusift_allgatherv_begin(c, producer, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered,
                               region_cap));
   return cusift_allgatherv_finish(c, h_counts, h_totals);

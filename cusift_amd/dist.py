@@ -50,17 +50,22 @@ class SiftGatherer:
     `gathered` is a [world, region_cap, 588] uint8 view of an internal ring buffer (n_out deep, n_out >= depth), valid
     until n_out begins later; rank r's records are gathered[r, :totals[r]] in image order (`regions()` lists them).
     `region_cap` = records one rank's region holds (default: the worst case n_images_max * max_pts).
+    `compact=True`: the records travel and arrive as 160-byte cusift_compact_point (capi.COMPACT_POINT_DTYPE; exact
+    header fields, 8-bit descriptor) -- `gathered` is then [world, region_cap, 160].
     The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: order
     the producer's next write after it with `producer_ctx.wait(comm.ctx)` (no host wait), or synchronise."""
 
-    def __init__(self, comm, n_images_max, max_pts, region_cap=None, device=None, n_out=2, depth=1, fixed_size=False):
+    def __init__(self, comm, n_images_max, max_pts, region_cap=None, device=None, n_out=2, depth=1, fixed_size=False,
+                 compact=False):
         self.comm, self.n_max, self.max_pts = comm, int(n_images_max), int(max_pts)
         self.region_cap = int(region_cap) if region_cap else self.n_max * self.max_pts
         self.device = torch.device("cuda", comm.ctx.device) if device is None else torch.device(device)
         self.depth = max(1, int(depth))
         n_out = max(int(n_out), self.depth)
-        self.out = [torch.empty((comm.world, self.region_cap, SIFT_POINT_BYTES), dtype=torch.uint8, device=self.device)
+        self.record_bytes = capi.COMPACT_POINT_BYTES if compact else SIFT_POINT_BYTES
+        self.out = [torch.empty((comm.world, self.region_cap, self.record_bytes), dtype=torch.uint8, device=self.device)
                     for _ in range(n_out)]
+        comm.set_wire_format(compact)
         comm.reserve(self.n_max, self.depth, self.region_cap)
         if fixed_size:
             comm.set_fixed_size(True)

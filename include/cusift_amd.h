@@ -323,12 +323,18 @@ int cusift_comm_reserve(cusift_comm *comm, int n_images_max, int tickets, size_t
  * valid records.  1: whole regions travel (region_cap records per peer whatever the counts), posted by begin(): the
  * exchange needs no host read at all, at the price of the bytes; for small capacities (a tiled image's merge). */
 int cusift_comm_set_fixed_size(cusift_comm *comm, int on);
-/* Diagnostic: how many finish() calls found their counts not yet arrived and had to wait (0 in a pipelined loop). */
+/* 0 (default): the gathered records are cusift_point (588 B, exact).  1: they travel -- and arrive -- as
+ * cusift_compact_point (160 B: exact header fields, 8-bit descriptor; see cusift_pack_points_compact): 3.7x fewer bytes
+ * over xGMI when the exchange, not the extraction, bounds a step.  d_gathered then holds world * region_cap compact
+ * records. */
+int cusift_comm_set_wire_format(cusift_comm *comm, int compact);
+/* Diagnostic: how many finish() calls found their counts not yet there, i.e. the host was ahead of the GPU (in a
+ * GPU-bound pipelined loop that is the normal case and costs nothing: the device has the caller's other steps queued). */
 unsigned long long cusift_comm_host_waits(cusift_comm *comm);
 
 /* All-gatherv of SiftData: every rank ends up with the valid records of ALL ranks' images.  d_gathered is `world`
- * REGIONS of region_cap records; region r holds rank r's records packed back to back in image order (h_totals[r] of
- * them).  Fixed region starts are what lets a rank pack its shard into place before anybody's counts are known.
+ * REGIONS of region_cap records (cusift_point, or cusift_compact_point after cusift_comm_set_wire_format(comm, 1));
+ * region r holds rank r's records packed back to back in image order (h_totals[r] of them).  Fixed region starts are what lets a rank pack its shard into place before anybody's counts are known.
  *   begin  (asynchronous, no host wait): orders the exchange after everything enqueued on `producer` so far (the
  *          context that extracted d_points; NULL: the caller has ordered the streams), clamps the per-image counters on
  *          the device, packs the local shard straight into region `rank` of d_gathered -- after which d_points /
@@ -345,11 +351,11 @@ unsigned long long cusift_comm_host_waits(cusift_comm *comm);
  * asynchronous device copies on ctx's stream), for consumers that want one list. */
 int cusift_allgatherv_begin(cusift_comm *comm, cusift_ctx *producer, const cusift_point *d_points,
                             const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
-                            cusift_point *d_gathered, size_t region_cap);
+                            void *d_gathered, size_t region_cap);
 int cusift_allgatherv_finish(cusift_comm *comm, unsigned int *h_counts, size_t *h_totals);
 int cusift_allgatherv(cusift_comm *comm, cusift_ctx *producer, const cusift_point *d_points,
                       const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
-                      cusift_point *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals);
+                      void *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals);
 int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_gathered, size_t region_cap, int world,
                             const size_t *h_totals, cusift_point *d_out, size_t capacity);
 
