@@ -47,21 +47,21 @@ def main():
         ext = StripExtractor(rank, world, W, H, prm, device=dev, comm=comm)
         b = ext.plan.bounds
         strip = torch.from_numpy(img[b[rank]:b[rank + 1]]).to(dev)
-        gat = SiftGatherer(comm, 1, ext.max_pts, capacity=ext.max_pts, device=dev)
+        gat = SiftGatherer(comm, 1, ext.max_pts, region_cap=ext.max_pts, device=dev)
         for it in range(steps + 2):
             if it == 2:
                 dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             pts, cnt = run_distributed(ext, strip)
-            ac, ga, off = gat.gather(pts, cnt)
+            ac, ga, totals = gat.gather(pts, cnt)
         ext.check()
         dist.barrier()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         if rank == 0:
             out.update({"n_gpus": world, "ms_per_image": round(dt * 1e3, 3), "Mpix_per_s": round(W * H / dt / 1e6, 1),
-                        "keypoints": int(off[-1]), "collapse_octave": ext.plan.collapse,
+                        "keypoints": int(sum(int(t) for t in totals)), "collapse_octave": ext.plan.collapse,
                         "mode": "distributed strips + halo exchange + all-gatherv (C ABI over RCCL)"})
             print(json.dumps(out), flush=True)
         comm.close()
