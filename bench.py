@@ -268,6 +268,9 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gatherv of SiftData even with one rank (self send/recv: exercises the RCCL path "
                          "on one GPU)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="under rocprofv3 (tools/profile_gpu.sh): skip the sub-legs that launch a kernel outside the "
+                         "5-octave cycle, so that per-launch PMC averages are over whole steps")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the launch only: ranks rendezvous over gloo on the CPU, shard the batch, barrier, "
                          "reduce a time and rank 0 prints a line -- no GPU, no extraction (tests the --gpus N spawn)")
@@ -659,6 +662,8 @@ def main():
                 # the octave-0 launch on its own (3/4 of the bytes): the same kernel through the stage entry point,
                 # DoG planes of the whole batch in a buffer of their own
                 try:
+                    if args.profile_run:
+                        raise RuntimeError("skipped (--profile-run)")
                     dog0 = torch.empty((B, 7, h, ex.pitch), dtype=torch.float32, device=dev)
                     ex.ctx.timing_enable(True)
                     for rep in range(2 + max(3, K // 2)):

@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp 2>/dev/null && cd - >/dev/null
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 5 --warmup 2 --legs single,two_stage $*"
+BENCH_ARGS="--steps 5 --warmup 2 --legs single,two_stage --profile-run $*"
 echo "bench args: $BENCH_ARGS" > "$OUT/command.txt"
 python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/trace.log" 2>&1
@@ -17,5 +17,6 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq2.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$OUT/pmc_lds" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_lds.log" 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_tcc.log" 2>&1
 du -sh "$OUT"

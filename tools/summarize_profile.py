@@ -118,10 +118,11 @@ def main():
             out_json[kern]["launches_profiled"] = n
             lines.append("%s: mean HBM traffic per launch over all %d profiled launches (all octaves) = %.1f MB"
                          % (kern, n, per_launch / 1e6))
-    # VALU issue: wave-instructions per launch and the busy fraction of the vector pipes, per kernel (all launches)
-    valu_json = {"_source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... / GRBM_GUI_ACTIVE (separate passes, "
-                            "--kernel-trace only) of `python3 bench.py --steps 5 --warmup 2 --legs single,two_stage`; "
-                            "valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8); see tools/profile_gpu.sh"}
+    # VALU issue: wave-instructions per launch, per kernel (all launches).  (Rounds 1-2 also derived a "busy fraction"
+    # SQ_ACTIVE_INST_VALU * 4 / SIMD-cycles: it exceeds 1 for the keypoint kernel -- not an occupancy of anything -- and is
+    # gone; bench.py prints a mix-weighted issue bound instead, profiles/isa_mix.json.)
+    valu_json = {"_source": "rocprofv3 --pmc SQ_INSTS_VALU ... (separate passes, --kernel-trace only) of `python3 bench.py "
+                            "--steps 5 --warmup 2 --legs single,two_stage --profile-run`; see tools/profile_gpu.sh"}
     lines.append("")
     for kern in ("detect_fused_kernel", "describe_all_kernel", "laplace_multi_fast_kernel", "find_points_fast_kernel",
                  "scale_down_fast_kernel"):
@@ -130,15 +131,14 @@ def main():
             continue
         insts = sum(pk["SQ_INSTS_VALU"]) / len(pk["SQ_INSTS_VALU"])
         entry = {"valu_wave_insts_per_launch": insts, "launches_profiled": len(pk["SQ_INSTS_VALU"])}
-        if "SQ_ACTIVE_INST_VALU" in pk and "GRBM_GUI_ACTIVE" in pk:
-            act = sum(pk["SQ_ACTIVE_INST_VALU"]) / len(pk["SQ_ACTIVE_INST_VALU"])
+        if "SQ_LDS_IDX_ACTIVE" in pk and "GRBM_GUI_ACTIVE" in pk:  # only when tools/pmc_lds.sh passes are present
             gui = sum(pk["GRBM_GUI_ACTIVE"]) / len(pk["GRBM_GUI_ACTIVE"])
-            entry["valu_busy"] = round(act * 4.0 / (1024.0 * gui / 8.0), 4)
+            entry["lds_busy"] = round(sum(pk["SQ_LDS_IDX_ACTIVE"]) / len(pk["SQ_LDS_IDX_ACTIVE"]) / (256.0 * gui / 8.0), 4)
         if "SQ_WAVES" in pk:
             entry["waves_per_launch"] = sum(pk["SQ_WAVES"]) / len(pk["SQ_WAVES"])
         valu_json[kern] = entry
-        lines.append("%s: %.4g VALU wave-instructions per launch (mean of %d launches), vector pipes busy %s"
-                     % (kern, insts, entry["launches_profiled"], entry.get("valu_busy")))
+        lines.append("%s: %.4g VALU wave-instructions per launch (mean of %d launches)"
+                     % (kern, insts, entry["launches_profiled"]))
     with open(os.path.join(os.path.dirname(dst) or ".", "valu.json"), "w") as f:
         json.dump(valu_json, f, indent=1)
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
