@@ -849,7 +849,10 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     pack_stream, copy_stream = torch.cuda.Stream(), torch.cuda.Stream()
     cctx = capi.Context(device_index, stream=pack_stream.cuda_stream)
     cap = int(max(1.5 * total_local_kp, 4096))  # records per step the staging buffers hold
-    depth = 4
+    # staging slots: a step's records leave depth - 2 steps after it was enqueued.  The exact records are bound by the
+    # copy itself (99 MB per step over PCIe); the compact ones are not, and need the host to stay further ahead than the
+    # 4-stream extraction pipeline is deep
+    depth = 8 if compact else 4
     rec_bytes = capi.COMPACT_POINT_BYTES if compact else capi.SIFT_POINT_BYTES
     packed = [torch.empty((cap, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]
     offs = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(depth)]

@@ -959,47 +959,45 @@ __global__ void __launch_bounds__(64) pack_points_compact_kernel(const cusift_po
   if (blockIdx.x == 0 && offsets)
     for (int i = lane; i <= n_images; i += 64) offsets[i] = s_prefix[i];
   const unsigned int total = min(s_prefix[n_images], capacity);
-  for (unsigned int g = blockIdx.x; g < total; g += gridDim.x) {
+  // TWO records per wave, one per half-wave: lane l of a half holds elements 4l .. 4l+3 of the descriptor (one 16-byte
+  // load), so its four bytes are one 32-bit store and no value has to change lanes -- only the maximum does (DPP).
+  const int half = lane >> 5, l = lane & 31;
+  for (unsigned int g0 = 2u * blockIdx.x; g0 < total; g0 += 2u * gridDim.x) {
+    const unsigned int g = g0 + (unsigned int)half;
+    const bool live = g < total;
     int lo = 0, hi_ = n_images;
+    const unsigned int gs = live ? g : g0;  // the idle half of the last pair repeats its neighbour's search
     while (hi_ - lo > 1) {
       const int mid = (lo + hi_) >> 1;
-      if (s_prefix[mid] <= g) lo = mid; else hi_ = mid;
+      if (s_prefix[mid] <= gs) lo = mid; else hi_ = mid;
     }
-    const cusift_point *src = points + (long)lo * max_pts + (g - s_prefix[lo]);
-    cusift_compact_point *dst = packed + g;
-    const float d0 = src->data[lane], d1 = src->data[lane + 64];
-    // maximum over the 128 elements; a NaN anywhere makes it NaN (fmaxf would drop it)
-    float m = (d0 > d1 || d0 != d0) ? d0 : d1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float o = __shfl_xor(m, off);
-      m = (m > o || m != m) ? m : o;
-    }
+    const cusift_point *src = points + (long)lo * max_pts + (gs - s_prefix[lo]);
+    cusift_compact_point *dst = packed + gs;
+    const float *dp = src->data + 4 * l;
+    const float d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3];
+    // maximum over the record's 128 elements; a NaN anywhere makes it NaN (fmaxf would drop it)
+    const bool has_nan = (d0 != d0) || (d1 != d1) || (d2 != d2) || (d3 != d3);
+    const unsigned long long nan_lanes = __ballot(has_nan);
+    const bool rec_nan = ((nan_lanes >> (32 * half)) & 0xffffffffull) != 0;
+    float m = max_over_32(fmaxf(fmaxf(d0, d1), fmaxf(d2, d3)));  // every lane of a half gets its half's maximum
+    if (rec_nan) m = __builtin_nanf("");
     const bool ok = m > 0.0f && m < __builtin_inff();
     const float step = ok ? m / 255.0f : m;
-    unsigned int q0 = 0, q1 = 0;
-    if (ok) {
-      q0 = (unsigned int)fminf(fmaxf(floorf(d0 / step + 0.5f), 0.0f), 255.0f);
-      q1 = (unsigned int)fminf(fmaxf(floorf(d1 / step + 0.5f), 0.0f), 255.0f);
-    }
-    // word k of q[] = elements 4k .. 4k+3: from lanes 4k.. (first half) or 4(k-16).. (second half)
-    const int k = lane & 31, base = 4 * (k & 15);
     unsigned int word = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned int a = (unsigned int)__shfl((int)q0, base + j), b = (unsigned int)__shfl((int)q1, base + j);
-      word |= ((k < 16) ? a : b) << (8 * j);
+    if (ok) {
+      const unsigned int q0 = (unsigned int)fminf(fmaxf(floorf(d0 / step + 0.5f), 0.0f), 255.0f);
+      const unsigned int q1 = (unsigned int)fminf(fmaxf(floorf(d1 / step + 0.5f), 0.0f), 255.0f);
+      const unsigned int q2 = (unsigned int)fminf(fmaxf(floorf(d2 / step + 0.5f), 0.0f), 255.0f);
+      const unsigned int q3 = (unsigned int)fminf(fmaxf(floorf(d3 / step + 0.5f), 0.0f), 255.0f);
+      word = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
     }
-    if (lane < 32) reinterpret_cast<unsigned int *>(dst->q)[k] = word;
-    if (lane == 0) {
-      dst->coords2D[0] = src->coords2D[0];
-      dst->coords2D[1] = src->coords2D[1];
-      dst->scale = src->scale;
-      dst->sharpness = src->sharpness;
-      dst->edgeness = src->edgeness;
-      dst->orientation = src->orientation;
-      dst->subsampling = src->subsampling;
-      dst->desc_step = step;
+    if (live) {
+      reinterpret_cast<unsigned int *>(dst->q)[l] = word;
+      if (l < 7) {  // coords2D[2], scale, sharpness, edgeness, orientation are the record's first six floats
+        const float v = l < 6 ? reinterpret_cast<const float *>(src)[l] : src->subsampling;
+        reinterpret_cast<float *>(dst)[l] = v;
+      }
+      if (l == 7) dst->desc_step = step;
     }
   }
 }
