@@ -406,10 +406,9 @@ def main():
             ticket = None
             with torch.cuda.stream(side_stream):
                 if gatherer is not None:
-                    gatherer.begin(pts, cnt, producer=exs[e].ctx)  # ordered after the extraction by begin() itself
-                    packed = torch.cuda.Event()
-                    packed.record(side_stream)
-                    slot_free[key] = packed  # the slot is free again once its records sit in the gathered buffer
+                    # ordered after the extraction by begin() itself; the slot is free again once its records sit in
+                    # the gathered buffer (the event begin() returns)
+                    slot_free[key] = gatherer.begin(pts, cnt, producer=exs[e].ctx)
                 else:
                     side_stream.wait_event(ev)
                     ticket = begin_allgather(pts, cnt, ex.max_pts, n_images_max=B)

@@ -52,8 +52,10 @@ class SiftGatherer:
     `region_cap` = records one rank's region holds (default: the worst case n_images_max * max_pts).
     `compact=True`: the records travel and arrive as 160-byte cusift_compact_point (capi.COMPACT_POINT_DTYPE; exact
     header fields, 8-bit descriptor) -- `gathered` is then [world, region_cap, 160].
-    The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: order
-    the producer's next write after it with `producer_ctx.wait(comm.ctx)` (no host wait), or synchronise."""
+    The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: begin()
+    returns an event recorded behind it -- `producer_stream.wait_event(ev)` (or `producer_ctx.wait(comm.ctx)`) orders
+    the producer's next write after the pack without a host wait.  The tensors themselves are kept alive by this object
+    until that event has fired."""
 
     def __init__(self, comm, n_images_max, max_pts, region_cap=None, device=None, n_out=2, depth=1, fixed_size=False,
                  compact=False):
@@ -70,7 +72,12 @@ class SiftGatherer:
         if fixed_size:
             comm.set_fixed_size(True)
         self.k = 0
-        self._inflight = []  # (output buffer, held producer tensors), oldest first
+        self._inflight = []  # output buffers of the begins not yet finished, oldest first
+        # the producer's tensors are read by the pack that begin() ENQUEUES on the communicator's stream -- a stream
+        # torch's allocator knows nothing about -- so they are kept alive here until an event behind that pack has fired
+        h = comm.ctx.stream_handle()
+        self._stream = torch.cuda.ExternalStream(h, device=self.device) if h else torch.cuda.default_stream(self.device)
+        self._held = []  # (event after the pack, (points, counts))
 
     def begin(self, points, counts, producer=None):
         assert points.is_cuda and points.is_contiguous() and counts.is_cuda and counts.dtype == torch.int32
@@ -79,16 +86,26 @@ class SiftGatherer:
         self.k += 1
         self.comm.allgatherv_begin(points.data_ptr(), counts.data_ptr(), n, self.max_pts, self.n_max, buf.data_ptr(),
                                    self.region_cap, producer=producer)
-        self._inflight.append((buf, (points, counts)))  # the tensors stay alive until the exchange has been posted
+        packed = torch.cuda.Event()
+        packed.record(self._stream)
+        self._held = [(e, t) for e, t in self._held if not e.query()] + [(packed, (points, counts))]
+        self._inflight.append(buf)
+        return packed  # after this event the caller may overwrite points / counts (stream.wait_event(packed))
 
     def finish(self):
-        buf, _held = self._inflight.pop(0)
+        buf = self._inflight.pop(0)
         counts, totals = self.comm.allgatherv_finish()
         return counts, buf, totals
 
     def gather(self, points, counts, producer=None):
         self.begin(points, counts, producer)
         return self.finish()
+
+    def close(self):
+        """Waits for the packs still reading producer tensors, then lets go of them."""
+        for e, _ in self._held:
+            e.synchronize()
+        self._held = []
 
     @staticmethod
     def regions(gathered, totals):
