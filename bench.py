@@ -242,8 +242,10 @@ def load_profile_json(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a 60 ms timed region after 12 ms of warm-up -- region-to-region spread on one box is +-5 % at 20 steps
+    # (clock management; `ms_per_step_spread`), and the legs below scale with K
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
