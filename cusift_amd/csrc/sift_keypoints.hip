@@ -111,10 +111,11 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, f
     a = floorf(fmaf(a, q, 0.5f)) * inv_q;
     b = floorf(fmaf(b, q, 0.5f)) * inv_q;
   }
-  // element index (fy - y0) * kStride + (fx - x0), formed in floating point: all three terms are small integers
-  // (patch_for_reach bounds |coordinates| by 1e5), so the fma is exact -- one v_fma + one v_cvt instead of two
-  // conversions, two integer subtractions and an integer multiply
-  const int e = (int)fmaf(fy - (float)y0, (float)kStride, fx - (float)x0);
+  // element index (fy - y0) * kStride + (fx - x0): fy * kStride + fx is formed in floating point -- both terms are
+  // integers below 2^23 (patch_for_reach bounds |coordinates| by 1e5), so the fma is exact -- and the patch origin,
+  // which is wave-uniform, comes off as one integer: v_fma + v_cvt + a subtraction that folds into the scalar part of
+  // the address, instead of two conversions, two integer subtractions and an integer multiply
+  const int e = (int)fmaf(fy, (float)kStride, fx) - (y0 * kStride + x0);
   const float *p0 = lds + e;
   const float *p1 = p0 + kStride;
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
