@@ -12,13 +12,16 @@ most real arithmetic) or a DPP modifier ~4.6, a packed fp32 instruction (v_pk_*_
 division helpers run at quarter rate (~4x a plain one).  The bound for a kernel that retires N wave-instructions of
 a given mix on S SIMDs at clock f is  N * sum_c(frac_c * cycles_c) / (S * f).
 
-Classes are counted over the basic blocks that sit INSIDE A LOOP (between a label and a later backward branch to it):
-the prologue, the window fill and other once-per-wave code do not weigh in.  For the fused detection that is still not
-the hot path: its loop holds 60 inlined copies of the 122-instruction candidate refinement (one per scale and column,
-cold: ~1 % of the dynamic instructions) beside the three 592-instruction blocks of the x3-unrolled row loop (blur + DoG
-+ threshold pre-test, which branch back to themselves when the pre-test finds nothing) -- there only the blocks that
-contain packed instructions are counted, i.e. exactly those three.  The count is static -- every counted block weighs
-one -- so it is an estimate of the dynamic mix, not a trace; the PMC total it is applied to is exact.
+Classes are counted over the basic blocks (split at labels AND at the assembler's fall-through block comments) that
+sit INSIDE A LOOP (between a label and a later backward branch to it): the prologue, the window fill and other
+once-per-wave code do not weigh in.  For the fused detection that is still not the hot path: its loop holds 60 inlined
+copies of the 122-instruction candidate refinement (cold: ~1 % of the dynamic instructions).  Its row step (x3
+unrolled) is two kinds of block: the BLUR blocks (packed instructions: blur + DoG, then the ten-instruction threshold
+pre-test) that every wave-row executes, and the ANALYSIS blocks (v_min3 / v_max3 trees of the 26-neighbour test) that
+only the wave-rows run in which the pre-test finds a centre above the threshold.  They are reported separately
+("mix" + "analysis") and bench.py weighs the second with the measured pass fraction of the content.  The count is
+static -- every counted block weighs one -- so it is an estimate of the dynamic mix, not a trace; the PMC total it is
+applied to is exact.
 """
 import json
 import os
@@ -31,8 +34,8 @@ sys.path.insert(0, ROOT)
 from cusift_amd import build as B  # noqa: E402
 
 KERNELS = {  # name -> (source, mangled-name needle, block selector)
-    "detect_fused_kernel": ("sift_stencils.hip", "detect_fused_kernelILb1E", "packed"),  # <kIdent0>: the benchmark's octave 0
-    "detect_fused_kernel<false>": ("sift_stencils.hip", "detect_fused_kernelILb0E", "packed"),
+    "detect_fused_kernel": ("sift_stencils.hip", "detect_fused_kernelILb1E", "detect"),  # <kIdent0>: the benchmark's octave 0
+    "detect_fused_kernel<false>": ("sift_stencils.hip", "detect_fused_kernelILb0E", "detect"),
     "describe_all_kernel": ("sift_keypoints.hip", "describe_all_kernel", "loop"),
     "laplace_multi_fast_kernel": ("sift_stencils.hip", "laplace_multi_fast_kernelILi2E", "loop"),
 }
@@ -81,9 +84,8 @@ def classify(line):
     return "multi_vgpr_src" if n >= 2 else "one_vgpr_src"
 
 
-def loop_mix(body, selector):
-    """Class counts over the basic blocks inside any loop (label .. backward branch to that label); selector "packed":
-    only those of them that contain packed instructions."""
+def loop_blocks(body):
+    """Per basic block inside a loop: {class: count} plus the raw mnemonic counts."""
     label_at = {}
     for i, l in enumerate(body):
         m = re.match(r"^(\.LBB[0-9_]+):", l)
@@ -95,22 +97,47 @@ def loop_mix(body, selector):
         if m and m.group(1) in label_at and label_at[m.group(1)] <= i:
             for j in range(label_at[m.group(1)], i + 1):
                 in_loop[j] = True
-    starts = sorted(set([0] + list(label_at.values()))) + [len(body)]
-    counts, total_all, n_blocks = {}, 0, 0
+    starts = set([0] + list(label_at.values()))
+    starts |= {i for i, l in enumerate(body) if l.lstrip().startswith("; %bb.")}
+    starts = sorted(starts) + [len(body)]
+    blocks, total_all = [], 0
     for a, b in zip(starts[:-1], starts[1:]):
-        blk = {}
+        blk, ops = {}, {}
         for i in range(a, b):
             c = classify(body[i])
             if c is not None:
                 total_all += 1
                 if in_loop[i]:
                     blk[c] = blk.get(c, 0) + 1
-        if not blk or (selector == "packed" and not blk.get("packed")):
-            continue
-        n_blocks += 1
-        for k, v in blk.items():
-            counts[k] = counts.get(k, 0) + v
-    return counts, total_all, n_blocks
+                    op = body[i].split()[0]
+                    ops[op] = ops.get(op, 0) + 1
+        if blk:
+            blocks.append((blk, ops))
+    return blocks, total_all
+
+
+def add(into, blk):
+    for k, v in blk.items():
+        into[k] = into.get(k, 0) + v
+
+
+def loop_mix(body, selector):
+    """Class counts over the loop blocks.  selector "loop": all of them; "detect": (blur blocks, analysis blocks)."""
+    blocks, total_all = loop_blocks(body)
+    main, ana, n_main, n_ana = {}, {}, 0, 0
+    for blk, ops in blocks:
+        if selector == "loop":
+            add(main, blk)
+            n_main += 1
+        elif blk.get("packed"):
+            add(main, blk)
+            n_main += 1
+        elif ops.get("v_min3_f32", 0) >= 20 and not blk.get("quarter_rate"):
+            add(ana, blk)
+            n_ana += 1
+        elif ops.get("v_max3_f32", 0) == 10 and sum(blk.values()) <= 16:  # the threshold pre-test: every row
+            add(main, blk)
+    return main, total_all, n_main, ana, n_ana
 
 
 def main():
@@ -121,16 +148,26 @@ def main():
     for name, (src, needle, selector) in KERNELS.items():
         if src not in cache:
             cache[src] = assembly(src)
-        counts, total_all, n_blocks = loop_mix(kernel_body(cache[src], needle), selector)
+        counts, total_all, n_blocks, ana, n_ana = loop_mix(kernel_body(cache[src], needle), selector)
         n = sum(counts.values())
         cyc = CYCLES[WAVES[name]]
         frac = {k: round(v / n, 4) for k, v in sorted(counts.items())}
         avg = sum(counts[k] / n * cyc[k] for k in counts)
         out[name] = {"counted_valu_instructions_static": n, "counted_blocks": n_blocks,
-                     "blocks": "loop blocks holding packed instructions" if selector == "packed" else "all loop blocks",
+                     "blocks": "blur + DoG + pre-test blocks (every wave-row)" if selector == "detect" else "all loop blocks",
                      "kernel_valu_instructions_static": total_all,
                      "waves_per_simd": WAVES[name], "mix": frac, "cycles_per_instruction_mix_weighted": round(avg, 3)}
         print("%-28s loop VALU %5d of %5d  %s  -> %.2f cycles/inst" % (name, n, total_all, frac, avg))
+        if ana:
+            na = sum(ana.values())
+            avg_a = sum(ana[k] / na * cyc[k] for k in ana)
+            out[name]["analysis"] = {"counted_valu_instructions_static": na, "counted_blocks": n_ana,
+                                     "blocks": "26-neighbour analysis blocks (only wave-rows that pass the pre-test)",
+                                     "mix": {k: round(v / na, 4) for k, v in sorted(ana.items())},
+                                     "cycles_per_instruction_mix_weighted": round(avg_a, 3),
+                                     "instructions_per_row_step": round(na / max(1, n_blocks), 1)}
+            out[name]["instructions_per_row_step"] = round(n / max(1, n_blocks), 1)
+            print("%-28s analysis  %5d in %d blocks %s -> %.2f cycles/inst" % ("", na, n_ana, out[name]["analysis"]["mix"], avg_a))
     dst = os.path.join(ROOT, "profiles", "isa_mix.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
