@@ -100,19 +100,20 @@ int make_strip_plan(StripPlan &pl, int W, int H, int world, int num_octaves, int
   for (int k = 0; k <= world; ++k) pl.bounds[k] = (long)k * H / world;
   pl.root = 0;
   pl.collapse = pl.n_oct;
-  if (world > 1)
-    for (int o = 0; o < pl.n_oct; ++o) {
-      int thinnest = 1 << 30;
-      for (int k = 0; k < world; ++k) {
-        int a, b;
-        pl.own(k, o, a, b);
-        thinnest = std::min(thinnest, b - a);
-      }
-      if (thinnest < halo || pl.w[o] < 4) {  // the band kernels need w >= 4; narrower octaves run whole as well
-        pl.collapse = o;
-        break;
-      }
+  for (int o = 0; o < pl.n_oct; ++o) {
+    int thinnest = 1 << 30;
+    for (int k = 0; k < world; ++k) {
+      int a, b;
+      pl.own(k, o, a, b);
+      thinnest = std::min(thinnest, b - a);
     }
+    // a rank that owns fewer rows than the halo cannot serve its neighbour's halo; and the band kernels need w >= 4 and
+    // h >= 3: narrower / flatter octaves run whole on the root as well (with one rank, too)
+    if ((world > 1 && thinnest < halo) || pl.w[o] < 4 || pl.h[o] < 3) {
+      pl.collapse = o;
+      break;
+    }
+  }
   return CUSIFT_OK;
 }
 

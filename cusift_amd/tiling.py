@@ -73,12 +73,12 @@ class StripPlan:
         self.bounds = [(k * self.H) // self.world for k in range(self.world + 1)]
         self.root = 0
         self.collapse = self.n_oct
-        if self.world > 1:
-            for o in range(self.n_oct):
-                thin = min(self.own(k, o)[1] - self.own(k, o)[0] for k in range(self.world)) < self.halo
-                if thin or self.w[o] < 4:  # the band kernels need w >= 4; narrower octaves run whole as well
-                    self.collapse = o
-                    break
+        for o in range(self.n_oct):
+            thin = self.world > 1 and min(self.own(k, o)[1] - self.own(k, o)[0] for k in range(self.world)) < self.halo
+            # the band kernels need w >= 4 and h >= 3; narrower / flatter octaves run whole as well (with one rank, too)
+            if thin or self.w[o] < 4 or self.h[o] < 3:
+                self.collapse = o
+                break
 
     def own(self, rank, o):
         return self.bounds[rank] >> o, self.bounds[rank + 1] >> o

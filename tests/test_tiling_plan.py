@@ -59,7 +59,7 @@ def test_python_plan_equals_the_c_abi_plan():
 
     cases = [(8192, 8192, 8, 7, 48), (8192, 8192, 8, 5, 48), (1000, 1531, 3, 6, 48), (640, 300, 8, 4, 48),
              (1024, 2048, 4, 7, 48), (512, 1024, 2, 2, 8), (64, 4096, 5, 9, 16), (4096, 3001, 7, 6, 32),
-             (256, 768, 1, 3, 48), (33, 2000, 3, 8, 48)]
+             (256, 768, 1, 3, 48), (33, 2000, 3, 8, 48), (99, 1000, 1, 6, 32), (640, 24, 1, 6, 48), (5, 40, 2, 3, 8)]
     for W, H, P, n_oct, halo in cases:
         py = StripPlan(W, H, P, n_oct, halo)
         for k in range(P):
