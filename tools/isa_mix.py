@@ -5,12 +5,15 @@ the product's flags -- the weights of the mix-weighted ISSUE BOUND bench.py prin
 
     python tools/isa_mix.py            # writes profiles/isa_mix.json (runs here: hipcc cross-compiles without a GPU)
 
-Why: the spec peak prices every VALU instruction at one issue slot per 4 cycles per SIMD... which no instruction of
-these kernels reaches.  tools/microbench/valu_rate.hip (profiles/r02_valu_rate_microbench.txt) measures, per SIMD at
-the kernels' occupancy: an instruction with at most one VGPR source ~3.0 cycles, with two or more VGPR sources (max3,
-most real arithmetic) or a DPP modifier ~4.6, a packed fp32 instruction (v_pk_*_f32) ~6.9, and transcendental /
-division helpers run at quarter rate (~4x a plain one).  The bound for a kernel that retires N wave-instructions of
-a given mix on S SIMDs at clock f is  N * sum_c(frac_c * cycles_c) / (S * f).
+Why: the spec peak prices every wave64 VALU instruction at two cycles per SIMD, which no instruction of these kernels
+reaches.  tools/microbench/valu_rate.hip (profiles/r03/valu_rate_microbench.txt) measures what one SIMD sustains per
+instruction kind; the BEST it does for a kind, with eight waves resident, is what is used here, so that the result is a
+bound whatever the kernel's occupancy: at most one VGPR source 2.40 cycles (v_fma_f32 v, s, s; an integer v_add_u32
+v, s 2.14), two or more VGPR sources 4.18 (v_max3_f32; v_mul_f32 v, v 4.34, v_fma_f32 v, v, v 5.34 -- the cheapest
+stands for the class), a DPP move 4.18, a packed fp32 instruction (v_pk_*_f32) 6.21, transcendental / division helpers
+at quarter rate.  At the kernels' own occupancy (2 / 4 waves per SIMD) the same streams run 3-11 % slower.  The bound for
+a kernel that retires N wave-instructions of a given mix on S SIMDs at clock f is  N * sum_c(frac_c * cycles_c) / (S * f)
+(the microbenchmark's cycles are time at the nominal 2.4 GHz with the whole chip loaded: a time calibration).
 
 Classes are counted over the basic blocks (split at labels AND at the assembler's fall-through block comments) that
 sit INSIDE A LOOP (between a label and a later backward branch to it): the prologue, the window fill and other
@@ -39,11 +42,10 @@ KERNELS = {  # name -> (source, mangled-name needle, block selector)
     "describe_all_kernel": ("sift_keypoints.hip", "describe_all_kernel", "loop"),
     "laplace_multi_fast_kernel": ("sift_stencils.hip", "laplace_multi_fast_kernelILi2E", "loop"),
 }
-# cycles per wave-instruction per SIMD (profiles/r02_valu_rate_microbench.txt), by waves resident per SIMD
-CYCLES = {
-    2: {"one_vgpr_src": 2.96, "multi_vgpr_src": 4.72, "dpp": 4.63, "packed": 6.85, "quarter_rate": 4 * 2.96},
-    4: {"one_vgpr_src": 2.70, "multi_vgpr_src": 4.33, "dpp": 4.35, "packed": 6.34, "quarter_rate": 4 * 2.70},
-}
+# best-case cycles per wave-instruction per SIMD (profiles/r03/valu_rate_microbench.txt, eight resident waves): the
+# same for every kernel -- a bound must not depend on the occupancy the kernel happens to run at
+BEST = {"one_vgpr_src": 2.40, "multi_vgpr_src": 4.18, "dpp": 4.18, "packed": 6.21, "quarter_rate": 4 * 2.40}
+CYCLES = {2: BEST, 4: BEST}
 WAVES = {"detect_fused_kernel": 2, "detect_fused_kernel<false>": 2, "describe_all_kernel": 4,
          "laplace_multi_fast_kernel": 4}
 QUARTER = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_", "v_div_fmas", "v_div_scale",
@@ -142,7 +144,7 @@ def loop_mix(body, selector):
 
 def main():
     out = {"_source": "python tools/isa_mix.py: static VALU class counts over the loop blocks of each kernel (hipcc -S with "
-                      "the product's flags), cycles per class from profiles/r02_valu_rate_microbench.txt",
+                      "the product's flags), best-case cycles per class from profiles/r03/valu_rate_microbench.txt",
            "_cycles_per_wave_instruction_per_simd": CYCLES}
     cache = {}
     for name, (src, needle, selector) in KERNELS.items():

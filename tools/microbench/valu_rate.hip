@@ -28,7 +28,19 @@ __global__ void __launch_bounds__(64) k(float *out, int iters, float a, float b)
         if (kKind == 2) x[0] = __builtin_fmaf(x[0], a, b);  // one dependent chain
         if (kKind == 3)
           x[i] = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[(i + 1) & 15]), 0x138, 0xf, 0xf, true));
-        if (kKind == 4) x[i] = fmaxf(fmaxf(x[i], a), x[(i + 3) & 15]);  // v_max3
+        if (kKind == 4) x[i] = fmaxf(fmaxf(x[i], a), x[(i + 3) & 15]);  // v_max3: two VGPR sources + a scalar
+        // round 3: the classes the issue bound of bench.py prices (tools/isa_mix.py)
+        if (kKind == 5) x[i] = x[i] * x[(i + 3) & 15];                              // v_mul_f32 v, v: two VGPR sources
+        if (kKind == 6) x[i] = __builtin_fmaf(x[i], x[(i + 3) & 15], x[(i + 7) & 15]);  // v_fma_f32 v, v, v: three
+        if (kKind == 7) x[i] = fmaxf(fmaxf(x[i], x[(i + 5) & 15]), x[(i + 3) & 15]);   // v_max3_f32 v, v, v
+        if (kKind == 8) {                                                             // v_add_u32 v, s: integer, one
+          int t = __builtin_bit_cast(int, x[i]) + it;
+          x[i] = __builtin_bit_cast(float, t);
+        }
+        if (kKind == 9) {  // v_cmp_lt_f32 + v_cndmask_b32: the compare / select pair (two instructions per element)
+          x[i] = (x[i] < x[(i + 3) & 15]) ? x[(i + 5) & 15] : x[i];
+        }
+        if (kKind == 10) x[i] = __builtin_floorf(x[i]) + 0.25f + a * 0.f;             // v_floor_f32 + v_add_f32 v, c
       }
     }
   }
@@ -73,5 +85,11 @@ int main() {
   run<2>("fma chain", cus);
   run<3>("v_mov_dpp", cus);
   run<4>("v_max3_f32", cus);
+  run<5>("v_mul v,v", cus);
+  run<6>("v_fma v,v,v", cus);
+  run<7>("v_max3 v,v,v", cus);
+  run<8>("v_add_u32 v,s", cus);
+  run<9>("cmp+cndmask(2)", cus);
+  run<10>("floor+add(2)", cus);
   return 0;
 }
