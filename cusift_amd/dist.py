@@ -13,7 +13,8 @@ On GPUs the exchange is the C ABI's (cusift_comm_* / cusift_allgatherv_*, csrc/s
 from C++) and this module is a thin caller: `make_comm` hands the communicator's unique id to every rank through
 torch.distributed, `SiftGatherer` owns the preallocated output buffers.  The torch.distributed implementation below
 (`begin_allgather` / `finish_allgather` / `allgather_siftdata`) is the host-logic twin used with CPU tensors over
-`gloo` (tests/test_dist_gloo.py); both produce the same layout.
+`gloo` (tests/test_dist_gloo.py); it packs the ranks' records back to back (the layout cusift_compact_gathered makes of
+the C ABI's fixed regions).
 """
 import numpy as np
 import torch
