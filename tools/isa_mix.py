@@ -48,8 +48,7 @@ BEST = {"one_vgpr_src": 2.40, "multi_vgpr_src": 4.18, "dpp": 4.18, "packed": 6.2
 CYCLES = {2: BEST, 4: BEST}
 WAVES = {"detect_fused_kernel": 2, "detect_fused_kernel<false>": 2, "describe_all_kernel": 4,
          "laplace_multi_fast_kernel": 4}
-QUARTER = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_", "v_div_fmas", "v_div_scale",
-           "v_div_fixup", "v_rcp_iflag")
+QUARTER = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")  # the transcendental unit
 
 
 def assembly(src):
