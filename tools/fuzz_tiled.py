@@ -76,6 +76,8 @@ def main():
         blur = float(rng.choice([0.0, 0.5, 1.0]))
         thresh = float(rng.choice([1.0, 2.0, 3.5]))
         root_sift = int(rng.integers(0, 4) == 0)
+        lowest = float(rng.choice([0.0, 0.0, 0.0, 2.0, 4.0]))
+        subs = float(rng.choice([1.0, 1.0, 1.0, 2.0]))
         virtual = case % 3 == 2
         kind = int(rng.integers(0, 3))
         if kind == 0:
@@ -86,9 +88,9 @@ def main():
             img = rng.integers(0, 256, size=(H, W)).astype(np.float32)
         img = np.ascontiguousarray(img, dtype=np.float32)
         prm = capi.default_params(num_octaves=n_oct, init_blur=blur, peak_thresh=thresh, max_pts=1 << 17,
-                                  root_sift=root_sift)
-        tag = "case %d: %dx%d P=%d oct=%d halo=%d blur=%.1f thr=%.1f kind=%d root=%d %s" % (
-            case, W, H, P, n_oct, halo, blur, thresh, kind, root_sift, "virtual" if virtual else "threads")
+                                  root_sift=root_sift, lowest_scale=lowest, subsampling=subs)
+        tag = "case %d: %dx%d P=%d oct=%d halo=%d blur=%.1f thr=%.1f kind=%d root=%d low=%g sub=%g %s" % (
+            case, W, H, P, n_oct, halo, blur, thresh, kind, root_sift, lowest, subs, "virtual" if virtual else "threads")
         d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
         h_pts = np.zeros(prm.max_pts, dtype=SIFT_POINT_DTYPE)
         n = ctx.extract_host(img, prm, d_pts.ptr, h_pts)
