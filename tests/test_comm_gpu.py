@@ -121,3 +121,22 @@ def test_ctx_wait_orders_two_contexts(ctx, gray1):
     got = b.to_numpy(np.uint8, (a.nbytes,))
     assert (got == 0x5A).all()
     other.close()
+
+
+def test_tiled_refuses_a_communicator_on_another_stream(ctx):
+    """Kernels and exchanges of the tiled driver must share one stream: cusift_tiled_create refuses a communicator that
+    is bound to another context (a halo received on another stream would race the detection -- round 2's Python driver
+    could be built that way)."""
+    a, b = capi.Context(0), capi.Context(0)  # two contexts, each with a stream of its own
+    comm = make_comm(a)
+    prm = capi.default_params(num_octaves=3, max_pts=1024)
+    with pytest.raises(capi.CusiftError, match="another context"):
+        capi.Tiled(b, comm, 0, 1, 256, 256, prm)
+    t = capi.Tiled(a, comm, 0, 1, 256, 256, prm)  # the communicator's own context: fine
+    assert t.n_oct == 3 and t.collapse == 3
+    with pytest.raises(capi.CusiftError, match="rank"):
+        capi.Tiled(a, comm, 1, 2, 256, 256, prm)  # the communicator is rank 0 of 1
+    t.close()
+    comm.close()
+    a.close()
+    b.close()
