@@ -96,6 +96,7 @@ SIGNATURES = {
     "cusift_comm_set_fixed_size": (_i, [_vp, _i]),
     "cusift_comm_set_wire_format": (_i, [_vp, _i]),
     "cusift_comm_host_waits": (C.c_ulonglong, [_vp]),
+    "cusift_comm_hip_syncs": (C.c_ulonglong, [_vp]),
     "cusift_allgatherv_begin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz]),
     "cusift_allgatherv_finish": (_i, [_vp, _vp, _vp]),
     "cusift_allgatherv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
@@ -516,6 +517,9 @@ class Comm:
 
     def host_waits(self):
         return int(lib().cusift_comm_host_waits(self._h))
+
+    def hip_syncs(self):
+        return int(lib().cusift_comm_hip_syncs(self._h))
 
     def allgatherv_begin(self, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, region_cap,
                          producer=None):

@@ -204,6 +204,7 @@ struct cusift_comm {
   cusift_point *d_stage = nullptr;  // self_p2p only: the packed local shard before it is "sent" into its region
   size_t stage_cap = 0;
   unsigned long long host_waits = 0;  // finish() calls that found their counts not yet arrived (diagnostic)
+  unsigned long long hip_syncs = 0;   // synchronising HIP calls this object has made (only ever while (re)sizing)
 };
 
 namespace {
@@ -256,6 +257,7 @@ int reserve_tickets(cusift_comm *c, int n_slots, int depth) {
   if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: cannot re-size the ticket ring with exchanges in flight");
   n_slots = std::max(n_slots, c->n_slots);
   depth = std::max(depth, c->depth);
+  c->hip_syncs++;
   HIP_TRY(hipStreamSynchronize(c->stream));
   free_tickets(c);
   const size_t W = (size_t)c->world;
@@ -282,6 +284,7 @@ int reserve_tickets(cusift_comm *c, int n_slots, int depth) {
 
 int reserve_stage(cusift_comm *c, size_t records) {
   if (records <= c->stage_cap) return CUSIFT_OK;
+  c->hip_syncs++;
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->d_stage) HIP_TRY(hipFree(c->d_stage));
   c->d_stage = nullptr;
@@ -414,6 +417,7 @@ extern "C" int cusift_comm_reserve(cusift_comm *c, int n_images_max, int tickets
 }
 
 extern "C" unsigned long long cusift_comm_host_waits(cusift_comm *c) { return c ? c->host_waits : 0; }
+extern "C" unsigned long long cusift_comm_hip_syncs(cusift_comm *c) { return c ? c->hip_syncs : 0; }
 
 extern "C" const char *cusift_comm_library(void) {
   std::lock_guard<std::mutex> lock(g_lib_mu);

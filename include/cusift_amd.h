@@ -331,6 +331,9 @@ int cusift_comm_set_wire_format(cusift_comm *comm, int compact);
 /* Diagnostic: how many finish() calls found their counts not yet there, i.e. the host was ahead of the GPU (in a
  * GPU-bound pipelined loop that is the normal case and costs nothing: the device has the caller's other steps queued). */
 unsigned long long cusift_comm_host_waits(cusift_comm *comm);
+/* Diagnostic: synchronising HIP calls (hipStreamSynchronize) this communicator has made so far -- they only happen while
+ * its buffers are (re)sized: after cusift_comm_reserve the number stays put through any number of begin / finish. */
+unsigned long long cusift_comm_hip_syncs(cusift_comm *comm);
 
 /* All-gatherv of SiftData: every rank ends up with the valid records of ALL ranks' images.  d_gathered is `world`
  * REGIONS of region_cap records (cusift_point, or cusift_compact_point after cusift_comm_set_wire_format(comm, 1));

@@ -88,6 +88,7 @@ def test_allgatherv_multirank(world, fixed):
             for o in outs:
                 o.zero()
             side.synchronize()
+            syncs_before = comm.hip_syncs()  # reserve() sized everything: nothing below may synchronise or allocate
             # all begins first (tickets in flight), then the finishes, oldest first
             for s in range(rounds):
                 comm.allgatherv_begin(d_pts[s].ptr, d_cnt[s].ptr, images[rank], max_pts, n_max, outs[s].ptr, region_cap,
@@ -98,6 +99,7 @@ def test_allgatherv_multirank(world, fixed):
                 side.synchronize()
                 got.append((counts, totals, outs[s].to_numpy(np.uint32, (world, region_cap, WORDS))))
             waits = comm.host_waits()
+            assert comm.hip_syncs() == syncs_before, "the exchange made a synchronising HIP call"
             comm.close()
             for b in d_pts + d_cnt + outs:
                 b.free()
