@@ -48,6 +48,12 @@ import numpy as np
 # environment before torch (or libcusift_amd.so) touches the GPU: the host driver only supports dmabuf IPC, and
 # without it RCCL's cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4).  The benchmark keeps four
+# extraction streams busy and, with N > 1, a fifth for the exchange: on four queues the exchange stream shares a queue
+# with an extraction stream, and its waits (for the producer's event, for the peers inside RCCL) block the kernels
+# queued behind them -- measured at one rank (--force-gather --no-self-p2p): 1.325 ms per step on 4 queues, 1.233 on 8,
+# against 1.157 without any exchange.  Read at HIP initialisation, so it has to be set here.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -268,6 +274,10 @@ def main():
     ap.add_argument("--gather-compact", action="store_true",
                     help="N > 1: exchange 160-byte compact records (exact header fields, 8-bit descriptor) instead of the "
                          "exact 588-byte SiftPoint records -- NOT the default: the metric is the all-gatherv of SiftData")
+    ap.add_argument("--no-self-p2p", action="store_true",
+                    help="with --force-gather at one rank: do not route the local shard through ncclSend/ncclRecv to self "
+                         "(what remains is what every rank does for ITS OWN shard at any N: clamp, pack into its region, "
+                         "counts all-gather, publish)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gatherv of SiftData even with one rank (self send/recv: exercises the RCCL path "
                          "on one GPU)")
@@ -366,7 +376,7 @@ def main():
         err = ""
         try:
             side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
-            comm = make_comm(side_ctx, self_p2p=(world == 1))
+            comm = make_comm(side_ctx, self_p2p=(world == 1 and not args.no_self_p2p))
             gatherer = SiftGatherer(comm, B, args.max_pts, region_cap=region_cap, device=dev, n_out=LAG + 2,
                                     depth=LAG + 1, compact=args.gather_compact)
         except Exception as e:  # noqa: BLE001
