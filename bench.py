@@ -592,11 +592,26 @@ def main():
         if "single" in legs:
             single_ms, stage = run_single_stream(ex, d_imgs, K)
             out["stage_ms_per_step"] = stage_table(stage, K)
+            # a lone caller: one batch at a time on one stream, no stage timers -- the driver then runs octave 0's
+            # detection on the context's second stream beside the ScaleDown chain and the coarser octaves
+            forks0 = ex.ctx.forks()
+            for _ in range(2):
+                ex.extract(d_imgs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(K):
+                ex.extract(d_imgs)
+            torch.cuda.synchronize()
+            lone_ms = (time.perf_counter() - t1) / K * 1e3
             out["single_stream_leg"] = {
                 "ms_per_step": round(single_ms, 4),
+                "lone_caller_ms_per_step": round(lone_ms, 4),
+                "lone_caller_forked_steps": ex.ctx.forks() - forks0 - 2,
                 "note": "the timed region alternates steps over %d streams; stage_ms_per_step, the VALU rooflines and "
                         "pyramid_mpix_per_s are measured on the same steps run on one stream (HIP events per launch), "
-                        "where kernel spans do not overlap" % E}
+                        "where kernel spans do not overlap.  lone_caller_ms_per_step: the same calls without the stage "
+                        "timers and with concurrent_batches = 1 -- what a caller that keeps ONE batch in flight gets "
+                        "(octave 0's detection then runs on the context's second stream)" % E}
             sd_ms = stage["scale_down"][0]
             det_ms, det_n = stage["detect_multi"]
             if det_n > 0:

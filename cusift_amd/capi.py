@@ -117,6 +117,7 @@ SIGNATURES = {
     "cusift_exchange_halos": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
     "cusift_ctx_arena_bytes": (_sz, [_vp]),
+    "cusift_ctx_forks": (C.c_ulong, [_vp]),
     "cusift_ctx_timing_enable": (_i, [_vp, _i]),
     "cusift_ctx_timing_read": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
     "cusift_ctx_timing_reset": (_i, [_vp]),
@@ -289,6 +290,10 @@ class Context:
 
     def arena_bytes(self):
         return lib().cusift_ctx_arena_bytes(self.handle)
+
+    def forks(self):
+        """cusift_ctx_forks: extractions that ran octave 0's detection on the context's second stream."""
+        return int(lib().cusift_ctx_forks(self.handle))
 
     # ---- timing ----
     def timing_enable(self, on=True):

@@ -26,7 +26,7 @@ template <int kStoreAux>
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                         FindParams);
-template <bool kIdent0>
+template <bool kIdent0, int kRecBytes>
 __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                     LaplaceTapsPk, FindParams, RowWindow, int, int);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
@@ -36,7 +36,8 @@ __global__ void orientations_kernel(const float *, int, int, int, long, cusift_p
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                    const unsigned int *, float, float, float, RowWindow, int, unsigned int *);
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int,
-                                    unsigned int *);
+                                    unsigned int *, const unsigned int *, const char *);
+__global__ void join_counts_kernel(unsigned int *, const unsigned int *, unsigned int *, int, int, unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
 template <bool kL2>
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, MatchPartial *, int);
@@ -116,6 +117,8 @@ struct Knobs {
   int laplace_aux = -1;                              // CUSIFT_LAPLACE_AUX: cache policy of the DoG stores
   bool no_ident = false, force_generic = false;      // CUSIFT_NO_IDENT, CUSIFT_FORCE_GENERIC
   int match_splits = 0;                              // CUSIFT_MATCH_SPLITS
+  int octave_overlap = -1;                           // CUSIFT_OCTAVE_OVERLAP: 0 never, 1 lone callers (default), 2 always
+  bool side_debug = false;                           // CUSIFT_SIDE_DEBUG: print the side stream's concurrency probe
 };
 
 static Knobs read_knobs() {
@@ -138,6 +141,8 @@ static Knobs read_knobs() {
   k.no_ident = text("CUSIFT_NO_IDENT") != nullptr;
   k.force_generic = text("CUSIFT_FORCE_GENERIC") != nullptr;
   k.match_splits = num("CUSIFT_MATCH_SPLITS", 0);
+  k.octave_overlap = num("CUSIFT_OCTAVE_OVERLAP", -1);
+  k.side_debug = text("CUSIFT_SIDE_DEBUG") != nullptr;
   return k;
 }
 
@@ -166,6 +171,12 @@ struct cusift_ctx {
   unsigned int *d_counter1 = nullptr;
   unsigned int *d_queue = nullptr;  // kQueueShards work cursors of describe_all_kernel, 128 bytes apart
   int describe_grid = 0;  // resident blocks of describe_all_kernel on this device (occupancy query, cached)
+  // octave 0's detection beside the coarser octaves (cusift_extract_batch): a second stream and its fork / join events
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_failed = false;  // no stream was found that runs beside the context's stream: never fork
+  bool recording = false;  // inside cusift_graph_create's capture
+  unsigned long forks = 0;  // extractions that took the side stream
   unsigned long scratch_gen = 0;  // bumped whenever arena / DoG / matcher scratch is re-allocated (recorded graphs check it)
   // timing
   bool timing = false;
@@ -227,9 +238,14 @@ struct Plan {
   // arena offsets in bytes
   size_t base_off[kMaxOctaves];  // octave >= 1 base images (n * h*p floats each); [0] unused
   size_t first_off = 0, total = 0;
+  size_t staged_off = 0;  // the staging list of octave 0's keypoints ([n][max_pts] heads), when `staged`
+  bool staged = false;
 };
 
-int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm) {
+// Largest staging list a context allocates for the side-by-side detection of octave 0 (beyond it: one stream, as before)
+constexpr size_t kMaxStagedBytes = (size_t)1 << 30;
+
+int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm, bool staged = false) {
   if (!prm) return fail(CUSIFT_ERR_INVALID, "params is NULL");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w)
     return fail(CUSIFT_ERR_INVALID, "bad geometry n=%d w=%d h=%d pitch=%d", n_images, w, h, pitch);
@@ -262,6 +278,11 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
   }
   pl.first_off = off;
   off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
+  pl.staged = staged && pl.n_oct >= 2 && (size_t)n_images * prm->max_pts * kStagedRecBytes <= kMaxStagedBytes;
+  if (pl.staged) {
+    pl.staged_off = off;
+    off = align_up_sz(off + (size_t)n_images * prm->max_pts * kStagedRecBytes, 256);
+  }
   pl.total = off;
   return CUSIFT_OK;
 }
@@ -417,6 +438,108 @@ extern "C" int cusift_init(int device) {
   return CUSIFT_OK;
 }
 
+// Octave 0 beside the coarser octaves.  One extraction on one stream is a chain of launches of very different sizes:
+// octave 0's detection (3/4 of the pixels), then four ScaleDowns and four detections that each fill the chip for a few
+// microseconds and end in a tail.  A caller that keeps several batches in flight (cusift_params.concurrent_batches >= 2)
+// covers those tails with the other batches' kernels; a lone caller -- ExtractSift as the reference calls it -- cannot.
+// For it the driver forks: octave 0's detection goes to a second stream of the context and appends HEADS (64 bytes)
+// to a staging list in the arena, the ScaleDown chain and the coarser detections run on the context's stream as
+// before, the streams join, and describe_all_kernel moves the staged keypoints behind the coarser ones while it
+// describes them -- so SiftData comes out coarsest octave first, and saturates coarsest first, exactly as before.
+// Measured on MI355X (tools/probe_octave_overlap.py, one stream, back to back): 64 x 1080p 1.527 -> 1.356 ms, 16: 0.478 ->
+// 0.429, 4: 0.213 -> 0.200 -- but ONE frame 0.132 -> 0.138 ms, and its recorded graph 0.148 -> 0.187: the two
+// cross-stream waits cost more than a frame's tails.  So the fork is taken from kSideStreamMinPixels up (three 1080p
+// frames), never inside a recording, never with the stage timers on (they bracket launches on one stream).
+constexpr size_t kSideStreamMinPixels = 6u << 20;
+static bool wants_side_stream(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h) {
+  const int mode = ctx->knobs.octave_overlap;
+  if (mode == 0 || ctx->timing || ctx->knobs.force_generic || ctx->side_failed) return false;
+  if (!prm || !prm->fused_detect || n_images < 1 || n_images > kMaxFlatImages) return false;
+  if (mode == 2) return true;  // tests: whatever the size, also inside a recording
+  if (ctx->recording) return false;
+  return prm->concurrent_batches < 2 && (size_t)n_images * (size_t)w * (size_t)h >= kSideStreamMinPixels;
+}
+
+// A second stream only helps if the device runs it BESIDE the context's stream.  HIP maps streams onto a few hardware
+// queues (GPU_MAX_HW_QUEUES, 4 by default) in the order of their first use, and the queues onto the compute pipes of
+// the command processor round robin.  Two streams on one hardware queue run one after the other; two queues on one
+// pipe run their kernels at the same time but the pipe serves one queue's packets while the other queue's wait, ~15 us
+// each -- worse than one queue for a chain of short launches (measured, 64 x 1080p: 1.29-1.35 ms beside each other, 1.55
+// on one queue, 1.88 on one pipe: four streams in use before this one and 8 hardware queues).  Which case a new stream
+// lands in depends on what else the process has created -- so the context finds out: a chain of sixteen 5 us probe
+// kernels on its own stream is timed alone and while a 120 us probe runs on the candidate, and the candidate is kept
+// only if the chain takes about as long in both cases.  Up to four candidates (consecutive hardware queues sit on
+// different pipes); if none passes, the context never forks.  One-time cost: under a millisecond and a wait for the
+// context's stream, at the first call that would fork.
+__global__ void __launch_bounds__(64) spin_kernel(long ticks) {
+  const long t0 = (long)wall_clock64();  // the 100 MHz constant clock
+  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+static int ensure_side_stream(cusift_ctx *ctx) {
+  if (ctx->side) return CUSIFT_OK;
+  if (ctx->side_failed) return fail(CUSIFT_ERR_HIP, "no side stream runs beside the context's stream");
+  if (!ctx->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  if (!ctx->ev_join) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  constexpr int kChain = 16;
+  constexpr long kShort = 500, kLong = 12000;  // 5 us, 120 us
+  int rc = CUSIFT_OK;
+  hipStream_t rejected[4] = {nullptr, nullptr, nullptr, nullptr};  // kept alive until the end so that each try is a NEW queue
+  int n_rejected = 0;
+  for (int attempt = 0; attempt < 4 && !ctx->side && rc == CUSIFT_OK; ++attempt) {
+    hipStream_t cand = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      rc = fail(CUSIFT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+      break;
+    }
+    float alone = 1e30f, beside_ms = 1e30f;
+    auto chain = [&](bool with_candidate, float &best) -> hipError_t {
+      hipError_t err;
+      if ((err = hipStreamSynchronize(cand)) != hipSuccess) return err;
+      if ((err = hipStreamSynchronize(ctx->stream)) != hipSuccess) return err;
+      if ((err = hipEventRecord(e0, ctx->stream)) != hipSuccess) return err;
+      if (with_candidate) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand, kLong);
+      for (int k = 0; k < kChain; ++k) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, ctx->stream, kShort);
+      if ((err = hipEventRecord(e1, ctx->stream)) != hipSuccess) return err;
+      if ((err = hipEventSynchronize(e1)) != hipSuccess) return err;
+      float ms = 0.f;
+      if ((err = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return err;
+      best = std::min(best, ms);
+      return hipStreamSynchronize(cand);
+    };
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand, 1L);  // first use: the candidate's hardware queue is created here
+    for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
+      e = chain(false, alone);
+      if (e == hipSuccess) e = chain(true, beside_ms);
+    }
+    if (e != hipSuccess) {
+      (void)hipStreamDestroy(cand);
+      rc = fail(CUSIFT_ERR_HIP, "side stream probe failed: %s", hipGetErrorString(e));
+      break;
+    }
+    const bool beside = beside_ms < 1.25f * std::max(alone, 0.08f);
+    if (ctx->knobs.side_debug)
+      fprintf(stderr, "cusift: side stream candidate %d: probe chain alone %.1f us, beside the candidate %.1f us -> %s\n",
+              attempt, alone * 1e3f, beside_ms * 1e3f, beside ? "kept" : "rejected");
+    if (beside)
+      ctx->side = cand;
+    else
+      rejected[n_rejected++] = cand;
+  }
+  if (!ctx->side && rc == CUSIFT_OK && ctx->knobs.octave_overlap == 2 && n_rejected > 0)
+    ctx->side = rejected[--n_rejected];  // forced (tests of the forked driver): any stream will do
+  for (int i = 0; i < n_rejected; ++i) (void)hipStreamDestroy(rejected[i]);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc == CUSIFT_OK && !ctx->side) rc = fail(CUSIFT_ERR_HIP, "no side stream runs beside the context's stream");
+  if (rc != CUSIFT_OK) ctx->side_failed = true;  // the callers go on with one stream
+  return rc;
+}
+
 extern "C" void cusift_default_params(cusift_params *p) {
   if (!p) return;
   p->num_octaves = 5;
@@ -493,6 +616,12 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
   if (ctx->match_scratch) (void)hipFree(ctx->match_scratch);
   if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
   if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipStreamDestroy(ctx->side);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return CUSIFT_OK;
@@ -524,12 +653,13 @@ extern "C" int cusift_ctx_wait(cusift_ctx *ctx, cusift_ctx *other) {
 extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p) {
   TRY(enter(ctx));
   Plan pl;
-  TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p));
+  TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p, wants_side_stream(ctx, p, n_images, w, h)));
   // + one pitched upload image for cusift_extract_host
   return ensure_arena(ctx, pl.total + align_up_sz((size_t)h * ialign_up(w, 128) * sizeof(float), 256));
 }
 
 extern "C" size_t cusift_ctx_arena_bytes(cusift_ctx *ctx) { return ctx ? ctx->arena_bytes + ctx->dog_bytes : 0; }
+extern "C" unsigned long cusift_ctx_forks(cusift_ctx *ctx) { return ctx ? ctx->forks : 0; }
 
 extern "C" int cusift_ctx_timing_enable(cusift_ctx *ctx, int on) {
   TRY(enter(ctx));
@@ -564,7 +694,7 @@ extern "C" int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, i
   int n = 0, t = 256;
   hipError_t e = hipErrorInvalidValue;
   if (k == "detect_fused")  // single-wave workgroups, a 10.5 KB candidate list each
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false>, t = 64,
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false, (int)sizeof(cusift_point)>, t = 64,
                                                      kDetectWaveLdsFloats * sizeof(float));
   else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel<0>, t, 0);
   else if (k == "find_points") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, find_points_fast_kernel, t, 0);
@@ -872,7 +1002,9 @@ static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t 
 static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
                        float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
                        unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end,
-                       int concurrent = 1) {
+                       int concurrent = 1, bool staged = false) {
+  // staged: `d_points` is the context's staging list (kStagedRecBytes per keypoint) and the launch goes to the side
+  // stream (cusift_extract_batch: octave 0 beside the coarser octaves)
   TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -919,12 +1051,12 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   for (int lv = 0; lv < 2; ++lv)
     for (int j = 0; j < 9; ++j) ident0 = ident0 && (taps[16 * lv + j] == (j == kBlurRadius ? 1.0f : 0.0f));
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
-  if (ident0 && !ctx->knobs.no_ident)
-    hipLaunchKernelGGL(detect_fused_kernel<true>, grid, dim3(64 * wpb), cube_bytes, ctx->stream, d_img, w, h, pitch,
-                       (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
-  else
-    hipLaunchKernelGGL(detect_fused_kernel<false>, grid, dim3(64 * wpb), cube_bytes, ctx->stream, d_img, w, h, pitch,
-                       (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
+  constexpr int kWhole = (int)sizeof(cusift_point);
+  const bool ident = ident0 && !ctx->knobs.no_ident;
+  auto kernel = staged ? (ident ? detect_fused_kernel<true, kStagedRecBytes> : detect_fused_kernel<false, kStagedRecBytes>)
+                       : (ident ? detect_fused_kernel<true, kWhole> : detect_fused_kernel<false, kWhole>);
+  hipLaunchKernelGGL(kernel, grid, dim3(64 * wpb), cube_bytes, staged ? ctx->side : ctx->stream, d_img, w, h, pitch,
+                     (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   return check_launch("detect_multi");
 }
 
@@ -1257,7 +1389,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   if (!d_imgs || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "extract: missing data");
   if (n_images > 1 && image_stride < (size_t)h * pitch) return fail(CUSIFT_ERR_INVALID, "image_stride too small");
   Plan pl;
-  TRY(make_plan(pl, n_images, w, h, pitch, prm));
+  TRY(make_plan(pl, n_images, w, h, pitch, prm, wants_side_stream(ctx, prm, n_images, w, h)));
   TRY(ensure_arena(ctx, pl.total));
   if (const size_t dog_need = two_stage_dog_bytes(ctx, pl, prm, d_imgs, image_stride, ctx->arena, n_images))
     TRY(ensure_dog(ctx, dog_need));  // sized once for the largest two-stage octave, before anything is enqueued
@@ -1270,14 +1402,6 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   size_t stride[kMaxOctaves];
   base[0] = d_imgs;
   stride[0] = image_stride;
-  // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest
-  for (int o = 1; o < pl.n_oct; ++o) {
-    float *dst = (float *)(ctx->arena + pl.base_off[o]);
-    stride[o] = (size_t)pl.h[o] * pl.p[o];
-    TRY(cusift_scale_down(ctx, dst, pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1], pl.p[o - 1],
-                          stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
-    base[o] = dst;
-  }
   unsigned int *first = (unsigned int *)(ctx->arena + pl.first_off);
   // With fused_detect the keypoint stages run once, after the last octave's detection, over the flattened list
   // of all keypoints of the batch (describe_all_kernel); otherwise per octave like the reference.  The DETECTION
@@ -1286,31 +1410,75 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   // no longer demotes the others.
   const bool generic = ctx->knobs.force_generic;
   const bool flat = prm->fused_detect && n_images <= kMaxFlatImages && !generic;
-  // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
-  for (int o = pl.n_oct - 1; o >= 0; --o) {
-    if (!(prm->lowest_scale < pl.sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
-    // ExtractSiftOctave, cuSIFT.cu:204-270
-    unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
-    if (!flat)
-      HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
-    if (prm->fused_detect && !generic && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o])) {
-      TRY(detect_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], prm->peak_thresh,
-                      prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters, n_images,
-                      RowWindow{0, pl.h[o]}, 0, pl.h[o], prm->concurrent_batches));
-    } else {
-      const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
-      float *dog = ctx->dog;
-      TRY(cusift_laplace_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], dog, dstride,
-                               n_images));
-      TRY(cusift_find_points_multi(ctx, dog, pl.w[o], pl.h[o], pl.p[o], dstride, prm->peak_thresh, prm->edge_thresh,
-                                   pl.sub[o], d_points, prm->max_pts, d_counters, n_images));
-    }
-    if (flat) continue;
-    TRY(cusift_compute_orientations(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
-                                    d_counters, prm->tex_frac_bits, n_images));
-    TRY(descriptors_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst, d_counters,
-                         pl.sub[o], prm->tex_frac_bits, n_images, RowWindow{0, pl.h[o]}, prm->root_sift));
+  auto searched = [&](int o) { return prm->lowest_scale < pl.sub[o] * 2.0f; };  // cuSIFT.cu:194
+
+  // fork: octave 0's detection to the side stream, if it and a coarser octave are searched at all
+  bool forked = flat && pl.staged && searched(0) && detect_fused_ok(d_imgs, w, h, pitch, image_stride);
+  if (forked) {
+    forked = false;
+    for (int o = 1; o < pl.n_oct; ++o) forked = forked || searched(o);
   }
+  unsigned int *side_counts = first, *in_place = first + n_images;  // `first` is free when the keypoint stages run once
+  char *staged = ctx->arena + pl.staged_off;
+  if (forked && ensure_side_stream(ctx) != CUSIFT_OK) forked = false;  // no stream runs beside this one: one stream
+  if (forked) {
+    ctx->forks++;
+    HIP_TRY(hipMemsetAsync(side_counts, 0, sizeof(unsigned int) * n_images, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    const int rc = detect_impl(ctx, d_imgs, w, h, pitch, image_stride, (float)pl.blur[0], prm->peak_thresh,
+                               prm->edge_thresh, pl.sub[0], reinterpret_cast<cusift_point *>(staged), prm->max_pts,
+                               side_counts, n_images, RowWindow{0, h}, 0, h, 1, true);
+    const hipError_t e = hipEventRecord(ctx->ev_join, ctx->side);
+    if (rc != CUSIFT_OK || e != hipSuccess) {
+      (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);  // never leave the side stream forked (a capture would not end)
+      if (rc != CUSIFT_OK) return rc;
+      HIP_TRY(e);
+    }
+  }
+  // the side stream rejoins the context's stream however the work in between ends
+  auto on_main = [&]() -> int {
+    // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest
+    for (int o = 1; o < pl.n_oct; ++o) {
+      float *dst = (float *)(ctx->arena + pl.base_off[o]);
+      stride[o] = (size_t)pl.h[o] * pl.p[o];
+      TRY(cusift_scale_down(ctx, dst, pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1], pl.p[o - 1],
+                            stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
+      base[o] = dst;
+    }
+    // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
+    for (int o = pl.n_oct - 1; o >= (forked ? 1 : 0); --o) {
+      if (!searched(o)) continue;
+      // ExtractSiftOctave, cuSIFT.cu:204-270
+      unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
+      if (!flat)
+        HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
+      if (prm->fused_detect && !generic && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o])) {
+        TRY(detect_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], prm->peak_thresh,
+                        prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters, n_images,
+                        RowWindow{0, pl.h[o]}, 0, pl.h[o], forked ? 1 : prm->concurrent_batches));
+      } else {
+        const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
+        float *dog = ctx->dog;
+        TRY(cusift_laplace_multi(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], dog, dstride,
+                                 n_images));
+        TRY(cusift_find_points_multi(ctx, dog, pl.w[o], pl.h[o], pl.p[o], dstride, prm->peak_thresh, prm->edge_thresh,
+                                     pl.sub[o], d_points, prm->max_pts, d_counters, n_images));
+      }
+      if (flat) continue;
+      TRY(cusift_compute_orientations(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst,
+                                      d_counters, prm->tex_frac_bits, n_images));
+      TRY(descriptors_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], d_points, prm->max_pts, fst, d_counters,
+                           pl.sub[o], prm->tex_frac_bits, n_images, RowWindow{0, pl.h[o]}, prm->root_sift));
+    }
+    return CUSIFT_OK;
+  };
+  const int rc_main = on_main();
+  if (forked) {
+    const hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    if (rc_main == CUSIFT_OK) HIP_TRY(e);
+  }
+  if (rc_main != CUSIFT_OK) return rc_main;
   if (flat) {
     OctaveTable T;
     memset(&T, 0, sizeof(T));
@@ -1337,11 +1505,18 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     // a multiple of the shard count (the kernel deals items to shards by workgroup index)
     const long want = std::max(1L, std::min(cap, (long)ctx->describe_grid));
     dim3 grid((unsigned int)std::max<long>(kQueueShards, want / kQueueShards * kQueueShards));
-    unsigned int *queue = ctx->d_queue;  // the kernel's work cursors
-    HIP_TRY(hipMemsetAsync(queue, 0, kQueueShards * 128, ctx->stream));
+    unsigned int *queue = ctx->d_queue;  // the kernel's work cursors, zero at launch
+    if (forked) {
+      hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counters, side_counts, in_place,
+                         n_images, prm->max_pts, queue);
+      TRY(check_launch("join_counts"));
+    } else {
+      HIP_TRY(hipMemsetAsync(queue, 0, kQueueShards * 128, ctx->stream));
+    }
     StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
     hipLaunchKernelGGL(describe_all_kernel, grid, dim3(64), 0, ctx->stream, T, d_points, prm->max_pts, d_counters,
-                       n_images, q, inv_q, prm->root_sift, queue);
+                       n_images, q, inv_q, prm->root_sift, queue, forked ? in_place : (const unsigned int *)nullptr,
+                       (const char *)staged);
     TRY(check_launch("describe_all"));
   }
   return CUSIFT_OK;
@@ -1366,8 +1541,18 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
   TRY(enter(ctx));
   *out = nullptr;
   if (!ctx->stream) return fail(CUSIFT_ERR_INVALID, "graph capture needs a real stream (the context borrows the null stream)");
+  // For the length of this call the context is "recording": no stage-timer events (they are not part of a recording)
+  // and the one-stream launch sequence (wants_side_stream) -- the plan below is the one cusift_extract_batch will make.
+  struct Recording {
+    cusift_ctx *c;
+    bool timing;
+    explicit Recording(cusift_ctx *ctx) : c(ctx), timing(ctx->timing) { c->timing = false; c->recording = true; }
+    ~Recording() { c->timing = timing; c->recording = false; }
+  } recording(ctx);
   Plan pl;
-  TRY(make_plan(pl, n_images, w, h, pitch, prm));
+  // the side stream is found (and probed: that waits) before the capture starts; the fork and the join become edges
+  const bool fork = wants_side_stream(ctx, prm, n_images, w, h) && ensure_side_stream(ctx) == CUSIFT_OK;
+  TRY(make_plan(pl, n_images, w, h, pitch, prm, fork));
   // everything that allocates or synchronises happens before the capture starts
   TRY(ensure_arena(ctx, pl.total));
   // the DoG planes of every octave that takes the two-stage path (see cusift_extract_batch), sized up front
@@ -1380,19 +1565,15 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
     ctx->describe_grid = std::max(1, per_cu) * std::max(1, cus);
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  const bool timing = ctx->timing;
-  ctx->timing = false;  // event records are not part of the recording
   cusift_graph *g = new cusift_graph();
   g->ctx = ctx;
   hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) {
-    ctx->timing = timing;
     delete g;
     return fail(CUSIFT_ERR_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
   }
   const int rc = cusift_extract_batch(ctx, d_imgs, n_images, w, h, pitch, image_stride, prm, d_points, d_counters);
   e = hipStreamEndCapture(ctx->stream, &g->graph);
-  ctx->timing = timing;
   if (rc != CUSIFT_OK || e != hipSuccess || !g->graph) {
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
@@ -1459,7 +1640,7 @@ extern "C" int cusift_extract_host(cusift_ctx *ctx, const float *h_img, int w, i
   if (w < 1 || h < 1) return fail(CUSIFT_ERR_INVALID, "bad image size %dx%d", w, h);
   const int pitch = ialign_up(w, 128);  // cuImage::AllocateWithHostMemory, cuImage.cu:11-13
   Plan pl;
-  TRY(make_plan(pl, 1, w, h, pitch, prm));
+  TRY(make_plan(pl, 1, w, h, pitch, prm, wants_side_stream(ctx, prm, 1, w, h)));  // the plan cusift_extract_batch will make
   const size_t img_bytes = align_up_sz((size_t)h * pitch * sizeof(float), 256);
   TRY(ensure_arena(ctx, pl.total + img_bytes));
   float *d_img = (float *)(ctx->arena + pl.total);

@@ -769,7 +769,13 @@ __device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, c
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) describe_all_kernel(OctaveTable T, cusift_point *__restrict__ points, int max_pts,
                                                          const unsigned int *__restrict__ counters, int n_images,
                                                          float q, float inv_q, int root_sift,
-                                                         unsigned int *__restrict__ queue) {
+                                                         unsigned int *__restrict__ queue,
+                                                         const unsigned int *__restrict__ in_place,
+                                                         const char *__restrict__ staged) {
+  // `in_place` (may be NULL: everything is): per image, how many of its keypoints were appended to `points` directly.
+  // The rest -- octave 0's, when cusift_extract_batch ran that octave's detection beside the coarser ones -- wait as
+  // record heads in the context's staging list `staged` ([image][max_pts] x kStagedRecBytes) and are moved behind
+  // them here: keypoint k >= in_place[i] of image i is staged record k - in_place[i].
   __shared__ KpShared S;
   __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
   const int lane = threadIdx.x;
@@ -806,24 +812,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   unsigned int *cursor = queue + shard * 32;                 // 128-byte stride
   const unsigned int per_shard = gridDim.x / kQueueShards;   // workgroups per shard (host: gridDim.x % shards == 0)
   unsigned int g = blockIdx.x;                               // = shard + kQueueShards * (blockIdx.x / kQueueShards)
-  auto locate = [&](unsigned int item) {  // item < total; moves `im` forward to the item's image
+  // item < total; moves `im` forward to the item's image.  Returns the record the keypoint ends up in; `src` is where its
+  // head waits (the same record, or a staged one)
+  auto locate = [&](unsigned int item, const cusift_point *&src) {
     while (__builtin_amdgcn_readfirstlane(s_prefix[im + 1]) <= item) ++im;  // ends: item < total = s_prefix[n_images]
-    return points + (long)im * max_pts + (item - __builtin_amdgcn_readfirstlane(s_prefix[im]));
+    const unsigned int idx = item - __builtin_amdgcn_readfirstlane(s_prefix[im]);
+    cusift_point *dst = points + (long)im * max_pts + idx;
+    src = dst;
+    if (in_place) {
+      const unsigned int direct = in_place[im];  // wave-uniform: a scalar load
+      if (idx >= direct)
+        src = reinterpret_cast<const cusift_point *>(staged + ((size_t)im * max_pts + (idx - direct)) * kStagedRecBytes);
+    }
+    return dst;
   };
   // lane l < 16 holds float l of the record's head (coords2D, scale, ..., subsampling = float 12): one register
   constexpr int kSubIndex = (int)(offsetof(cusift_point, subsampling) / sizeof(float));
   static_assert(kSubIndex < 16 && offsetof(cusift_point, scale) == 8, "record head layout");
   cusift_point *pt = nullptr;
+  const cusift_point *src = nullptr;
   float rec = 0.0f;
   auto fetch_head = [&](const cusift_point *p) { return reinterpret_cast<const float *>(p)[lane & 15]; };
   auto head = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rec), i)); };
+  constexpr int kSharpIndex = (int)(offsetof(cusift_point, sharpness) / sizeof(float));
+  constexpr int kEdgeIndex = (int)(offsetof(cusift_point, edgeness) / sizeof(float));
   if (g < total) {
-    pt = locate(g);
-    rec = fetch_head(pt);
+    pt = locate(g, src);
+    rec = fetch_head(src);
   }
   while (g < total) {
     unsigned int nxt = 0;
     if (lane == 0) nxt = shard + kQueueShards * (atomicAdd(cursor, 1u) + per_shard);
+    // a staged keypoint: the three fields of the head that detection wrote and nothing below rewrites
+    if (src != pt && (lane == kSharpIndex || lane == kEdgeIndex || lane == kSubIndex))
+      reinterpret_cast<float *>(pt)[lane] = rec;
     const float px = head(0), py = head(1), kscale = head(2), sub = head(kSubIndex);
     const int im_cur = im;
     int o = ((__float_as_int(sub) >> 23) & 0xff) - exp0;  // subsampling = sub0 * 2^octave
@@ -845,8 +867,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     g = __builtin_amdgcn_readfirstlane(nxt);
     cusift_point *pt_next = nullptr;
     if (g < total) {
-      pt_next = locate(g);
-      rec = fetch_head(pt_next);
+      pt_next = locate(g, src);
+      rec = fetch_head(src);
     }
     if (use_patch) {
       if (q > 0.0f)
@@ -860,6 +882,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     wave_sync();
     pt = pt_next;
+  }
+}
+
+// Joins the two keypoint lists of a batch whose octave 0 was searched beside the coarser octaves: `counters` (the caller's;
+// the coarser octaves' keypoints are in place behind them) and `side_counts` (octave 0's, staged).  in_place[i] = what
+// of image i is in place; counters[i] becomes the image's total as one stream would have left it (it keeps counting
+// beyond max_pts, like the reference's).  Also clears the work cursors of describe_all_kernel, which runs next.
+__global__ void __launch_bounds__(256) join_counts_kernel(unsigned int *__restrict__ counters,
+                                                          const unsigned int *__restrict__ side_counts,
+                                                          unsigned int *__restrict__ in_place, int n_images, int max_pts,
+                                                          unsigned int *__restrict__ queue) {
+  for (int i = threadIdx.x; i < kQueueShards * 32; i += 256) queue[i] = 0u;
+  for (int i = threadIdx.x; i < n_images; i += 256) {
+    const unsigned int c = counters[i];
+    in_place[i] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
+    counters[i] = c + side_counts[i];
   }
 }
 

@@ -819,7 +819,10 @@ struct CandList {
     return e;
   }
   // refines the last min(n, 64) entries and appends the accepted ones to the image's SiftData
-  __device__ __forceinline__ void refine_batch(cusift_point *__restrict__ pts, int max_pts, unsigned int *counter,
+  // kRecBytes: the stride of the destination list -- sizeof(cusift_point), or kStagedRecBytes when the points go to the
+  // context's staging list (heads only, see cusift_extract_batch) -- a record's head has the same layout in both
+  template <int kRecBytes>
+  __device__ __forceinline__ void refine_batch(char *__restrict__ pts, int max_pts, unsigned int *counter,
                                                const FindParams &P, int lane) {
     const int cnt = n < 64 ? n : 64;  // wave-uniform
     if (cnt == 0) return;
@@ -846,7 +849,7 @@ struct CandList {
     base = __builtin_amdgcn_readfirstlane(base);
     const unsigned int idx = base + (unsigned int)rank;
     if (accept && idx < (unsigned int)max_pts) {
-      cusift_point *pt = pts + idx;
+      cusift_point *pt = reinterpret_cast<cusift_point *>(pts + (size_t)idx * kRecBytes);
       pt->coords2D[0] = r.x;
       pt->coords2D[1] = r.y;
       pt->scale = r.scale;
@@ -857,7 +860,7 @@ struct CandList {
   }
 };
 
-template <bool kIdent0>
+template <bool kIdent0, int kRecBytes>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
                                                           long img_stride, cusift_point *__restrict__ points,
                                                           int max_pts, unsigned int *__restrict__ counters,
@@ -875,7 +878,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
   const int yb = min(min(gy0 + rows_per_wave, rw.hg - 1), cy_end) - rw.row0;  // local centres [ya, yb)
   if (ya >= yb) return;                                                         // wave-uniform
   img += (long)bz * img_stride;
-  points += (long)bz * max_pts;
+  char *const list = reinterpret_cast<char *>(points) + (size_t)bz * max_pts * kRecBytes;
   unsigned int *counter = counters + bz;
   CandList cands{s_cands + wv * kDetectWaveLdsFloats, 0};
 
@@ -1020,7 +1023,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
                 e[20] = __builtin_bit_cast(float, ((y + rw.row0) << 3) | k);
               }
               if (cands.n >= 64) {
-                cands.refine_batch(points, max_pts, counter, P, lane);
+                cands.refine_batch<kRecBytes>(list, max_pts, counter, P, lane);
               }
             };
             column(std::integral_constant<int, 0>{});
@@ -1050,13 +1053,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
     if (yy + 2 > yb) break;
     row_step(yy + 2, DC, DA, DB);
   }
-  cands.refine_batch(points, max_pts, counter, P, lane);  // what is left of the chunk's candidates (fewer than 64)
+  cands.refine_batch<kRecBytes>(list, max_pts, counter, P, lane);  // what is left of the chunk's candidates (fewer than 64)
 }
 
 
-template __global__ void detect_fused_kernel<false>(const float *, int, int, int, long, cusift_point *, int,
-                                                    unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, int, int);
-template __global__ void detect_fused_kernel<true>(const float *, int, int, int, long, cusift_point *, int,
-                                                   unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, int, int);
+#define CUSIFT_DETECT_INSTANCE(IDENT, REC)                                                                         \
+  template __global__ void detect_fused_kernel<IDENT, REC>(const float *, int, int, int, long, cusift_point *, int,  \
+                                                           unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, \
+                                                           int, int);
+CUSIFT_DETECT_INSTANCE(false, (int)sizeof(cusift_point))
+CUSIFT_DETECT_INSTANCE(true, (int)sizeof(cusift_point))
+CUSIFT_DETECT_INSTANCE(false, kStagedRecBytes)
+CUSIFT_DETECT_INSTANCE(true, kStagedRecBytes)
+#undef CUSIFT_DETECT_INSTANCE
 
 }  // namespace cusift

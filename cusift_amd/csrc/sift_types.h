@@ -58,6 +58,7 @@ struct RowWindow {
 // Per-octave base images of a batch, passed by value to describe_all_kernel (driver path).
 constexpr int kMaxFlatImages = 256;  // batch size up to which the flattened keypoint kernel is used
 constexpr int kDetectWaveLdsFloats = 128 * 21;  // detect_fused_kernel: candidate list per wave (128 entries of 21 words)
+constexpr int kStagedRecBytes = 64;   // a staged keypoint: the first 16 floats of a cusift_point (coords2D .. subsampling)
 constexpr int kQueueShards = 64;      // work cursors of describe_all_kernel (a power of two)
 struct OctaveTable {
   const float *base[kMaxOctaves];  // image 0 of octave o

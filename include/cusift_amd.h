@@ -77,7 +77,10 @@ typedef struct cusift_params {
                           flight on this device at once (one context + stream each).  1 (default): this call has the
                           GPU to itself -- the detection launches use short row chunks so that their tails stay
                           short; >= 2: other batches fill the tails, so tall chunks (less redundant blurring at chunk
-                          borders) are faster.  cusift_amd.batch.PipelinedExtractor sets it to its stream count. */
+                          borders) are faster.  cusift_amd.batch.PipelinedExtractor sets it to its stream count.
+                          With 1 a call of three 1080p frames' worth of pixels or more also runs octave 0's detection
+                          on a second stream of the context, beside the ScaleDown chain and the coarser octaves
+                          (cusift_ctx_forks; same SiftData, coarsest octave first). */
 } cusift_params;
 
 typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */
@@ -110,6 +113,9 @@ int cusift_ctx_wait(cusift_ctx *ctx, cusift_ctx *other);
 int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p);
 /* Bytes of HBM currently held by the arena. */
 size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
+/* How many extractions of this context ran octave 0's detection on the context's second stream (see
+ * cusift_params.concurrent_batches; $CUSIFT_OCTAVE_OVERLAP, read when the context is created: 0 never, 2 always). */
+unsigned long cusift_ctx_forks(cusift_ctx *ctx);
 /* Per-stage GPU timing with HIP events on the context's stream (TimerGPU, cutils.h:94-114, used at
  * cuSIFT.cu:64,177,208,238,249).  Stages: 0 ScaleDown, 1 LaplaceMulti, 2 FindPointsMulti,
  * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call, 6 fused detection, 7 orientation+descriptor of all octaves in one launch.  Accumulates
