@@ -633,29 +633,45 @@ def main():
                      "ms_per_step": round(ms / K, 4),
                      "hbm_traffic_bytes_per_launch": traffic.get(kernel, {}).get("hbm_bytes_per_launch"),
                      "note": note}
-                # The spec peak prices every wave-instruction at 4 cycles per SIMD; this kernel's instructions cost more
-                # (packed fp32 ~6.9, two-VGPR-source and DPP ~4.7: tools/microbench/valu_rate.hip).  Issue bound = PMC
-                # instruction count x the mix-weighted cycles per instruction (static mix of the hot loop blocks from the
-                # ISA, tools/isa_mix.py) / (1024 SIMDs x 2.4 GHz): the time the SIMDs need just to ISSUE the kernel.
+                # The spec peak prices every wave-instruction at 2 cycles per SIMD; only the plain fp32 / integer add,
+                # multiply, fma, logic and move forms with no SGPR operand come near it (2.65), every other form --
+                # packed, DPP, min / max, compare, select, convert, anything that reads an SGPR -- costs 4.2 and a
+                # transcendental 8.2 (tools/microbench/valu_rate.hip, profiles/r03/valu_rate_forms.txt).  Issue bound =
+                # PMC instruction count x the mix-weighted cycles per instruction (static mix of the hot loop blocks from
+                # the ISA, tools/isa_mix.py) / (1024 SIMDs x 2.4 GHz): the time the SIMDs need just to ISSUE the kernel
+                # -- at the best the hardware does per class (eight waves per SIMD), and at what the classes cost with
+                # the kernel's own number of resident waves.
                 mix = isa_mix.get(kernel)
-                if mix:
-                    cpi, detail = mix["cycles_per_instruction_mix_weighted"], {"mix": mix["mix"]}
+                if mix and "cycles_per_instruction_at_occupancy" in mix:
+                    keys = ("cycles_per_instruction_mix_weighted", "cycles_per_instruction_at_occupancy")
+                    cpi = [mix[k] for k in keys]
+                    detail = {"mix": mix["mix"]}
                     ana = mix.get("analysis")
                     if ana:  # fused detection: every wave-row runs the blur blocks, a fraction p of them the analysis
                         p_pass = 1.0 - PRETEST_SKIP_HEADLINE
                         nb, na = mix["instructions_per_row_step"], ana["instructions_per_row_step"]
-                        cpi = (nb * cpi + p_pass * na * ana["cycles_per_instruction_mix_weighted"]) / (nb + p_pass * na)
+                        cpi = [(nb * mix[k] + p_pass * na * ana[k]) / (nb + p_pass * na) for k in keys]
                         detail = {"blur_blocks": {"instructions_per_row": nb, "mix": mix["mix"],
-                                                  "cycles_per_instruction": mix["cycles_per_instruction_mix_weighted"]},
+                                                  "cycles_per_instruction": mix[keys[0]],
+                                                  "cycles_per_instruction_at_occupancy": mix[keys[1]]},
                                   "analysis_blocks": {"instructions_per_row": na, "mix": ana["mix"],
-                                                      "cycles_per_instruction": ana["cycles_per_instruction_mix_weighted"],
+                                                      "cycles_per_instruction": ana[keys[0]],
+                                                      "cycles_per_instruction_at_occupancy": ana[keys[1]],
                                                       "rows_that_run_them": round(p_pass, 3)}}
-                    bound_ms = insts_per_step * cpi / (1024 * 2.4e9) * 1e3
-                    r["issue_bound"] = dict(detail, cycles_per_wave_instruction=round(cpi, 3),
-                                            waves_per_simd=mix["waves_per_simd"], bound_ms_per_step=round(bound_ms, 4),
-                                            frac_of_issue_bound=round(bound_ms / (ms / K), 4),
-                                            note="bound_ms / measured ms: 1.0 = the vector pipes issue back to back; "
-                                                 "the mix is a static estimate (profiles/isa_mix.json)")
+                    bound_ms = [insts_per_step * c / (1024 * 2.4e9) * 1e3 for c in cpi]
+                    r["issue_bound"] = dict(detail, cycles_per_wave_instruction=round(cpi[0], 3),
+                                            cycles_per_wave_instruction_at_occupancy=round(cpi[1], 3),
+                                            waves_per_simd=mix["waves_per_simd"],
+                                            bound_ms_per_step=round(bound_ms[0], 4),
+                                            frac_of_issue_bound=round(bound_ms[0] / (ms / K), 4),
+                                            bound_ms_per_step_at_occupancy=round(bound_ms[1], 4),
+                                            frac_at_own_occupancy=round(bound_ms[1] / (ms / K), 4),
+                                            note="bound_ms / measured ms: 1.0 = the vector pipes issue back to back.  "
+                                                 "frac_of_issue_bound prices each class at the best the SIMD does for "
+                                                 "it (eight resident waves), frac_at_own_occupancy at its cost with "
+                                                 "this kernel's resident waves (two waves: a slow-class instruction "
+                                                 "4.6-5.7 cycles by run, 5.1 used); the mix is a static estimate "
+                                                 "(profiles/isa_mix.json)")
                 return r
 
             rk = []

@@ -23,9 +23,9 @@ HIPCC_FLAGS = [
     "-O3",
     "-std=c++17",
     "-ffp-contract=off",
-    # no automatic packing of adjacent scalar fp32 operations into v_pk_*_f32: on gfx950 a packed operation costs more
-    # than the two plain ones it replaces (tools/microbench/valu_rate.hip: 6.3-6.9 vs 2 x 2.7-3.0 cycles per SIMD);
-    # the keypoint kernel is 2.7 % faster without it.  The blur kernels pack BY HAND (scale pairs, one SGPR tap pair
+    # no automatic packing of adjacent scalar fp32 operations into v_pk_*_f32: measured, the keypoint kernel is 2.7 %
+    # faster without it (a packed operation costs 4.2-4.4 cycles per SIMD against 2 x 2.65 for two plain ones without an
+    # SGPR operand -- tools/microbench/valu_rate.hip -- and the compiler's packing adds v_pk_mov / v_mov_b64 shuffles).  The blur kernels pack BY HAND (scale pairs, one SGPR tap pair
     # per operation) because there the halved instruction count wins (measured both ways).
     "-fno-slp-vectorize",
     "-fPIC",

@@ -5,15 +5,28 @@ the product's flags -- the weights of the mix-weighted ISSUE BOUND bench.py prin
 
     python tools/isa_mix.py            # writes profiles/isa_mix.json (runs here: hipcc cross-compiles without a GPU)
 
-Why: the spec peak prices every wave64 VALU instruction at two cycles per SIMD, which no instruction of these kernels
-reaches.  tools/microbench/valu_rate.hip (profiles/r03/valu_rate_microbench.txt) measures what one SIMD sustains per
-instruction kind; the BEST it does for a kind, with eight waves resident, is what is used here, so that the result is a
-bound whatever the kernel's occupancy: at most one VGPR source 2.40 cycles (v_fma_f32 v, s, s; an integer v_add_u32
-v, s 2.14), two or more VGPR sources 4.18 (v_max3_f32; v_mul_f32 v, v 4.34, v_fma_f32 v, v, v 5.34 -- the cheapest
-stands for the class), a DPP move 4.18, a packed fp32 instruction (v_pk_*_f32) 6.21, transcendental / division helpers
-at quarter rate.  At the kernels' own occupancy (2 / 4 waves per SIMD) the same streams run 3-11 % slower.  The bound for
-a kernel that retires N wave-instructions of a given mix on S SIMDs at clock f is  N * sum_c(frac_c * cycles_c) / (S * f)
-(the microbenchmark's cycles are time at the nominal 2.4 GHz with the whole chip loaded: a time calibration).
+Why: the spec peak prices every wave64 VALU instruction at two cycles per SIMD.  tools/microbench/valu_rate.hip (one
+inline-assembly block per instruction form; profiles/r03/valu_rate_forms.txt) measures what one SIMD of an MI355X
+sustains, and it is a matter of the FORM, not of the number of VGPR operands (the first version of that microbenchmark
+let the compiler choose the instructions and mislabelled half of its rows; the classes and costs used here until then
+-- "one / several VGPR sources", packed at 6.2 cycles -- were wrong):
+
+  fast            2.65 cycles  v_fma / v_fmac / v_add / v_sub / v_mul _f32, v_add / v_sub _u32, v_and / v_or / v_xor,
+                               v_mov_b32 -- with VGPR, inline-constant or literal operands
+  slow            4.2          everything else at "full" rate: ANY of the above with an SGPR operand, v_max / v_min
+                               (2- and 3-input), compares, v_cndmask, conversions, floor, shifts, v_lshl_add, v_add3,
+                               v_mad_*, v_mul_lo, v_bfe, v_perm, v_readlane, every DPP and SDWA form, every packed
+                               (v_pk_*) instruction, v_mov_b64
+  transcendental  8.2          v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos
+
+A lone wave issues one VALU instruction per ~8 cycles whatever the form, so a SIMD needs two resident waves for the
+slow class and three to four for the fast one; with two waves (the fused detection: 224 VGPRs) a slow instruction costs
+4.6-5.7 cycles (it varies from run to run between those two values per form: issue arbitration, not the form) and a
+fast one 2.8-3.2.  Two numbers per kernel therefore: `cycles_per_instruction_mix_weighted` prices the mix at the BEST
+the hardware does for each class (eight waves) -- a bound whatever the occupancy -- and
+`cycles_per_instruction_at_occupancy` at what the classes cost at the kernel's own occupancy.  The bound for a kernel
+that retires N wave-instructions of a given mix on S SIMDs at clock f is  N * sum_c(frac_c * cycles_c) / (S * f)  (the
+microbenchmark's cycles are time at the nominal 2.4 GHz with the whole chip loaded: a time calibration).
 
 Classes are counted over the basic blocks (split at labels AND at the assembler's fall-through block comments) that
 sit INSIDE A LOOP (between a label and a later backward branch to it): the prologue, the window fill and other
@@ -42,13 +55,19 @@ KERNELS = {  # name -> (source, mangled-name needle, block selector)
     "describe_all_kernel": ("sift_keypoints.hip", "describe_all_kernel", "loop"),
     "laplace_multi_fast_kernel": ("sift_stencils.hip", "laplace_multi_fast_kernelILi2E", "loop"),
 }
-# best-case cycles per wave-instruction per SIMD (profiles/r03/valu_rate_microbench.txt, eight resident waves): the
-# same for every kernel -- a bound must not depend on the occupancy the kernel happens to run at
-BEST = {"one_vgpr_src": 2.40, "multi_vgpr_src": 4.18, "dpp": 4.18, "packed": 6.21, "quarter_rate": 4 * 2.40}
-CYCLES = {2: BEST, 4: BEST}
+# cycles per wave-instruction per SIMD by class and resident waves (profiles/r03/valu_rate_forms.txt; "best" = 8 waves)
+BEST = {"fast": 2.65, "slow": 4.2, "transcendental": 8.2}
+CYCLES = {"best": BEST,
+          2: {"fast": 3.0, "slow": 5.1, "transcendental": 8.7},   # slow: 4.6-5.7 by run, fast: 2.8-3.2
+          4: {"fast": 2.75, "slow": 4.5, "transcendental": 8.3}}
 WAVES = {"detect_fused_kernel": 2, "detect_fused_kernel<false>": 2, "describe_all_kernel": 4,
          "laplace_multi_fast_kernel": 4}
-QUARTER = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")  # the transcendental unit
+TRANSCENDENTAL = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
+FAST = ("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32",
+        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32")
+DPP = re.compile(r"\b(row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|wave_rol|quad_perm|row_bcast|row_mirror|"
+                 r"row_half_mirror|row_share|row_xmask|dpp8)\b")
+SCALAR_OPERAND = re.compile(r"^-?\|?(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0|src_\w+|ttmp\d+)")
 
 
 def assembly(src):
@@ -69,20 +88,18 @@ def classify(line):
     if not t.startswith("v_"):
         return None
     op = t.split()[0]
-    if op.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_nop")):
+    if op.startswith(("v_readfirstlane", "v_writelane", "v_nop")):
         return None
-    if op.startswith("v_pk_"):
-        return "packed"
-    if any(op.startswith(q) for q in QUARTER):
-        return "quarter_rate"
-    if re.search(r"\b(row_shr|row_shl|row_ror|wave_shr|wave_shl|wave_ror|wave_rol|quad_perm|row_bcast|row_mirror|"
-                 r"row_half_mirror|row_share|row_xmask|dpp8)\b", t) or "_dpp" in op:
-        return "dpp"
+    if any(op.startswith(q) for q in TRANSCENDENTAL):
+        return "transcendental"
+    if DPP.search(t) or "_dpp" in op or "_sdwa" in op:
+        return "slow"
+    base = re.sub(r"_e(32|64)$", "", op)
+    if base not in FAST:
+        return "slow"
     ops = t[len(op):].split(";")[0]
-    parts = [p.strip() for p in ops.split(",")]
-    srcs = parts if op.startswith("v_cmp") else parts[1:]
-    n = sum(1 for p in srcs if re.match(r"^-?\|?v(\d+|\[\d+:\d+\])", p))
-    return "multi_vgpr_src" if n >= 2 else "one_vgpr_src"
+    srcs = [p.strip() for p in ops.split(",")][1:]
+    return "slow" if any(SCALAR_OPERAND.match(p) for p in srcs) else "fast"
 
 
 def loop_blocks(body):
@@ -130,10 +147,10 @@ def loop_mix(body, selector):
         if selector == "loop":
             add(main, blk)
             n_main += 1
-        elif blk.get("packed"):
+        elif ops.get("v_pk_fma_f32", 0) >= 20:
             add(main, blk)
             n_main += 1
-        elif ops.get("v_min3_f32", 0) >= 20 and not blk.get("quarter_rate"):
+        elif ops.get("v_min3_f32", 0) >= 20 and not blk.get("transcendental"):
             add(ana, blk)
             n_ana += 1
         elif ops.get("v_max3_f32", 0) == 10 and sum(blk.values()) <= 16:  # the threshold pre-test: every row
@@ -143,32 +160,41 @@ def loop_mix(body, selector):
 
 def main():
     out = {"_source": "python tools/isa_mix.py: static VALU class counts over the loop blocks of each kernel (hipcc -S with "
-                      "the product's flags), best-case cycles per class from profiles/r03/valu_rate_microbench.txt",
-           "_cycles_per_wave_instruction_per_simd": CYCLES}
+                      "the product's flags); cycles per class from profiles/r03/valu_rate_forms.txt "
+                      "(tools/microbench/valu_rate.hip: one inline-assembly block per instruction form)",
+           "_cycles_per_wave_instruction_per_simd": {str(k): v for k, v in CYCLES.items()}}
     cache = {}
+
+    def priced(counts, table):
+        n = sum(counts.values())
+        return sum(counts[k] / n * table[k] for k in counts)
+
     for name, (src, needle, selector) in KERNELS.items():
         if src not in cache:
             cache[src] = assembly(src)
         counts, total_all, n_blocks, ana, n_ana = loop_mix(kernel_body(cache[src], needle), selector)
         n = sum(counts.values())
-        cyc = CYCLES[WAVES[name]]
+        own = CYCLES[WAVES[name]]
         frac = {k: round(v / n, 4) for k, v in sorted(counts.items())}
-        avg = sum(counts[k] / n * cyc[k] for k in counts)
         out[name] = {"counted_valu_instructions_static": n, "counted_blocks": n_blocks,
                      "blocks": "blur + DoG + pre-test blocks (every wave-row)" if selector == "detect" else "all loop blocks",
                      "kernel_valu_instructions_static": total_all,
-                     "waves_per_simd": WAVES[name], "mix": frac, "cycles_per_instruction_mix_weighted": round(avg, 3)}
-        print("%-28s loop VALU %5d of %5d  %s  -> %.2f cycles/inst" % (name, n, total_all, frac, avg))
+                     "waves_per_simd": WAVES[name], "mix": frac,
+                     "cycles_per_instruction_mix_weighted": round(priced(counts, BEST), 3),
+                     "cycles_per_instruction_at_occupancy": round(priced(counts, own), 3)}
+        print("%-28s loop VALU %5d of %5d  %s  -> %.2f cycles/inst best, %.2f at %d waves" % (
+            name, n, total_all, frac, priced(counts, BEST), priced(counts, own), WAVES[name]))
         if ana:
             na = sum(ana.values())
-            avg_a = sum(ana[k] / na * cyc[k] for k in ana)
             out[name]["analysis"] = {"counted_valu_instructions_static": na, "counted_blocks": n_ana,
                                      "blocks": "26-neighbour analysis blocks (only wave-rows that pass the pre-test)",
                                      "mix": {k: round(v / na, 4) for k, v in sorted(ana.items())},
-                                     "cycles_per_instruction_mix_weighted": round(avg_a, 3),
+                                     "cycles_per_instruction_mix_weighted": round(priced(ana, BEST), 3),
+                                     "cycles_per_instruction_at_occupancy": round(priced(ana, own), 3),
                                      "instructions_per_row_step": round(na / max(1, n_blocks), 1)}
             out[name]["instructions_per_row_step"] = round(n / max(1, n_blocks), 1)
-            print("%-28s analysis  %5d in %d blocks %s -> %.2f cycles/inst" % ("", na, n_ana, out[name]["analysis"]["mix"], avg_a))
+            print("%-28s analysis  %5d in %d blocks %s -> %.2f best, %.2f at occupancy" % (
+                "", na, n_ana, out[name]["analysis"]["mix"], priced(ana, BEST), priced(ana, own)))
     dst = os.path.join(ROOT, "profiles", "isa_mix.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
