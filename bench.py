@@ -52,7 +52,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # extraction streams busy and, with N > 1, a fifth for the exchange: on four queues the exchange stream shares a queue
 # with an extraction stream, and its waits (for the producer's event, for the peers inside RCCL) block the kernels
 # queued behind them -- measured at one rank (--force-gather --no-self-p2p): 1.325 ms per step on 4 queues, 1.233 on 8,
-# against 1.157 without any exchange.  Read at HIP initialisation, so it has to be set here.
+# against 1.157 without any exchange.  Read at HIP initialisation, so it has to be set here.  (With the exchange the
+# bench also drops to three extraction streams: see `E` in main().)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -266,9 +267,11 @@ def main():
                          % ", ".join(ALL_LEGS))
     ap.add_argument("--two-stage", action="store_true",
                     help="time the reference's two-stage pipeline (DoG planes in HBM) instead of the fused detection")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps alternate over (one extractor each): the HBM-bound ScaleDown chain and "
-                         "the launch tails of one batch overlap the VALU-bound kernels of the next")
+                         "the launch tails of one batch overlap the VALU-bound kernels of the next.  0 (default): four, "
+                         "or three when the step includes the exchange (N > 1, --force-gather) -- with the exchange "
+                         "stream that makes four busy streams, one per pipe of the command processor")
     ap.add_argument("--gather-capacity", type=int, default=8192,
                     help="N > 1: records per image the gathered SiftData buffer is sized for")
     ap.add_argument("--gather-compact", action="store_true",
@@ -340,7 +343,11 @@ def main():
                   lowest_scale=0.0, subsampling=1.0, max_pts=args.max_pts, tex_frac_bits=8)
     # One extractor (context + arena + output slots) per stream; step i runs on stream i % E.  A step is still one
     # whole pass of the hot path over one batch -- consecutive steps merely overlap on the device.
-    E = max(1, args.streams)
+    # The command processor has four compute pipes; hardware queues 1, 5, 9 ... share the first.  A fifth busy stream
+    # (the exchange) lands on a pipe that an extraction stream uses and the two queues' packets wait for each other:
+    # measured at one rank (--force-gather, self send/recv): 4 + 1 streams 1.32-1.33 ms per step, 3 + 1 streams 1.29
+    # (without the exchange four streams win: 1.17 against 1.19).
+    E = args.streams if args.streams > 0 else (3 if use_dist else 4)
     n_slots = 2 if use_dist else 1  # a slot is read by the pack of its step's gather while the next steps are extracted
     pipe = PipelinedExtractor(B, w, h, n_streams=E, n_slots=n_slots,
                               fused_detect=0 if args.two_stage else 1, **prm_kw)
