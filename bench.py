@@ -906,6 +906,23 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     The copy size is a host argument, so a step's counts travel first (4 bytes x images) and its records one step
     later, exactly sized -- no host wait on the extraction streams, and the copies run back to back on their own
     stream (they, not the GPU, bound this leg: ~99 MB per step over PCIe)."""
+    # At most three extraction streams here: with the pack and the copy stream that is five busy streams on the command
+    # processor's four compute pipes -- a sixth made the compact leg a lottery (92-131 M keypoints/s by run with 4 + 2
+    # streams, depending on which queues shared a pipe; 125 M with 3 + 2).
+    all_streams, all_extractors = pipe.streams, pipe.extractors
+    pipe.streams, pipe.extractors = all_streams[:3], all_extractors[:3]
+    for x in pipe.extractors:
+        x.params.concurrent_batches = len(pipe.streams)
+    try:
+        return _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact)
+    finally:
+        pipe.streams, pipe.extractors = all_streams, all_extractors
+        for x in pipe.extractors:
+            x.params.concurrent_batches = len(pipe.streams)
+        torch.cuda.synchronize()
+
+
+def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact):
     pack_stream, copy_stream = torch.cuda.Stream(), torch.cuda.Stream()
     cctx = capi.Context(device_index, stream=pack_stream.cuda_stream)
     cap = int(max(1.5 * total_local_kp, 4096))  # records per step the staging buffers hold
@@ -975,7 +992,7 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     cctx.close()
     return {"ms_per_step": round(dt / K * 1e3, 4), "keypoints_per_s": round(got["records"] / dt, 1),
             "d2h_GBps": round(got["bytes"] / dt / 1e9, 2), "d2h_bytes_per_step": int(got["bytes"] / K),
-            "record_bytes": rec_bytes,
+            "record_bytes": rec_bytes, "extraction_streams": E,
             "note": "device-resident input -> SiftData records in pinned host memory (packed on the device, copied on "
                     "a copy stream, overlapped with the following steps); bounded by the D2H copy when d2h_bytes_per_step "
                     "/ PCIe rate exceeds the extraction time"}
