@@ -463,8 +463,8 @@ static bool wants_side_stream(const cusift_ctx *ctx, const cusift_params *prm, i
 // A second stream only helps if the device runs it BESIDE the context's stream.  HIP maps streams onto a few hardware
 // queues (GPU_MAX_HW_QUEUES, 4 by default) in the order of their first use, and the queues onto the compute pipes of
 // the command processor round robin.  Two streams on one hardware queue run one after the other; two queues on one
-// pipe run their kernels at the same time but the pipe serves one queue's packets while the other queue's wait, ~15 us
-// each -- worse than one queue for a chain of short launches (measured, 64 x 1080p: 1.29-1.35 ms beside each other, 1.55
+// pipe run their kernels at the same time but the pipe serves one queue's packets while the other queue's wait, a few
+// microseconds each -- worse than one queue for a chain of short launches (measured, 64 x 1080p: 1.29-1.35 ms beside each other, 1.55
 // on one queue, 1.88 on one pipe: four streams in use before this one and 8 hardware queues).  Which case a new stream
 // lands in depends on what else the process has created -- so the context finds out: a chain of sixteen 5 us probe
 // kernels on its own stream is timed alone and while a 120 us probe runs on the candidate, and the candidate is kept
