@@ -291,6 +291,10 @@ def main():
                     help="rehearse the launch only: ranks rendezvous over gloo on the CPU, shard the batch, barrier, "
                          "reduce a time and rank 0 prints a line -- no GPU, no extraction (tests the --gpus N spawn)")
     args = ap.parse_args()
+    if args.profile_run:
+        # one launch sequence per step under the profiler (its per-kernel figures are means per launch): no side stream
+        # for octave 0 (read when a context is created), no probe kernels
+        os.environ["CUSIFT_OCTAVE_OVERLAP"] = "0"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as a plain command: this process has not touched a GPU (no torch import, no HIP
         # call so far) and never will -- it starts the N ranks as CHILDREN and relays rank 0's line
@@ -602,18 +606,19 @@ def main():
             # a lone caller: one batch at a time on one stream, no stage timers -- the driver then runs octave 0's
             # detection on the context's second stream beside the ScaleDown chain and the coarser octaves
             forks0 = ex.ctx.forks()
-            for _ in range(2):
+            lone_steps = 0 if args.profile_run else K  # (not under the profiler: its per-kernel averages are per launch)
+            for _ in range(2 if lone_steps else 0):
                 ex.extract(d_imgs)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(K):
+            for _ in range(lone_steps):
                 ex.extract(d_imgs)
             torch.cuda.synchronize()
-            lone_ms = (time.perf_counter() - t1) / K * 1e3
+            lone_ms = (time.perf_counter() - t1) / max(1, lone_steps) * 1e3
             out["single_stream_leg"] = {
                 "ms_per_step": round(single_ms, 4),
-                "lone_caller_ms_per_step": round(lone_ms, 4),
-                "lone_caller_forked_steps": ex.ctx.forks() - forks0 - 2,
+                "lone_caller_ms_per_step": round(lone_ms, 4) if lone_steps else None,
+                "lone_caller_forked_steps": max(0, ex.ctx.forks() - forks0 - 2),
                 "note": "the timed region alternates steps over %d streams; stage_ms_per_step, the VALU rooflines and "
                         "pyramid_mpix_per_s are measured on the same steps run on one stream (HIP events per launch), "
                         "where kernel spans do not overlap.  lone_caller_ms_per_step: the same calls without the stage "
