@@ -36,8 +36,8 @@ __global__ void orientations_kernel(const float *, int, int, int, long, cusift_p
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                    const unsigned int *, float, float, float, RowWindow, int, unsigned int *);
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int,
-                                    unsigned int *, const unsigned int *, const char *);
-__global__ void join_counts_kernel(unsigned int *, const unsigned int *, unsigned int *, int, int, unsigned int *);
+                                    unsigned int *, SegmentTable, const unsigned int *);
+__global__ void join_counts_kernel(unsigned int *, SegmentTable, unsigned int *, int, int, unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
 template <bool kL2>
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, MatchPartial *, int);
@@ -119,6 +119,7 @@ struct Knobs {
   int match_splits = 0;                              // CUSIFT_MATCH_SPLITS
   int octave_overlap = -1;                           // CUSIFT_OCTAVE_OVERLAP: 0 never, 1 lone callers (default), 2 always
   bool side_debug = false;                           // CUSIFT_SIDE_DEBUG: print the side stream's concurrency probe
+  int stage_all = -1;                                // CUSIFT_STAGE_ALL: 0 never, 1 whenever it fits (default), 2 = 1
 };
 
 static Knobs read_knobs() {
@@ -143,6 +144,7 @@ static Knobs read_knobs() {
   k.match_splits = num("CUSIFT_MATCH_SPLITS", 0);
   k.octave_overlap = num("CUSIFT_OCTAVE_OVERLAP", -1);
   k.side_debug = text("CUSIFT_SIDE_DEBUG") != nullptr;
+  k.stage_all = num("CUSIFT_STAGE_ALL", -1);
   return k;
 }
 
@@ -238,14 +240,19 @@ struct Plan {
   // arena offsets in bytes
   size_t base_off[kMaxOctaves];  // octave >= 1 base images (n * h*p floats each); [0] unused
   size_t first_off = 0, total = 0;
-  size_t staged_off = 0;  // the staging list of octave 0's keypoints ([n][max_pts] heads), when `staged`
-  bool staged = false;
+  // staging lists of keypoint heads ([octave][image][max_pts] x kStagedRecBytes), see cusift_extract_batch:
+  // staged_octaves == 0: none; 1: octave 0's (searched on the side stream); n_oct: every octave's
+  size_t staged_off = 0, seg_end_off = 0;
+  int staged_octaves = 0;
+  bool fork = false;  // octave 0's detection on the context's side stream
 };
 
-// Largest staging list a context allocates for the side-by-side detection of octave 0 (beyond it: one stream, as before)
-constexpr size_t kMaxStagedBytes = (size_t)1 << 30;
+// Largest staging a context allocates: for octave 0 alone (the side stream), for all octaves (one launch for the coarser
+// octaves; a batch beyond it keeps the in-place lists)
+constexpr size_t kMaxStagedBytes = (size_t)1 << 30, kMaxStagedAllBytes = (size_t)256 << 20;
 
-int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm, bool staged = false) {
+int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm, bool fork = false,
+              bool stage_all = false) {
   if (!prm) return fail(CUSIFT_ERR_INVALID, "params is NULL");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w)
     return fail(CUSIFT_ERR_INVALID, "bad geometry n=%d w=%d h=%d pitch=%d", n_images, w, h, pitch);
@@ -276,12 +283,16 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
     pl.base_off[o] = off;
     off = align_up_sz(off + (size_t)n_images * pl.h[o] * pl.p[o] * sizeof(float), 256);
   }
-  pl.first_off = off;
+  pl.first_off = off;  // per-octave snapshots of the counters (fstPts), or the segments' counters
   off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
-  pl.staged = staged && pl.n_oct >= 2 && (size_t)n_images * prm->max_pts * kStagedRecBytes <= kMaxStagedBytes;
-  if (pl.staged) {
+  pl.seg_end_off = off;  // join_counts_kernel's running sums, [image][segment]
+  off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
+  const size_t per_octave = (size_t)n_images * prm->max_pts * kStagedRecBytes;
+  pl.fork = fork && pl.n_oct >= 2 && per_octave <= kMaxStagedBytes;
+  pl.staged_octaves = (stage_all && pl.n_oct >= 2 && per_octave * pl.n_oct <= kMaxStagedAllBytes) ? pl.n_oct : (pl.fork ? 1 : 0);
+  if (pl.staged_octaves) {
     pl.staged_off = off;
-    off = align_up_sz(off + (size_t)n_images * prm->max_pts * kStagedRecBytes, 256);
+    off = align_up_sz(off + per_octave * pl.staged_octaves, 256);
   }
   pl.total = off;
   return CUSIFT_OK;
@@ -458,6 +469,14 @@ static bool wants_side_stream(const cusift_ctx *ctx, const cusift_params *prm, i
   if (mode == 2) return true;  // tests: whatever the size, also inside a recording
   if (ctx->recording) return false;
   return prm->concurrent_batches < 2 && (size_t)n_images * (size_t)w * (size_t)h >= kSideStreamMinPixels;
+}
+
+// Every octave's keypoints to staging lists, joined by describe_all_kernel: detections no longer have to run, or end, in
+// list order -- the coarser octaves are searched by ONE launch (detect_impl_multi).  Whenever the lists fit
+// (make_plan: kMaxStagedAllBytes), except with the per-octave stage sequence or the generic kernels.
+static bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_images) {
+  if (ctx->knobs.stage_all == 0 || ctx->knobs.force_generic) return false;
+  return prm && prm->fused_detect && n_images >= 1 && n_images <= kMaxFlatImages;
 }
 
 // A second stream only helps if the device runs it BESIDE the context's stream.  HIP maps streams onto a few hardware
@@ -653,7 +672,8 @@ extern "C" int cusift_ctx_wait(cusift_ctx *ctx, cusift_ctx *other) {
 extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p) {
   TRY(enter(ctx));
   Plan pl;
-  TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p, wants_side_stream(ctx, p, n_images, w, h)));
+  TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p, wants_side_stream(ctx, p, n_images, w, h),
+                wants_stage_all(ctx, p, n_images)));
   // + one pitched upload image for cusift_extract_host
   return ensure_arena(ctx, pl.total + align_up_sz((size_t)h * ialign_up(w, 128) * sizeof(float), 256));
 }
@@ -1002,9 +1022,9 @@ static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t 
 static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
                        float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
                        unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end,
-                       int concurrent = 1, bool staged = false) {
-  // staged: `d_points` is the context's staging list (kStagedRecBytes per keypoint) and the launch goes to the side
-  // stream (cusift_extract_batch: octave 0 beside the coarser octaves)
+                       int concurrent = 1, bool heads = false, bool side = false) {
+  // heads: `d_points` is a staging list of the context (kStagedRecBytes per keypoint); side: the launch goes to the
+  // context's side stream (cusift_extract_batch)
   TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -1053,9 +1073,9 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
   constexpr int kWhole = (int)sizeof(cusift_point);
   const bool ident = ident0 && !ctx->knobs.no_ident;
-  auto kernel = staged ? (ident ? detect_fused_kernel<true, kStagedRecBytes> : detect_fused_kernel<false, kStagedRecBytes>)
-                       : (ident ? detect_fused_kernel<true, kWhole> : detect_fused_kernel<false, kWhole>);
-  hipLaunchKernelGGL(kernel, grid, dim3(64 * wpb), cube_bytes, staged ? ctx->side : ctx->stream, d_img, w, h, pitch,
+  auto kernel = heads ? (ident ? detect_fused_kernel<true, kStagedRecBytes> : detect_fused_kernel<false, kStagedRecBytes>)
+                      : (ident ? detect_fused_kernel<true, kWhole> : detect_fused_kernel<false, kWhole>);
+  hipLaunchKernelGGL(kernel, grid, dim3(64 * wpb), cube_bytes, side ? ctx->side : ctx->stream, d_img, w, h, pitch,
                      (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   return check_launch("detect_multi");
 }
@@ -1389,19 +1409,22 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   if (!d_imgs || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "extract: missing data");
   if (n_images > 1 && image_stride < (size_t)h * pitch) return fail(CUSIFT_ERR_INVALID, "image_stride too small");
   Plan pl;
-  TRY(make_plan(pl, n_images, w, h, pitch, prm, wants_side_stream(ctx, prm, n_images, w, h)));
+  TRY(make_plan(pl, n_images, w, h, pitch, prm, wants_side_stream(ctx, prm, n_images, w, h),
+                wants_stage_all(ctx, prm, n_images)));
   TRY(ensure_arena(ctx, pl.total));
   if (const size_t dog_need = two_stage_dog_bytes(ctx, pl, prm, d_imgs, image_stride, ctx->arena, n_images))
     TRY(ensure_dog(ctx, dog_need));  // sized once for the largest two-stage octave, before anything is enqueued
 
   StageTimer total(ctx, CUSIFT_STAGE_TOTAL);
-  // cuSIFT.cu:69: point counter = 0
-  HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));
 
   const float *base[kMaxOctaves];
   size_t stride[kMaxOctaves];
   base[0] = d_imgs;
   stride[0] = image_stride;
+  for (int o = 1; o < pl.n_oct; ++o) {
+    base[o] = (const float *)(ctx->arena + pl.base_off[o]);
+    stride[o] = (size_t)pl.h[o] * pl.p[o];
+  }
   unsigned int *first = (unsigned int *)(ctx->arena + pl.first_off);
   // With fused_detect the keypoint stages run once, after the last octave's detection, over the flattened list
   // of all keypoints of the batch (describe_all_kernel); otherwise per octave like the reference.  The DETECTION
@@ -1411,24 +1434,55 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   const bool generic = ctx->knobs.force_generic;
   const bool flat = prm->fused_detect && n_images <= kMaxFlatImages && !generic;
   auto searched = [&](int o) { return prm->lowest_scale < pl.sub[o] * 2.0f; };  // cuSIFT.cu:194
+  auto fused_ok = [&](int o) { return detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o]); };
 
-  // fork: octave 0's detection to the side stream, if it and a coarser octave are searched at all
-  bool forked = flat && pl.staged && searched(0) && detect_fused_ok(d_imgs, w, h, pitch, image_stride);
-  if (forked) {
-    forked = false;
-    for (int o = 1; o < pl.n_oct; ++o) forked = forked || searched(o);
+  // Where the octaves' keypoints go (sift_types.h: SegmentTable).  One stream searching coarsest first leaves SiftData
+  // in list order by itself; the moment two detections may overlap -- octave 0 on the side stream, the coarser octaves
+  // in one launch -- they append to lists of their own (record heads in the arena) and describe_all_kernel joins them.
+  //   stage_all   every searched octave to its own list: needs the fused kernel for every searched octave
+  //   forked      octave 0 to a list of its own and to the side stream; the coarser ones in place (or staged too)
+  bool stage_all = flat && pl.staged_octaves == pl.n_oct;
+  bool any_coarser = false;
+  for (int o = 0; o < pl.n_oct; ++o) {
+    if (!searched(o)) continue;
+    stage_all = stage_all && fused_ok(o);
+    any_coarser = any_coarser || o > 0;
   }
-  unsigned int *side_counts = first, *in_place = first + n_images;  // `first` is free when the keypoint stages run once
-  char *staged = ctx->arena + pl.staged_off;
+  bool forked = flat && pl.fork && pl.staged_octaves >= 1 && searched(0) && fused_ok(0) && any_coarser;
   if (forked && ensure_side_stream(ctx) != CUSIFT_OK) forked = false;  // no stream runs beside this one: one stream
+  const size_t list_bytes = (size_t)n_images * prm->max_pts * kStagedRecBytes;
+  char *const lists = ctx->arena + pl.staged_off;
+  unsigned int *const seg_counts = first;  // [octave][image]: `first` is free when the keypoint stages run once
+  unsigned int *const seg_end = (unsigned int *)(ctx->arena + pl.seg_end_off);
+  auto list_of = [&](int o) { return reinterpret_cast<cusift_point *>(lists + (size_t)o * list_bytes); };
+  SegmentTable G;
+  memset(&G, 0, sizeof(G));
+  if (stage_all) {
+    G.n_seg = pl.n_oct;
+    for (int r = 0; r < pl.n_oct; ++r) {  // list order: coarsest octave first
+      const int o = pl.n_oct - 1 - r;
+      G.base[r] = reinterpret_cast<const char *>(list_of(o));
+      G.count[r] = seg_counts + (size_t)o * n_images;
+    }
+  } else if (forked) {
+    G.n_seg = 2;
+    G.base[0] = nullptr;  // the coarser octaves: in place, the caller's counter
+    G.count[0] = d_counters;
+    G.base[1] = reinterpret_cast<const char *>(list_of(0));
+    G.count[1] = seg_counts;
+  }
+  // cuSIFT.cu:69: point counter = 0 (with every octave staged join_counts_kernel writes it instead)
+  if (!stage_all) HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));
+  if (G.n_seg)
+    HIP_TRY(hipMemsetAsync(seg_counts, 0, sizeof(unsigned int) * n_images * (stage_all ? pl.n_oct : 1), ctx->stream));
+
   if (forked) {
     ctx->forks++;
-    HIP_TRY(hipMemsetAsync(side_counts, 0, sizeof(unsigned int) * n_images, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     const int rc = detect_impl(ctx, d_imgs, w, h, pitch, image_stride, (float)pl.blur[0], prm->peak_thresh,
-                               prm->edge_thresh, pl.sub[0], reinterpret_cast<cusift_point *>(staged), prm->max_pts,
-                               side_counts, n_images, RowWindow{0, h}, 0, h, 1, true);
+                               prm->edge_thresh, pl.sub[0], list_of(0), prm->max_pts, seg_counts, n_images,
+                               RowWindow{0, h}, 0, h, 1, true, true);
     const hipError_t e = hipEventRecord(ctx->ev_join, ctx->side);
     if (rc != CUSIFT_OK || e != hipSuccess) {
       (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);  // never leave the side stream forked (a capture would not end)
@@ -1439,13 +1493,9 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   // the side stream rejoins the context's stream however the work in between ends
   auto on_main = [&]() -> int {
     // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest
-    for (int o = 1; o < pl.n_oct; ++o) {
-      float *dst = (float *)(ctx->arena + pl.base_off[o]);
-      stride[o] = (size_t)pl.h[o] * pl.p[o];
-      TRY(cusift_scale_down(ctx, dst, pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1], pl.p[o - 1],
-                            stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
-      base[o] = dst;
-    }
+    for (int o = 1; o < pl.n_oct; ++o)
+      TRY(cusift_scale_down(ctx, const_cast<float *>(base[o]), pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1],
+                            pl.p[o - 1], stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
     // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
     for (int o = pl.n_oct - 1; o >= (forked ? 1 : 0); --o) {
       if (!searched(o)) continue;
@@ -1453,10 +1503,11 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
       unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
       if (!flat)
         HIP_TRY(hipMemcpyAsync(fst, d_counters, sizeof(unsigned int) * n_images, hipMemcpyDeviceToDevice, ctx->stream));
-      if (prm->fused_detect && !generic && detect_fused_ok(base[o], pl.w[o], pl.h[o], pl.p[o], stride[o])) {
+      if (prm->fused_detect && !generic && fused_ok(o)) {
         TRY(detect_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], prm->peak_thresh,
-                        prm->edge_thresh, pl.sub[o], d_points, prm->max_pts, d_counters, n_images,
-                        RowWindow{0, pl.h[o]}, 0, pl.h[o], forked ? 1 : prm->concurrent_batches));
+                        prm->edge_thresh, pl.sub[o], stage_all ? list_of(o) : d_points, prm->max_pts,
+                        stage_all ? seg_counts + (size_t)o * n_images : d_counters, n_images, RowWindow{0, pl.h[o]}, 0,
+                        pl.h[o], forked ? 1 : prm->concurrent_batches, stage_all));
       } else {
         const size_t dstride = (size_t)kNumDog * pl.h[o] * pl.p[o];
         float *dog = ctx->dog;
@@ -1506,17 +1557,16 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     const long want = std::max(1L, std::min(cap, (long)ctx->describe_grid));
     dim3 grid((unsigned int)std::max<long>(kQueueShards, want / kQueueShards * kQueueShards));
     unsigned int *queue = ctx->d_queue;  // the kernel's work cursors, zero at launch
-    if (forked) {
-      hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counters, side_counts, in_place,
-                         n_images, prm->max_pts, queue);
+    if (G.n_seg) {
+      hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counters, G, seg_end, n_images,
+                         prm->max_pts, queue);
       TRY(check_launch("join_counts"));
     } else {
       HIP_TRY(hipMemsetAsync(queue, 0, kQueueShards * 128, ctx->stream));
     }
     StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
     hipLaunchKernelGGL(describe_all_kernel, grid, dim3(64), 0, ctx->stream, T, d_points, prm->max_pts, d_counters,
-                       n_images, q, inv_q, prm->root_sift, queue, forked ? in_place : (const unsigned int *)nullptr,
-                       (const char *)staged);
+                       n_images, q, inv_q, prm->root_sift, queue, G, (const unsigned int *)seg_end);
     TRY(check_launch("describe_all"));
   }
   return CUSIFT_OK;
@@ -1552,7 +1602,7 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
   Plan pl;
   // the side stream is found (and probed: that waits) before the capture starts; the fork and the join become edges
   const bool fork = wants_side_stream(ctx, prm, n_images, w, h) && ensure_side_stream(ctx) == CUSIFT_OK;
-  TRY(make_plan(pl, n_images, w, h, pitch, prm, fork));
+  TRY(make_plan(pl, n_images, w, h, pitch, prm, fork, wants_stage_all(ctx, prm, n_images)));
   // everything that allocates or synchronises happens before the capture starts
   TRY(ensure_arena(ctx, pl.total));
   // the DoG planes of every octave that takes the two-stage path (see cusift_extract_batch), sized up front
@@ -1640,7 +1690,8 @@ extern "C" int cusift_extract_host(cusift_ctx *ctx, const float *h_img, int w, i
   if (w < 1 || h < 1) return fail(CUSIFT_ERR_INVALID, "bad image size %dx%d", w, h);
   const int pitch = ialign_up(w, 128);  // cuImage::AllocateWithHostMemory, cuImage.cu:11-13
   Plan pl;
-  TRY(make_plan(pl, 1, w, h, pitch, prm, wants_side_stream(ctx, prm, 1, w, h)));  // the plan cusift_extract_batch will make
+  TRY(make_plan(pl, 1, w, h, pitch, prm, wants_side_stream(ctx, prm, 1, w, h),
+                wants_stage_all(ctx, prm, 1)));  // the plan cusift_extract_batch will make
   const size_t img_bytes = align_up_sz((size_t)h * pitch * sizeof(float), 256);
   TRY(ensure_arena(ctx, pl.total + img_bytes));
   float *d_img = (float *)(ctx->arena + pl.total);

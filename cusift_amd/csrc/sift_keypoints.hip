@@ -770,12 +770,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                                          const unsigned int *__restrict__ counters, int n_images,
                                                          float q, float inv_q, int root_sift,
                                                          unsigned int *__restrict__ queue,
-                                                         const unsigned int *__restrict__ in_place,
-                                                         const char *__restrict__ staged) {
-  // `in_place` (may be NULL: everything is): per image, how many of its keypoints were appended to `points` directly.
-  // The rest -- octave 0's, when cusift_extract_batch ran that octave's detection beside the coarser ones -- wait as
-  // record heads in the context's staging list `staged` ([image][max_pts] x kStagedRecBytes) and are moved behind
-  // them here: keypoint k >= in_place[i] of image i is staged record k - in_place[i].
+                                                         SegmentTable G,
+                                                         const unsigned int *__restrict__ seg_end) {
+  // G.n_seg == 0: every keypoint was appended to `points` directly.  Otherwise the batch's keypoints wait in segments
+  // (sift_types.h) -- octave 0's when cusift_extract_batch ran that octave's detection beside the coarser ones, every
+  // octave's when the coarser octaves were searched by one launch -- and are moved into place here, coarsest octave
+  // first: keypoint k of image i belongs to the first segment r with k < seg_end[i * n_seg + r].
   __shared__ KpShared S;
   __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
   const int lane = threadIdx.x;
@@ -819,10 +819,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const unsigned int idx = item - __builtin_amdgcn_readfirstlane(s_prefix[im]);
     cusift_point *dst = points + (long)im * max_pts + idx;
     src = dst;
-    if (in_place) {
-      const unsigned int direct = in_place[im];  // wave-uniform: a scalar load
-      if (idx >= direct)
-        src = reinterpret_cast<const cusift_point *>(staged + ((size_t)im * max_pts + (idx - direct)) * kStagedRecBytes);
+    if (G.n_seg > 0) {
+      const unsigned int *ends = seg_end + im * G.n_seg;  // wave-uniform: scalar loads
+      int r = 0;
+      unsigned int first = 0;
+      while (idx >= ends[r]) first = ends[r++];  // ends: idx < this image's total = ends[n_seg - 1]
+      const char *base = G.base[r];
+      if (base) src = reinterpret_cast<const cusift_point *>(base + ((size_t)im * max_pts + (idx - first)) * kStagedRecBytes);
     }
     return dst;
   };
@@ -885,19 +888,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
 }
 
-// Joins the two keypoint lists of a batch whose octave 0 was searched beside the coarser octaves: `counters` (the caller's;
-// the coarser octaves' keypoints are in place behind them) and `side_counts` (octave 0's, staged).  in_place[i] = what
-// of image i is in place; counters[i] becomes the image's total as one stream would have left it (it keeps counting
-// beyond max_pts, like the reference's).  Also clears the work cursors of describe_all_kernel, which runs next.
-__global__ void __launch_bounds__(256) join_counts_kernel(unsigned int *__restrict__ counters,
-                                                          const unsigned int *__restrict__ side_counts,
-                                                          unsigned int *__restrict__ in_place, int n_images, int max_pts,
+// Joins the keypoint segments of a batch (sift_types.h: SegmentTable) before describe_all_kernel walks them: per image
+// the running sum of the segments' counts in list order, clamped at max_pts -- so the coarser segments survive whole,
+// as when one stream searches coarsest first (cuSIFT.cu:190-196) -- and the image's counter as one stream would have left
+// it: the sum of what every detection counted (it keeps counting beyond max_pts, like the reference's).  Segment 0 may be
+// the caller's own counter (keypoints appended in place).  Also clears the work cursors of describe_all_kernel.
+__global__ void __launch_bounds__(256) join_counts_kernel(unsigned int *__restrict__ counters, SegmentTable G,
+                                                          unsigned int *__restrict__ seg_end, int n_images, int max_pts,
                                                           unsigned int *__restrict__ queue) {
   for (int i = threadIdx.x; i < kQueueShards * 32; i += 256) queue[i] = 0u;
   for (int i = threadIdx.x; i < n_images; i += 256) {
-    const unsigned int c = counters[i];
-    in_place[i] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
-    counters[i] = c + side_counts[i];
+    unsigned int raw = 0, kept = 0;
+    for (int r = 0; r < G.n_seg; ++r) {
+      const unsigned int c = G.count[r][i];
+      raw += c;
+      const unsigned int room = (unsigned int)max_pts - kept;
+      kept += c < room ? c : room;
+      seg_end[i * G.n_seg + r] = kept;
+    }
+    counters[i] = raw;
   }
 }
 

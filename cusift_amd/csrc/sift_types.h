@@ -59,6 +59,16 @@ struct RowWindow {
 constexpr int kMaxFlatImages = 256;  // batch size up to which the flattened keypoint kernel is used
 constexpr int kDetectWaveLdsFloats = 128 * 21;  // detect_fused_kernel: candidate list per wave (128 entries of 21 words)
 constexpr int kStagedRecBytes = 64;   // a staged keypoint: the first 16 floats of a cusift_point (coords2D .. subsampling)
+// Where the keypoints of a batch wait before describe_all_kernel puts them in place (cusift_extract_batch).  A batch's
+// SiftData is a sequence of SEGMENTS in list order -- coarsest octave first.  Segment r of image i holds
+// seg_end[i * n_seg + r] - seg_end[i * n_seg + r - 1] keypoints (join_counts_kernel clamps the sequence at max_pts, so
+// the coarser segments survive whole); its keypoints wait as record heads at base[r] + (i * max_pts + j) * kStagedRecBytes,
+// or -- base[r] == NULL, segment 0 only -- already sit in the caller's records.
+struct SegmentTable {
+  int n_seg;                          // 0: no table, everything is in place
+  const char *base[kMaxOctaves];      // staging list of segment r ([image][max_pts] heads), or NULL
+  const unsigned int *count[kMaxOctaves];  // per-image counters the detection of segment r incremented (unclamped)
+};
 constexpr int kQueueShards = 64;      // work cursors of describe_all_kernel (a power of two)
 struct OctaveTable {
   const float *base[kMaxOctaves];  // image 0 of octave o

@@ -1,7 +1,8 @@
-"""Octave 0 beside the coarser octaves (cusift_extract_batch, a lone caller: cusift_params.concurrent_batches < 2).
+"""The staged drivers of cusift_extract_batch: octave 0 beside the coarser octaves (a lone caller:
+cusift_params.concurrent_batches < 2), every octave's keypoints to a list of its own (whenever the lists fit), or both.
 
-The forked driver -- octave 0's detection on the context's side stream into a staging list, joined and moved into place by
-describe_all_kernel -- must leave the same SiftData as the one-stream driver: the same records (bit for bit, as sets per
+A staged driver -- detections appending record heads to staging lists in the arena, joined and moved into place by
+describe_all_kernel -- must leave the same SiftData as the plain one-stream driver: the same records (bit for bit, as sets per
 octave: the order inside an octave is unspecified in both and in the reference), coarsest octave first, the same counter
 (it keeps counting beyond max_pts), and under saturation the coarser octaves survive whole, as in the reference
 (cuSIFT.cu:190-196 searches them first).  The default `ctx` of the other parity tests forks too, so every whole-image
@@ -49,26 +50,36 @@ def same_records(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f], equal_nan=True) for f in FIELDS)
 
 
-def context_with(monkeypatch, mode):
-    """The knob is read when the context is created."""
-    monkeypatch.setenv("CUSIFT_OCTAVE_OVERLAP", str(mode))
+def context_with(monkeypatch, overlap, stage_all=None):
+    """The knobs are read when the context is created."""
+    monkeypatch.setenv("CUSIFT_OCTAVE_OVERLAP", str(overlap))
+    if stage_all is not None:
+        monkeypatch.setenv("CUSIFT_STAGE_ALL", str(stage_all))
     c = capi.Context(0)
     monkeypatch.delenv("CUSIFT_OCTAVE_OVERLAP")
+    if stage_all is not None:
+        monkeypatch.delenv("CUSIFT_STAGE_ALL")
     return c
 
 
-@pytest.fixture
-def ctx(monkeypatch):
-    """This module's `ctx` forks whatever the size of the call (the default: from three 1080p frames' worth of pixels up)."""
-    c = context_with(monkeypatch, 2)
+# how the keypoints of a call reach SiftData (cusift_extract_batch): octave 0 on the side stream with a list of its own
+# and the coarser octaves in place; every octave to a list of its own on one stream; both
+MODES = {"fork": (2, 0), "lists": (0, 1), "fork+lists": (2, 1)}
+
+
+@pytest.fixture(params=sorted(MODES))
+def ctx(request, monkeypatch):
+    """This module's `ctx`: one of the staged drivers, forced whatever the size of the call."""
+    c = context_with(monkeypatch, *MODES[request.param])
+    c.mode = request.param
     yield c
     c.close()
 
 
 @pytest.fixture
 def one_stream(monkeypatch):
-    """A context that never forks."""
-    c = context_with(monkeypatch, 0)
+    """The plain driver: one stream, every keypoint appended in place."""
+    c = context_with(monkeypatch, 0, 0)
     yield c
     c.close()
 
@@ -80,7 +91,7 @@ def test_forked_equals_one_stream(ctx, one_stream, n, w, h, n_oct, blur):
     imgs = images(n, w, h, blur)
     cnt_f, pts_f = run_batch(ctx, imgs, prm, fill=0x5A)
     cnt_s, pts_s = run_batch(one_stream, imgs, prm, fill=0x5A)
-    assert ctx.forks() == 1 and one_stream.forks() == 0
+    assert ctx.forks() == (1 if "fork" in ctx.mode else 0) and one_stream.forks() == 0
     np.testing.assert_array_equal(cnt_f, cnt_s)
     assert w < 128 or cnt_f.sum() > 20 * n  # (a 64 x 48 tile may hold no keypoint at all)
     for i in range(n):
@@ -169,12 +180,12 @@ def test_host_entry_point_and_graph_replay(ctx, one_stream, monkeypatch):
     src = pitched(img)
     h, w = img.shape
     p = src.shape[1]
-    with context_with(monkeypatch, 2) as c:
+    with context_with(monkeypatch, *MODES[ctx.mode]) as c:
         d_img = DeviceBuffer.from_numpy(c, src)
         d_pts = DeviceBuffer(c, prm.max_pts * 588)
         d_cnt = DeviceBuffer(c, 4)
         g = c.record_graph(d_img.ptr, 1, w, h, p, h * p, prm, d_pts.ptr, d_cnt.ptr)
-        assert c.forks() == 1  # the recording holds the fork and the join
+        assert c.forks() == (1 if "fork" in ctx.mode else 0)  # the recording holds the fork and the join
         for _ in range(3):
             d_pts.zero()
             g.launch()
