@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcusift_amd.so")
 SOURCES = ["sift_capi.hip", "sift_stencils.hip", "sift_keypoints.hip", "sift_match.hip",
            "sift_frontend.hip", "sift_homography.hip", "sift_comm.hip", "sift_tiled.hip"]
-HEADERS = [os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"), os.path.join(CSRC, "sift_internal.h"),
+HEADERS = [os.path.join(CSRC, "detect_chunk.inc"), os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"), os.path.join(CSRC, "sift_internal.h"),
            os.path.join(HERE, "..", "include", "cusift_amd.h")]
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).

@@ -29,6 +29,8 @@ __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusi
 template <bool kIdent0, int kRecBytes>
 __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                     LaplaceTapsPk, FindParams, RowWindow, int, int);
+template <int kRecBytes>
+__global__ void detect_multi_kernel(DetectTable, int);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
                                    FindParams);
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
@@ -120,6 +122,7 @@ struct Knobs {
   int octave_overlap = -1;                           // CUSIFT_OCTAVE_OVERLAP: 0 never, 1 lone callers (default), 2 always
   bool side_debug = false;                           // CUSIFT_SIDE_DEBUG: print the side stream's concurrency probe
   int stage_all = -1;                                // CUSIFT_STAGE_ALL: 0 never, 1 whenever it fits (default), 2 = 1
+  bool no_multi = false;                             // CUSIFT_NO_MULTI: the coarser octaves one launch each, even with lists
 };
 
 static Knobs read_knobs() {
@@ -145,6 +148,7 @@ static Knobs read_knobs() {
   k.octave_overlap = num("CUSIFT_OCTAVE_OVERLAP", -1);
   k.side_debug = text("CUSIFT_SIDE_DEBUG") != nullptr;
   k.stage_all = num("CUSIFT_STAGE_ALL", -1);
+  k.no_multi = text("CUSIFT_NO_MULTI") != nullptr;
   return k;
 }
 
@@ -1019,6 +1023,16 @@ static bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t 
          ((size_t)h * pitch * sizeof(float) < (1ull << 31));
 }
 
+// Chunk height of the fused detection: centre rows per wave (see the comment in detect_impl).
+static int detect_rows(const cusift_ctx *ctx, int rows_total, int strips, int n_images, int concurrent) {
+  int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 64;
+  rows_bounds(ctx, kKnobDetect, rows_lo, rows_hi);
+  const double wave_rows = (double)rows_total * strips * n_images;
+  double coef = concurrent >= 2 ? 0.09 : 0.05;
+  if (ctx->knobs.detect_rows_coef > 0.0) coef = ctx->knobs.detect_rows_coef;  // tuning experiments only
+  return std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
+}
+
 static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
                        float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
                        unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end,
@@ -1053,12 +1067,7 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   // several streams -- the throughput mode -- the other batches' kernels fill the tail and taller chunks win: two
   // streams 0.05 -> 1.451, 0.08 -> 1.414 ms per step; four streams 0.05 -> 1.414, 0.08 -> 1.370, 0.1 -> 1.379,
   // 0.13 -> 1.382.  The caller says which case it is (cusift_params.concurrent_batches).
-  int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 64;
-  rows_bounds(ctx, kKnobDetect, rows_lo, rows_hi);
-  const double wave_rows = (double)rows_total * strips * n_images;
-  double coef = concurrent >= 2 ? 0.09 : 0.05;
-  if (ctx->knobs.detect_rows_coef > 0.0) coef = ctx->knobs.detect_rows_coef;  // tuning experiments only
-  const int rows = std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
+  const int rows = detect_rows(ctx, rows_total, strips, n_images, concurrent);
   // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
   // threshold pre-test makes the waves' run times uneven -- measured 64x1080p, r = 16: 4 waves per workgroup 0.693 ms,
   // 2: 0.645 ms, 1: 0.630 ms (tools/probe_rows.py with CUSIFT_DETECT_WAVES).
@@ -1078,6 +1087,58 @@ static int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pi
   hipLaunchKernelGGL(kernel, grid, dim3(64 * wpb), cube_bytes, side ? ctx->side : ctx->stream, d_img, w, h, pitch,
                      (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
   return check_launch("detect_multi");
+}
+
+// The fused detection of several octaves of a batch in ONE launch (detect_multi_kernel): whole images, general taps,
+// keypoint HEADS to a staging list per octave.  `octaves` in launch order (largest first: the small ones fill its tail).
+struct MultiOctave {
+  const float *img;
+  int w, h, pitch;
+  size_t img_stride;
+  float init_blur, subsampling;
+  cusift_point *lists;
+  unsigned int *counters;
+};
+
+static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_octaves, float peak_thresh,
+                             float edge_thresh, int max_pts, int n_images, int concurrent) {
+  TRY(enter(ctx));
+  if (n_octaves < 1 || n_octaves > kMaxMultiOctaves) return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): 1..%d octaves", kMaxMultiOctaves);
+  DetectTable tab;
+  memset(&tab, 0, sizeof(tab));
+  tab.n = n_octaves;
+  long blocks = 0;
+  for (int k = 0; k < n_octaves; ++k) {
+    const MultiOctave &m = octaves[k];
+    if (!detect_fused_ok(m.img, m.w, m.h, m.pitch, m.img_stride))
+      return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): octave %d needs 16-byte aligned rows, w >= 4, h >= 3", k);
+    DetectOctave &o = tab.o[k];
+    float taps[8 * 16];
+    laplace_taps_table(m.init_blur, taps);
+    for (int q = 0; q < kNumLevels / 2; ++q)
+      for (int j = 0; j < 5; ++j) {
+        o.T.k[q][j].x = taps[16 * (2 * q) + j];
+        o.T.k[q][j].y = taps[16 * (2 * q + 1) + j];
+      }
+    find_params(o.P, peak_thresh, edge_thresh, m.subsampling);
+    o.img = m.img;
+    o.img_stride = (long)m.img_stride;
+    o.lists = reinterpret_cast<char *>(m.lists);
+    o.counters = m.counters;
+    o.w = m.w;
+    o.h = m.h;
+    o.pitch = m.pitch;
+    o.strips = idiv_up(m.w, 240);  // kDetStrip
+    o.rows_per_wave = detect_rows(ctx, m.h, o.strips, n_images, concurrent);
+    o.chunks = idiv_up(m.h, o.rows_per_wave);
+    o.first_block = (int)blocks;
+    blocks += (long)o.strips * o.chunks * n_images;
+  }
+  if (blocks > 0x7fffffffL) return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): too many workgroups");
+  StageTimer t(ctx, CUSIFT_STAGE_DETECT);
+  hipLaunchKernelGGL(detect_multi_kernel<kStagedRecBytes>, dim3((unsigned int)blocks), dim3(64),
+                     kDetectWaveLdsFloats * sizeof(float), ctx->stream, tab, max_pts);
+  return check_launch("detect_multi (octaves)");
 }
 
 extern "C" int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
@@ -1496,9 +1557,26 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     for (int o = 1; o < pl.n_oct; ++o)
       TRY(cusift_scale_down(ctx, const_cast<float *>(base[o]), pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1],
                             pl.p[o - 1], stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
+    // With a list per octave the coarser octaves are searched by ONE launch, largest first
+    bool in_one_launch[kMaxOctaves] = {false};
+    if (stage_all && !ctx->knobs.no_multi) {
+      MultiOctave mo[kMaxMultiOctaves];
+      int n_mo = 0;
+      for (int o = 1; o < pl.n_oct && n_mo < kMaxMultiOctaves; ++o)
+        if (searched(o)) {
+          mo[n_mo++] = MultiOctave{base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], pl.sub[o], list_of(o),
+                                   seg_counts + (size_t)o * n_images};
+          in_one_launch[o] = true;
+        }
+      if (n_mo >= 2)
+        TRY(detect_multi_impl(ctx, mo, n_mo, prm->peak_thresh, prm->edge_thresh, prm->max_pts, n_images,
+                              forked ? 1 : prm->concurrent_batches));
+      else
+        for (int o = 1; o < pl.n_oct; ++o) in_one_launch[o] = false;
+    }
     // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
     for (int o = pl.n_oct - 1; o >= (forked ? 1 : 0); --o) {
-      if (!searched(o)) continue;
+      if (!searched(o) || in_one_launch[o]) continue;
       // ExtractSiftOctave, cuSIFT.cu:204-270
       unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device
       if (!flat)

@@ -882,180 +882,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
   unsigned int *counter = counters + bz;
   CandList cands{s_cands + wv * kDetectWaveLdsFloats, 0};
 
-  const int c0 = bx * kDetStrip - kDetHaloLanes * kBlurCols + lane * kBlurCols;
-  const EdgeFix4 edge(c0, w);  // any w >= 4
-  const __amdgpu_buffer_rsrc_t rin =
-      __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)((unsigned int)h * (unsigned int)pitch * 4u), kBufFlags);
-  const bool lane_valid = lane >= kDetHaloLanes && lane < 64 - kDetHaloLanes;
-
-  // The load and its border fix-up are separate: the fix-up is the first USE of the loaded registers, and it is
-  // written where the row enters the window -- two row steps after the load was issued -- so that the wait for the
-  // load sits there too (as one function the compiler fixed the row up, and waited, one row step after the issue).
-  auto load_raw = [&](int y) -> f4 {
-    const int yc = clampi(y, 0, h - 1);
-    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, edge.voff, yc * pitch * 4, 0));
-  };
-  auto fix = [&](f4 v) -> f4 { return edge(v); };
-
-  f4 win[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) win[i] = fix(load_raw(ya - 1 - 4 + i));
-
-  // DoG rows yy-2, yy-1, yy live in three register sets whose roles rotate; the row loop is unrolled by
-  // three so the rotation costs no moves.
-  f4 DA[kNumDog], DB[kNumDog], DC[kNumDog];
-#pragma unroll
-  for (int p = 0; p < kNumDog; ++p) DA[p] = DB[p] = DC[p] = f4{0.f, 0.f, 0.f, 0.f};
-
-  f4 ahead = load_raw(ya - 1 + 5);  // row yy+5 of the first iteration; the loop keeps two rows in flight
-  auto row_step = [&](int yy, f4 (&D0)[kNumDog], f4 (&D1)[kNumDog], f4 (&D2)[kNumDog]) {
-    const f4 nxt = ahead;        // requested one iteration ago (raw)
-    ahead = load_raw(yy + 6);    // needed two iterations from now
-    blur_dog_row<kIdent0>(win, T, D2);
-
-    if (yy >= ya + 1) {
-      const int y = yy - 1;  // centre row: D0 = y-1, D1 = y, D2 = y+1
-      // Threshold pre-test.  An extremum must have |v| > peakThresh at its centre; for natural images <1 % of the
-      // pixels do, so for most wave-rows no lane holds a candidate centre at a given scale (and often at none).
-      // measured 73-79 % of the octave-0 wave-rows (240 px x 5 scales) of the 1080p benchmark images hold no such
-      // centre at all.  One wave-uniform test skips the whole neighbourhood analysis for them; skipping cannot
-      // change the result, because a hit implies |v| > thr.  (Skipping per scale/plane as well was tried: the
-      // conditionally live min/max arrays cost 258 VGPRs -> 1 wave per SIMD, slower.)
-      // (one running maximum of |v| -- ten v_max3_f32 with |.| modifiers and one compare instead of twenty compares;
-      // a NaN never raises the maximum, just as it never passed `|v| > thr`)
-      float vmax = 0.0f;
-#pragma unroll
-      for (int s = 0; s < kNumScales; ++s) {
-        const f4 v = D1[s + 1];
-        vmax = max3f(vmax, fabsf(v.x), fabsf(v.y));
-        vmax = max3f(vmax, fabsf(v.z), fabsf(v.w));
-      }
-      // halo lanes and lanes right of the image hold no centres (and their DoG values are not meaningful)
-      const bool big = vmax > P.thr_pos && lane_valid && c0 < w;
-      unsigned int cand = 0;  // bit (4*s + j)
-      if (__builtin_amdgcn_ballot_w64(big) != 0) {  // wave-uniform
-        // per plane: 3-row column min/max, then the 3x3 min/max (h*) and the left/right neighbours' columns
-        f4 hmn[kNumDog], hmx[kNumDog];
-        f4 lmn[kNumScales], rmn[kNumScales], lmx[kNumScales], rmx[kNumScales];  // for the 5 centre planes 1..5
-#pragma unroll
-        for (int p = 0; p < kNumDog; ++p) {
-          f4 cmn, cmx, l_mn, r_mn, l_mx, r_mx;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            cmn[j] = min3f(D0[p][j], D1[p][j], D2[p][j]);
-            cmx[j] = max3f(D0[p][j], D1[p][j], D2[p][j]);
-          }
-          l_mn = f4{from_prev_lane(cmn[3]), cmn[0], cmn[1], cmn[2]};
-          r_mn = f4{cmn[1], cmn[2], cmn[3], from_next_lane(cmn[0])};
-          l_mx = f4{from_prev_lane(cmx[3]), cmx[0], cmx[1], cmx[2]};
-          r_mx = f4{cmx[1], cmx[2], cmx[3], from_next_lane(cmx[0])};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            hmn[p][j] = min3f(l_mn[j], cmn[j], r_mn[j]);
-            hmx[p][j] = max3f(l_mx[j], cmx[j], r_mx[j]);
-          }
-          if (p >= 1 && p <= kNumScales) {
-            lmn[p - 1] = l_mn;
-            rmn[p - 1] = r_mn;
-            lmx[p - 1] = l_mx;
-            rmx[p - 1] = r_mx;
-          }
-        }
-#pragma unroll
-        for (int s = 0; s < kNumScales; ++s) {
-          const int c = s + 1;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = D1[c][j];
-            // v < thr_neg && v < every neighbour  <=>  v < min(thr_neg, neighbours): three 3-input trees, one compare
-            const float mn_a = min3f(lmn[s][j], rmn[s][j], D0[c][j]);
-            const float mn_b = min3f(D2[c][j], hmn[c - 1][j], hmn[c + 1][j]);
-            const float mx_a = max3f(lmx[s][j], rmx[s][j], D0[c][j]);
-            const float mx_b = max3f(D2[c][j], hmx[c - 1][j], hmx[c + 1][j]);
-            const bool hit = (v < min3f(mn_a, mn_b, P.thr_neg)) || (v > max3f(mx_a, mx_b, P.thr_pos));
-            cand |= (hit ? 1u : 0u) << (4 * s + j);
-          }
-        }
-      }
-      if (!lane_valid) cand = 0;
-      // border pixels are never extrema in the reference (clamped neighbour == centre)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c0 + j < 1 || c0 + j > w - 2) cand &= ~(0x11111u << j);
-      if (__builtin_amdgcn_ballot_w64(cand != 0) != 0) {  // wave-uniform, rare
-#pragma unroll 1
-        for (int s = 0; s < kNumScales; ++s) {
-          const unsigned int m = (cand >> (4 * s)) & 0xfu;
-          if (__builtin_amdgcn_ballot_w64(m != 0) == 0) continue;  // wave-uniform
-          // A candidate's refinement reads 19 DoG values: the 3x3 of its own plane, and the centre with its four
-          // neighbours in the planes below and above.  All of them are in the registers of the detecting lane, except
-          // the column beyond its float4 (from the lane before for column 0, the lane after for column 3: five DPP
-          // moves).  The scale index and the column are made compile-time constants -- one case per scale, one block
-          // per column -- so every value is a named register and the lane stores its entry directly.  (Round 2 first
-          // dumped the three planes of the strip into an LDS cube, 9 KB per wave, and copied from there: ~1,750
-          // cycles per row-and-scale with a candidate by the phase stamps.)
-          auto emit = [&](auto scale_c) {
-            constexpr int k = decltype(scale_c)::value;  // planes k (below), k + 1 (the candidate's), k + 2 (above)
-            auto column = [&](auto col_c) {
-              constexpr int j = decltype(col_c)::value;
-              const bool mine = (m >> j) & 1u;
-              if (__builtin_amdgcn_ballot_w64(mine) == 0) return;  // wave-uniform
-              // value of plane p, row set D, column j + dx
-              auto at = [&](const f4 (&D)[kNumDog], int p, int dx) -> float {
-                const int col = j + dx;
-                if (col < 0) return from_prev_lane(D[p][3]);
-                if (col > 3) return from_next_lane(D[p][0]);
-                return D[p][col];
-              };
-              // all lanes take part in the DPP moves; only the candidates' lanes store
-              const float c00 = at(D0, k + 1, -1), c01 = at(D0, k + 1, 0), c02 = at(D0, k + 1, 1);
-              const float c10 = at(D1, k + 1, -1), c11 = at(D1, k + 1, 0), c12 = at(D1, k + 1, 1);
-              const float c20 = at(D2, k + 1, -1), c21 = at(D2, k + 1, 0), c22 = at(D2, k + 1, 1);
-              const float l0 = at(D1, k, 0), l1 = at(D1, k, -1), l2 = at(D1, k, 1), l3 = at(D0, k, 0), l4 = at(D2, k, 0);
-              const float h0 = at(D1, k + 2, 0), h1 = at(D1, k + 2, -1), h2 = at(D1, k + 2, 1), h3 = at(D0, k + 2, 0),
-                          h4 = at(D2, k + 2, 0);
-              float *e = cands.reserve(mine);  // at most 64 more entries
-              if (mine) {
-                e[0] = c00, e[1] = c01, e[2] = c02, e[3] = c10, e[4] = c11, e[5] = c12, e[6] = c20, e[7] = c21, e[8] = c22;
-                e[9] = l0, e[10] = l1, e[11] = l2, e[12] = l3, e[13] = l4;
-                e[14] = h0, e[15] = h1, e[16] = h2, e[17] = h3, e[18] = h4;
-                e[19] = __builtin_bit_cast(float, c0 + j);
-                e[20] = __builtin_bit_cast(float, ((y + rw.row0) << 3) | k);
-              }
-              if (cands.n >= 64) {
-                cands.refine_batch<kRecBytes>(list, max_pts, counter, P, lane);
-              }
-            };
-            column(std::integral_constant<int, 0>{});
-            column(std::integral_constant<int, 1>{});
-            column(std::integral_constant<int, 2>{});
-            column(std::integral_constant<int, 3>{});
-          };
-          switch (s) {
-            case 0: emit(std::integral_constant<int, 0>{}); break;
-            case 1: emit(std::integral_constant<int, 1>{}); break;
-            case 2: emit(std::integral_constant<int, 2>{}); break;
-            case 3: emit(std::integral_constant<int, 3>{}); break;
-            default: emit(std::integral_constant<int, 4>{}); break;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) win[i] = win[i + 1];
-    win[8] = fix(nxt);
-  };
-
-  for (int yy = ya - 1; yy <= yb; yy += 3) {
-    row_step(yy, DA, DB, DC);
-    if (yy + 1 > yb) break;
-    row_step(yy + 1, DB, DC, DA);
-    if (yy + 2 > yb) break;
-    row_step(yy + 2, DC, DA, DB);
-  }
-  cands.refine_batch<kRecBytes>(list, max_pts, counter, P, lane);  // what is left of the chunk's candidates (fewer than 64)
+#include "detect_chunk.inc"
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The fused detection of SEVERAL octaves in one launch.  The coarser octaves of an image are small -- for one 1080p frame
+// octaves 1..4 are 14-16 us launches each, most of it the launch itself and the latency of a chunk's window fill -- and
+// they do not depend on each other, only on the ScaleDown chain.  One launch, the workgroups of octave 1 first and the
+// smaller ones behind them, costs what the largest costs.  Their keypoints cannot go to one list then (SiftData is
+// coarsest octave first): every octave appends to a list of its own (sift_types.h: SegmentTable) and
+// describe_all_kernel joins them.  Same chunk body as detect_fused_kernel (detect_chunk.inc), general taps.
+// ------------------------------------------------------------------------------------------------
+template <int kRecBytes>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) detect_multi_kernel(DetectTable tab, int max_pts) {
+  extern __shared__ float s_cands[];  // the wave's candidate list
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  int oi = 0;
+  while (oi + 1 < tab.n && b >= tab.o[oi + 1].first_block) ++oi;  // wave-uniform
+  const DetectOctave &O = tab.o[oi];
+  const int local = b - O.first_block;
+  const int bx = local % O.strips;
+  const int by = (local / O.strips) % O.chunks;
+  const int bz = local / (O.strips * O.chunks);
+  const int w = O.w, h = O.h, pitch = O.pitch;
+  const RowWindow rw{0, h};
+  const int gy0 = by * O.rows_per_wave;
+  const int ya = max(gy0, 1);
+  const int yb = min(gy0 + O.rows_per_wave, h - 1);  // local centres [ya, yb)
+  if (ya >= yb) return;                              // wave-uniform
+  const float *img = O.img + (long)bz * O.img_stride;
+  char *const list = O.lists + (size_t)bz * max_pts * kRecBytes;
+  unsigned int *counter = O.counters + bz;
+  CandList cands{s_cands, 0};
+  constexpr bool kIdent0 = false;
+  const LaplaceTapsPk &T = O.T;
+  const FindParams &P = O.P;
+#include "detect_chunk.inc"
+}
+
+template __global__ void detect_multi_kernel<kStagedRecBytes>(DetectTable, int);
 
 #define CUSIFT_DETECT_INSTANCE(IDENT, REC)                                                                         \
   template __global__ void detect_fused_kernel<IDENT, REC>(const float *, int, int, int, long, cusift_point *, int,  \

@@ -87,6 +87,28 @@ struct FindParams {
   float subsampling;
 };
 
+// One launch for several octaves of the fused detection (detect_multi_kernel): per octave what detect_fused_kernel takes
+// as arguments, plus the octave's range of workgroups.  Passed by value (kernarg: <= 4 KB).
+struct DetectOctave {
+  const float *img;        // image 0 of the octave
+  long img_stride;         // floats between images
+  char *lists;             // image 0's keypoint list of this octave (records or heads, the kernel's kRecBytes apart)
+  unsigned int *counters;  // [n_images]
+  int w, h, pitch;
+  int rows_per_wave;       // centre rows per workgroup (one wave each)
+  int strips, chunks;      // workgroups of this octave: strips x chunks x images, strip fastest
+  int first_block;         // its first workgroup in the launch
+  int reserved;
+  LaplaceTapsPk T;
+  FindParams P;
+};
+constexpr int kMaxMultiOctaves = 8;
+struct DetectTable {
+  int n;
+  DetectOctave o[kMaxMultiOctaves];
+};
+static_assert(sizeof(DetectTable) <= 3072, "DetectTable travels as a kernel argument");
+
 // per-(column split, row) result of the matcher, folded by match_merge_kernel
 struct MatchPartial {
   float best, second;

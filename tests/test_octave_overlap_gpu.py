@@ -50,21 +50,25 @@ def same_records(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f], equal_nan=True) for f in FIELDS)
 
 
-def context_with(monkeypatch, overlap, stage_all=None):
+def context_with(monkeypatch, overlap, stage_all=None, no_multi=False):
     """The knobs are read when the context is created."""
-    monkeypatch.setenv("CUSIFT_OCTAVE_OVERLAP", str(overlap))
+    env = {"CUSIFT_OCTAVE_OVERLAP": str(overlap)}
     if stage_all is not None:
-        monkeypatch.setenv("CUSIFT_STAGE_ALL", str(stage_all))
+        env["CUSIFT_STAGE_ALL"] = str(stage_all)
+    if no_multi:
+        env["CUSIFT_NO_MULTI"] = "1"
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     c = capi.Context(0)
-    monkeypatch.delenv("CUSIFT_OCTAVE_OVERLAP")
-    if stage_all is not None:
-        monkeypatch.delenv("CUSIFT_STAGE_ALL")
+    for k in env:
+        monkeypatch.delenv(k)
     return c
 
 
 # how the keypoints of a call reach SiftData (cusift_extract_batch): octave 0 on the side stream with a list of its own
-# and the coarser octaves in place; every octave to a list of its own on one stream; both
-MODES = {"fork": (2, 0), "lists": (0, 1), "fork+lists": (2, 1)}
+# and the coarser octaves in place; every octave to a list of its own and the coarser octaves searched by one launch
+# (or by a launch each); both
+MODES = {"fork": (2, 0), "lists": (0, 1), "lists, a launch per octave": (0, 1, True), "fork+lists": (2, 1)}
 
 
 @pytest.fixture(params=sorted(MODES))
