@@ -1120,6 +1120,10 @@ static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_
         o.T.k[q][j].x = taps[16 * (2 * q) + j];
         o.T.k[q][j].y = taps[16 * (2 * q + 1) + j];
       }
+    bool ident0 = !ctx->knobs.no_ident;  // levels 0 and 1 both identity (initBlur >= their sigma)?
+    for (int lv = 0; lv < 2; ++lv)
+      for (int j = 0; j < 9; ++j) ident0 = ident0 && (taps[16 * lv + j] == (j == kBlurRadius ? 1.0f : 0.0f));
+    o.ident = ident0 ? 1 : 0;
     find_params(o.P, peak_thresh, edge_thresh, m.subsampling);
     o.img = m.img;
     o.img_stride = (long)m.img_stride;
@@ -1557,12 +1561,12 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     for (int o = 1; o < pl.n_oct; ++o)
       TRY(cusift_scale_down(ctx, const_cast<float *>(base[o]), pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1],
                             pl.p[o - 1], stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
-    // With a list per octave the coarser octaves are searched by ONE launch, largest first
+    // With a list per octave all octaves (but a forked octave 0) are searched by ONE launch, largest first
     bool in_one_launch[kMaxOctaves] = {false};
     if (stage_all && !ctx->knobs.no_multi) {
       MultiOctave mo[kMaxMultiOctaves];
       int n_mo = 0;
-      for (int o = 1; o < pl.n_oct && n_mo < kMaxMultiOctaves; ++o)
+      for (int o = forked ? 1 : 0; o < pl.n_oct && n_mo < kMaxMultiOctaves; ++o)
         if (searched(o)) {
           mo[n_mo++] = MultiOctave{base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], pl.sub[o], list_of(o),
                                    seg_counts + (size_t)o * n_images};
@@ -1572,7 +1576,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
         TRY(detect_multi_impl(ctx, mo, n_mo, prm->peak_thresh, prm->edge_thresh, prm->max_pts, n_images,
                               forked ? 1 : prm->concurrent_batches));
       else
-        for (int o = 1; o < pl.n_oct; ++o) in_one_launch[o] = false;
+        for (int o = 0; o < pl.n_oct; ++o) in_one_launch[o] = false;
     }
     // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
     for (int o = pl.n_oct - 1; o >= (forked ? 1 : 0); --o) {

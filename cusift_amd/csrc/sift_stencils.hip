@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
 // they do not depend on each other, only on the ScaleDown chain.  One launch, the workgroups of octave 1 first and the
 // smaller ones behind them, costs what the largest costs.  Their keypoints cannot go to one list then (SiftData is
 // coarsest octave first): every octave appends to a list of its own (sift_types.h: SegmentTable) and
-// describe_all_kernel joins them.  Same chunk body as detect_fused_kernel (detect_chunk.inc), general taps.
+// describe_all_kernel joins them.  Same chunk body as detect_fused_kernel (detect_chunk.inc), in both instantiations.
 // ------------------------------------------------------------------------------------------------
 template <int kRecBytes>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) detect_multi_kernel(DetectTable tab, int max_pts) {
@@ -916,10 +916,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) de
   char *const list = O.lists + (size_t)bz * max_pts * kRecBytes;
   unsigned int *counter = O.counters + bz;
   CandList cands{s_cands, 0};
-  constexpr bool kIdent0 = false;
   const LaplaceTapsPk &T = O.T;
   const FindParams &P = O.P;
+  if (O.ident) {  // wave-uniform; both bodies live in this kernel, a wave runs one
+    constexpr bool kIdent0 = true;
 #include "detect_chunk.inc"
+  } else {
+    constexpr bool kIdent0 = false;
+#include "detect_chunk.inc"
+  }
 }
 
 template __global__ void detect_multi_kernel<kStagedRecBytes>(DetectTable, int);

@@ -98,7 +98,7 @@ struct DetectOctave {
   int rows_per_wave;       // centre rows per workgroup (one wave each)
   int strips, chunks;      // workgroups of this octave: strips x chunks x images, strip fastest
   int first_block;         // its first workgroup in the launch
-  int reserved;
+  int ident;               // levels 0 and 1 of T are the identity (initBlur >= their sigma): the pass-through body
   LaplaceTapsPk T;
   FindParams P;
 };
