@@ -123,6 +123,7 @@ struct Knobs {
   bool side_debug = false;                           // CUSIFT_SIDE_DEBUG: print the side stream's concurrency probe
   int stage_all = -1;                                // CUSIFT_STAGE_ALL: 0 never, 1 whenever it fits (default), 2 = 1
   bool no_multi = false;                             // CUSIFT_NO_MULTI: the coarser octaves one launch each, even with lists
+  int stage_all_mb = 0;                              // CUSIFT_STAGE_ALL_MB: largest staging for all octaves (0: default)
 };
 
 static Knobs read_knobs() {
@@ -149,6 +150,7 @@ static Knobs read_knobs() {
   k.side_debug = text("CUSIFT_SIDE_DEBUG") != nullptr;
   k.stage_all = num("CUSIFT_STAGE_ALL", -1);
   k.no_multi = text("CUSIFT_NO_MULTI") != nullptr;
+  k.stage_all_mb = num("CUSIFT_STAGE_ALL_MB", 0);
   return k;
 }
 
@@ -251,12 +253,12 @@ struct Plan {
   bool fork = false;  // octave 0's detection on the context's side stream
 };
 
-// Largest staging a context allocates: for octave 0 alone (the side stream), for all octaves (one launch for the coarser
-// octaves; a batch beyond it keeps the in-place lists)
-constexpr size_t kMaxStagedBytes = (size_t)1 << 30, kMaxStagedAllBytes = (size_t)256 << 20;
+// Largest staging a context allocates: for octave 0 alone (the side stream), for all octaves (one detection launch; a
+// batch beyond it keeps the in-place lists)
+constexpr size_t kMaxStagedBytes = (size_t)1 << 30, kMaxStagedAllBytes = (size_t)1 << 30;
 
 int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_params *prm, bool fork = false,
-              bool stage_all = false) {
+              bool stage_all = false, size_t stage_all_limit = kMaxStagedAllBytes) {
   if (!prm) return fail(CUSIFT_ERR_INVALID, "params is NULL");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w)
     return fail(CUSIFT_ERR_INVALID, "bad geometry n=%d w=%d h=%d pitch=%d", n_images, w, h, pitch);
@@ -293,7 +295,7 @@ int make_plan(Plan &pl, int n_images, int w, int h, int pitch, const cusift_para
   off = align_up_sz(off + (size_t)n_images * kMaxOctaves * sizeof(unsigned int), 256);
   const size_t per_octave = (size_t)n_images * prm->max_pts * kStagedRecBytes;
   pl.fork = fork && pl.n_oct >= 2 && per_octave <= kMaxStagedBytes;
-  pl.staged_octaves = (stage_all && pl.n_oct >= 2 && per_octave * pl.n_oct <= kMaxStagedAllBytes) ? pl.n_oct : (pl.fork ? 1 : 0);
+  pl.staged_octaves = (stage_all && pl.n_oct >= 2 && per_octave * pl.n_oct <= stage_all_limit) ? pl.n_oct : (pl.fork ? 1 : 0);
   if (pl.staged_octaves) {
     pl.staged_off = off;
     off = align_up_sz(off + per_octave * pl.staged_octaves, 256);
@@ -476,11 +478,23 @@ static bool wants_side_stream(const cusift_ctx *ctx, const cusift_params *prm, i
 }
 
 // Every octave's keypoints to staging lists, joined by describe_all_kernel: detections no longer have to run, or end, in
-// list order -- the coarser octaves are searched by ONE launch (detect_impl_multi).  Whenever the lists fit
-// (make_plan: kMaxStagedAllBytes), except with the per-octave stage sequence or the generic kernels.
-static bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_images) {
+// list order -- ALL octaves are searched by ONE launch (detect_multi_impl; two with octave 0 on the side stream), the
+// large octave's workgroups first and the small ones in its tail.  What it buys is dispatches and tails (MI355X,
+// 1080p, ms per call back to back on one stream: 1 frame 0.130 -> 0.082, 4: 0.210 -> 0.145, 16: 0.476 -> 0.389,
+// 64: 1.52 -> 1.41; with four calls in flight: 1 frame 0.062 -> 0.043, 4: 0.111 -> 0.106, 16: 0.338 -> 0.343,
+// 64: 1.165 -> 1.20 -- there the other batches fill the tails already and octave 0 is better off in its own, tuned
+// instantiation).  So: a lone caller whenever the lists fit, a pipelining caller up to eight 1080p frames' worth of
+// pixels per call.  Not with the per-octave stage sequence, the generic kernels or the stage timers on.
+constexpr size_t kListsMaxPixelsPipelined = 16u << 20;
+static size_t stage_all_limit(const cusift_ctx *ctx) {
+  return ctx->knobs.stage_all_mb > 0 ? (size_t)ctx->knobs.stage_all_mb << 20 : kMaxStagedAllBytes;
+}
+static bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h) {
   if (ctx->knobs.stage_all == 0 || ctx->knobs.force_generic) return false;
-  return prm && prm->fused_detect && n_images >= 1 && n_images <= kMaxFlatImages;
+  if (!prm || !prm->fused_detect || n_images < 1 || n_images > kMaxFlatImages) return false;
+  if (ctx->knobs.stage_all > 0) return true;  // tests: whenever the lists fit
+  if (ctx->timing) return false;  // the stage timers bracket the reference's launch-per-octave sequence
+  return prm->concurrent_batches < 2 || (size_t)n_images * (size_t)w * (size_t)h <= kListsMaxPixelsPipelined;
 }
 
 // A second stream only helps if the device runs it BESIDE the context's stream.  HIP maps streams onto a few hardware
@@ -677,7 +691,7 @@ extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, c
   TRY(enter(ctx));
   Plan pl;
   TRY(make_plan(pl, n_images, w, h, ialign_up(w, 128), p, wants_side_stream(ctx, p, n_images, w, h),
-                wants_stage_all(ctx, p, n_images)));
+                wants_stage_all(ctx, p, n_images, w, h), stage_all_limit(ctx)));
   // + one pitched upload image for cusift_extract_host
   return ensure_arena(ctx, pl.total + align_up_sz((size_t)h * ialign_up(w, 128) * sizeof(float), 256));
 }
@@ -1475,7 +1489,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   if (n_images > 1 && image_stride < (size_t)h * pitch) return fail(CUSIFT_ERR_INVALID, "image_stride too small");
   Plan pl;
   TRY(make_plan(pl, n_images, w, h, pitch, prm, wants_side_stream(ctx, prm, n_images, w, h),
-                wants_stage_all(ctx, prm, n_images)));
+                wants_stage_all(ctx, prm, n_images, w, h), stage_all_limit(ctx)));
   TRY(ensure_arena(ctx, pl.total));
   if (const size_t dog_need = two_stage_dog_bytes(ctx, pl, prm, d_imgs, image_stride, ctx->arena, n_images))
     TRY(ensure_dog(ctx, dog_need));  // sized once for the largest two-stage octave, before anything is enqueued
@@ -1684,7 +1698,7 @@ extern "C" int cusift_graph_create(cusift_ctx *ctx, cusift_graph **out, const fl
   Plan pl;
   // the side stream is found (and probed: that waits) before the capture starts; the fork and the join become edges
   const bool fork = wants_side_stream(ctx, prm, n_images, w, h) && ensure_side_stream(ctx) == CUSIFT_OK;
-  TRY(make_plan(pl, n_images, w, h, pitch, prm, fork, wants_stage_all(ctx, prm, n_images)));
+  TRY(make_plan(pl, n_images, w, h, pitch, prm, fork, wants_stage_all(ctx, prm, n_images, w, h), stage_all_limit(ctx)));
   // everything that allocates or synchronises happens before the capture starts
   TRY(ensure_arena(ctx, pl.total));
   // the DoG planes of every octave that takes the two-stage path (see cusift_extract_batch), sized up front
@@ -1773,7 +1787,7 @@ extern "C" int cusift_extract_host(cusift_ctx *ctx, const float *h_img, int w, i
   const int pitch = ialign_up(w, 128);  // cuImage::AllocateWithHostMemory, cuImage.cu:11-13
   Plan pl;
   TRY(make_plan(pl, 1, w, h, pitch, prm, wants_side_stream(ctx, prm, 1, w, h),
-                wants_stage_all(ctx, prm, 1)));  // the plan cusift_extract_batch will make
+                wants_stage_all(ctx, prm, 1, w, h), stage_all_limit(ctx)));  // the plan cusift_extract_batch will make
   const size_t img_bytes = align_up_sz((size_t)h * pitch * sizeof(float), 256);
   TRY(ensure_arena(ctx, pl.total + img_bytes));
   float *d_img = (float *)(ctx->arena + pl.total);
