@@ -78,9 +78,11 @@ typedef struct cusift_params {
                           GPU to itself -- the detection launches use short row chunks so that their tails stay
                           short; >= 2: other batches fill the tails, so tall chunks (less redundant blurring at chunk
                           borders) are faster.  cusift_amd.batch.PipelinedExtractor sets it to its stream count.
-                          With 1 a call of three 1080p frames' worth of pixels or more also runs octave 0's detection
-                          on a second stream of the context, beside the ScaleDown chain and the coarser octaves
-                          (cusift_ctx_forks; same SiftData, coarsest octave first). */
+                          With 1 the driver searches all octaves with ONE launch whenever a keypoint list per octave
+                          fits the arena (with >= 2: up to eight 1080p frames' worth of pixels per call), and a call of
+                          three 1080p frames' worth of pixels or more also runs octave 0's detection on a second stream
+                          of the context, beside the ScaleDown chain (cusift_ctx_forks).  Same SiftData either way,
+                          coarsest octave first. */
 } cusift_params;
 
 typedef struct cusift_ctx cusift_ctx; /* opaque: device, stream, scratch arena, timers */
