@@ -31,6 +31,7 @@ __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_p
                                     LaplaceTapsPk, FindParams, RowWindow, int, int);
 template <int kRecBytes>
 __global__ void detect_multi_kernel(DetectTable, int);
+__global__ void pyramid_small_kernel(PyramidLevels, ScaleDownTaps);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
                                    FindParams);
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
@@ -124,6 +125,7 @@ struct Knobs {
   int stage_all = -1;                                // CUSIFT_STAGE_ALL: 0 never, 1 whenever it fits (default), 2 = 1
   bool no_multi = false;                             // CUSIFT_NO_MULTI: the coarser octaves one launch each, even with lists
   int stage_all_mb = 0;                              // CUSIFT_STAGE_ALL_MB: largest staging for all octaves (0: default)
+  int small_pyramid = -1;                            // CUSIFT_SMALL_PYRAMID: 0 never, 1 always, default by size
 };
 
 static Knobs read_knobs() {
@@ -151,6 +153,7 @@ static Knobs read_knobs() {
   k.stage_all = num("CUSIFT_STAGE_ALL", -1);
   k.no_multi = text("CUSIFT_NO_MULTI") != nullptr;
   k.stage_all_mb = num("CUSIFT_STAGE_ALL_MB", 0);
+  k.small_pyramid = num("CUSIFT_SMALL_PYRAMID", -1);
   return k;
 }
 
@@ -924,6 +927,54 @@ static int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t 
   return check_launch("scale_down");
 }
 
+// The ScaleDown chain of a small call -- levels 1 .. n from level 0 -- in ONE launch (pyramid_small_kernel).
+// A call takes it up to kPyramidSmallPixels source pixels (one 1080p frame: four launches of 6-10 us become one of
+// ~10); beyond that the 2.9x re-reads of the source cost more than the dispatches.  Not with the stage timers on (they
+// count one ScaleDown per octave).
+constexpr size_t kPyramidSmallPixels = (size_t)5 << 19;  // 2.6 Mpixel
+static bool wants_small_pyramid(const cusift_ctx *ctx, int n_images, int w, int h) {
+  if (ctx->knobs.small_pyramid == 0 || ctx->knobs.force_generic) return false;
+  if (ctx->knobs.small_pyramid > 0) return true;
+  return !ctx->timing && (size_t)n_images * (size_t)w * (size_t)h <= kPyramidSmallPixels;
+}
+
+static int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const int *w, const int *h, const int *pitch,
+                              const size_t *stride, int n_levels, int n_images, float variance) {
+  TRY(enter(ctx));
+  if (n_levels < 1 || n_levels > kMaxPyramidLevels || n_images < 1)
+    return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): 1..%d levels", kMaxPyramidLevels);
+  if (!(variance > 0.0f)) return fail(CUSIFT_ERR_INVALID, "ScaleDown: variance must be > 0");
+  PyramidLevels P;
+  memset(&P, 0, sizeof(P));
+  P.n = n_levels;
+  P.tile = 64 >> n_levels;  // 32, 16, 8, 4: a workgroup needs about 60 x 60 pixels of level 1 whatever the depth
+  for (int k = 0; k <= n_levels; ++k) {
+    if (!base[k] || w[k] < 1 || h[k] < 1 || pitch[k] < w[k]) return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): bad level %d", k);
+    if (k > 0 && (w[k] != w[k - 1] / 2 || h[k] != h[k - 1] / 2)) return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): level %d is not half of level %d", k, k - 1);
+    P.base[k] = const_cast<float *>(base[k]);
+    P.w[k] = w[k];
+    P.h[k] = h[k];
+    P.pitch[k] = pitch[k];
+    P.stride[k] = (long)stride[k];
+  }
+  // LDS: the needed squares of every level + the largest H, for the largest workgroup: a side grows as 2 s + 3 going
+  // down a level, + 1 for the odd remainder an owner at the far edge takes on
+  size_t floats = 0, h_max = 0;
+  int side = P.tile;
+  for (int k = n_levels; k >= 1; --k) {
+    floats += (size_t)side * side;
+    h_max = std::max(h_max, (size_t)(2 * side + 3) * side);
+    side = 2 * side + 4;
+  }
+  floats += h_max;
+  ScaleDownTaps T;
+  scale_down_taps(T, variance);
+  dim3 grid(idiv_up(w[n_levels], P.tile), idiv_up(h[n_levels], P.tile), n_images);
+  StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
+  hipLaunchKernelGGL(pyramid_small_kernel, grid, dim3(256), floats * sizeof(float), ctx->stream, P, T);
+  return check_launch("scale_down (levels)");
+}
+
 extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
                                  int w, int h, int src_pitch, size_t src_stride, int n_images, float variance) {
   if (h / 2 < 1) return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);
@@ -1151,6 +1202,24 @@ static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_
     o.chunks = idiv_up(m.h, o.rows_per_wave);
     o.first_block = (int)blocks;
     blocks += (long)o.strips * o.chunks * n_images;
+  }
+  // A small call's workgroups should all be resident at once (two single-wave workgroups per SIMD): a handful beyond
+  // that would run as a second round of their own -- one more chunk's latency for the whole launch (one 1080p frame:
+  // 2160 workgroups on 2048 slots, 34 us; taller chunks that fit, 26 us).
+  const long slots = (long)ctx->num_cus * 4 * 2;
+  if (blocks > slots && blocks <= 2 * slots) {
+    for (int grow = 1; grow <= 8 && blocks > slots; ++grow) {
+      blocks = 0;
+      for (int k = 0; k < n_octaves; ++k) {
+        DetectOctave &o = tab.o[k];
+        if (o.chunks > 1) {  // taller chunks for the octaves that have several
+          o.rows_per_wave += std::max(1, o.rows_per_wave / 8);
+          o.chunks = idiv_up(o.h, o.rows_per_wave);
+        }
+        o.first_block = (int)blocks;
+        blocks += (long)o.strips * o.chunks * n_images;
+      }
+    }
   }
   if (blocks > 0x7fffffffL) return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): too many workgroups");
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
@@ -1552,8 +1621,12 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   }
   // cuSIFT.cu:69: point counter = 0 (with every octave staged join_counts_kernel writes it instead)
   if (!stage_all) HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));
-  if (G.n_seg)
-    HIP_TRY(hipMemsetAsync(seg_counts, 0, sizeof(unsigned int) * n_images * (stage_all ? pl.n_oct : 1), ctx->stream));
+  if (G.n_seg) {
+    // (a multiple of 64 bytes: the runtime fills an odd size with two dispatches; the region is kMaxOctaves x n_images)
+    const size_t bytes = sizeof(unsigned int) * n_images * (stage_all ? pl.n_oct : 1);
+    HIP_TRY(hipMemsetAsync(seg_counts, 0, std::min(align_up_sz(bytes, 64), sizeof(unsigned int) * n_images * kMaxOctaves),
+                           ctx->stream));
+  }
 
   if (forked) {
     ctx->forks++;
@@ -1571,8 +1644,13 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   }
   // the side stream rejoins the context's stream however the work in between ends
   auto on_main = [&]() -> int {
-    // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest
-    for (int o = 1; o < pl.n_oct; ++o)
+    // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest -- a small call's first levels in one launch
+    int built = 0;
+    if (pl.n_oct >= 2 && wants_small_pyramid(ctx, n_images, w, h)) {
+      built = std::min(pl.n_oct - 1, kMaxPyramidLevels);
+      TRY(pyramid_small_impl(ctx, base, pl.w, pl.h, pl.p, stride, built, n_images, 0.5f));
+    }
+    for (int o = built + 1; o < pl.n_oct; ++o)
       TRY(cusift_scale_down(ctx, const_cast<float *>(base[o]), pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1],
                             pl.p[o - 1], stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
     // With a list per octave all octaves (but a forked octave 0) are searched by ONE launch, largest first

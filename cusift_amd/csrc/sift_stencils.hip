@@ -887,6 +887,114 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
 
 
 // ------------------------------------------------------------------------------------------------
+// The ScaleDown chain of a small call in ONE launch.  For one 1080p frame the four ScaleDowns are 6-10 us launches each,
+// nearly all of it dispatch; they depend on each other (level k+1 reads level k), so one launch has to carry the
+// dependency inside: a workgroup owns a square of the LAST level, works out which pixels of every level it needs for
+// it (out <- source columns 2c-2 .. 2c+2 and rows 2r-1 .. 2r+3, clamped: the reference's windows, cuSIFT_D.cu:75-177),
+// and computes them level by level in LDS -- horizontal pass into H, vertical pass into the level -- recomputing what
+// its neighbours also compute (for four levels a 109 x 109 source region per 4 x 4 pixels of level 4: 2.9x the reads,
+// which is why only small calls take this kernel).  Every level's pixels are written to HBM by the one workgroup that
+// OWNS them (its square scaled up; the last square of a row / column also takes the odd remainder).  Same operations
+// in the same order as scale_down_fast_kernel on the same values: the same bits whoever computes a pixel.
+// ------------------------------------------------------------------------------------------------
+struct PyrRange {
+  int x0, x1, y0, y1;  // [x0, x1) x [y0, y1)
+  __device__ __forceinline__ int w() const { return x1 - x0; }
+  __device__ __forceinline__ int h() const { return y1 - y0; }
+};
+
+__global__ void __launch_bounds__(256) pyramid_small_kernel(PyramidLevels P, ScaleDownTaps T) {
+  extern __shared__ float s_pyr[];
+  const int tid = threadIdx.x;
+  const long img = blockIdx.z;
+  // what this workgroup owns (writes) and needs (computes) of every level, from the last level down
+  PyrRange own[kMaxPyramidLevels + 2], need[kMaxPyramidLevels + 2];
+#pragma unroll
+  for (int k = kMaxPyramidLevels; k >= 1; --k) {  // (compile-time indices: the ranges stay in registers)
+    if (k > P.n) continue;
+    if (k == P.n) {
+      own[k].x0 = blockIdx.x * P.tile;
+      own[k].y0 = blockIdx.y * P.tile;
+      own[k].x1 = min(own[k].x0 + P.tile, P.w[k]);
+      own[k].y1 = min(own[k].y0 + P.tile, P.h[k]);
+      need[k] = own[k];
+    } else {
+      // level k: owned = the owner's square scaled up (+ the odd remainder at the far edges) ...
+      own[k].x0 = 2 * own[k + 1].x0;
+      own[k].y0 = 2 * own[k + 1].y0;
+      own[k].x1 = own[k + 1].x1 == P.w[k + 1] ? P.w[k] : 2 * own[k + 1].x1;
+      own[k].y1 = own[k + 1].y1 == P.h[k + 1] ? P.h[k] : 2 * own[k + 1].y1;
+      // ... needed = owned + what level k+1's needed pixels read (clamped to the image)
+      need[k].x0 = min(own[k].x0, max(2 * need[k + 1].x0 - 2, 0));
+      need[k].x1 = max(own[k].x1, min(2 * (need[k + 1].x1 - 1) + 2, P.w[k] - 1) + 1);
+      need[k].y0 = min(own[k].y0, max(2 * need[k + 1].y0 - 1, 0));
+      need[k].y1 = max(own[k].y1, min(2 * (need[k + 1].y1 - 1) + 3, P.h[k] - 1) + 1);
+    }
+  }
+  need[0] = own[0] = PyrRange{0, 0, 0, 0};
+  const float k0 = T.k[0], k1 = T.k[1], k2 = T.k[2];
+  // LDS: [ H of the current level | level 1 | level 2 | ... ]; the levels stay (level k+1 reads level k)
+  float *lvl[kMaxPyramidLevels + 1];
+  float *cursor = s_pyr;
+  lvl[0] = nullptr;
+#pragma unroll
+  for (int k = 1; k <= kMaxPyramidLevels; ++k) {
+    lvl[k] = cursor;
+    if (k <= P.n) cursor += need[k].w() * need[k].h();
+  }
+  float *const H = cursor;  // the largest H (level 1's) fits behind the levels: the host sizes the allocation for it
+
+#pragma unroll
+  for (int k = 1; k <= kMaxPyramidLevels; ++k) {
+    if (k > P.n) break;
+    const int sw = P.w[k - 1], sh = P.h[k - 1];  // source level
+    const PyrRange N = need[k];
+    const int nw = N.w();
+    // source rows the vertical pass reads, clamped: [ry0, ry1]
+    const int ry0 = max(2 * N.y0 - 1, 0), ry1 = min(2 * (N.y1 - 1) + 3, sh - 1);
+    const int hrows = ry1 - ry0 + 1;
+    // horizontal pass: H[y - ry0][c - N.x0] for the source rows y and the needed columns c
+    const float *src0 = P.base[0] + img * P.stride[0];
+    const PyrRange S = need[k - 1];  // (k >= 2) where level k-1 sits in LDS
+    const int spw = k >= 2 ? S.w() : 0;
+    // (unrolled: level 1 reads HBM, and a thread's ~29 elements would otherwise be 29 memory latencies in a row)
+    for (int e = tid; e < hrows * nw; e += 256) {
+      const int yy = e / nw, cc = e - yy * nw;
+      const int y = ry0 + yy, c = N.x0 + cc;
+      const int xa = max(2 * c - 2, 0), xb = max(2 * c - 1, 0), xc = 2 * c, xd = min(2 * c + 1, sw - 1), xe = min(2 * c + 2, sw - 1);
+      float a0, a1, a2, a3, a4;
+      if (k == 1) {
+        const float *r = src0 + (long)y * P.pitch[0];
+        a0 = r[xa], a1 = r[xb], a2 = r[min(xc, sw - 1)], a3 = r[xd], a4 = r[xe];
+      } else {
+        const float *r = lvl[k - 1] + (y - S.y0) * spw - S.x0;
+        a0 = r[xa], a1 = r[xb], a2 = r[min(xc, sw - 1)], a3 = r[xd], a4 = r[xe];
+      }
+      float v = k0 * (a0 + a4);
+      v = fmaf(k1, a1 + a3, v);
+      v = fmaf(k2, a2, v);
+      H[e] = v;
+    }
+    __syncthreads();
+    // vertical pass: level k over the needed range; the owned part also goes to HBM
+    float *dst = P.base[k] + img * P.stride[k];
+    const PyrRange O = own[k];
+    for (int e = tid; e < N.h() * nw; e += 256) {
+      const int rr = e / nw, cc = e - rr * nw;
+      const int r = N.y0 + rr, c = N.x0 + cc;
+      const float *h = H + cc;
+      auto row = [&](int y) { return h[(min(max(y, 0), sh - 1) - ry0) * nw]; };
+      float v = k2 * row(2 * r);
+      v = fmaf(k0, row(2 * r + 3) + row(2 * r + 2), v);
+      v = fmaf(k1, row(2 * r - 1) + row(2 * r + 1), v);
+      lvl[k][e] = v;
+      if (r >= O.y0 && r < O.y1 && c >= O.x0 && c < O.x1) dst[(long)r * P.pitch[k] + c] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The fused detection of SEVERAL octaves in one launch.  The coarser octaves of an image are small -- for one 1080p frame
 // octaves 1..4 are 14-16 us launches each, most of it the launch itself and the latency of a chunk's window fill -- and
 // they do not depend on each other, only on the ScaleDown chain.  One launch, the workgroups of octave 1 first and the

@@ -87,6 +87,16 @@ struct FindParams {
   float subsampling;
 };
 
+// The ScaleDown chain of a SMALL call in one launch (pyramid_small_kernel): level k+1 from level k, k = 0 .. n-1.
+constexpr int kMaxPyramidLevels = 4;
+struct PyramidLevels {
+  int n;                                  // levels produced (1..kMaxPyramidLevels)
+  int tile;                               // side of a workgroup's square of level n
+  int w[kMaxPyramidLevels + 1], h[kMaxPyramidLevels + 1], pitch[kMaxPyramidLevels + 1];
+  long stride[kMaxPyramidLevels + 1];     // floats between images
+  float *base[kMaxPyramidLevels + 1];     // image 0 of level k (base[0]: the source, read only)
+};
+
 // One launch for several octaves of the fused detection (detect_multi_kernel): per octave what detect_fused_kernel takes
 // as arguments, plus the octave's range of workgroups.  Passed by value (kernarg: <= 4 KB).
 struct DetectOctave {
