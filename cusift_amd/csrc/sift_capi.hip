@@ -1203,24 +1203,6 @@ static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_
     o.first_block = (int)blocks;
     blocks += (long)o.strips * o.chunks * n_images;
   }
-  // A small call's workgroups should all be resident at once (two single-wave workgroups per SIMD): a handful beyond
-  // that would run as a second round of their own -- one more chunk's latency for the whole launch (one 1080p frame:
-  // 2160 workgroups on 2048 slots, 34 us; taller chunks that fit, 26 us).
-  const long slots = (long)ctx->num_cus * 4 * 2;
-  if (blocks > slots && blocks <= 2 * slots) {
-    for (int grow = 1; grow <= 8 && blocks > slots; ++grow) {
-      blocks = 0;
-      for (int k = 0; k < n_octaves; ++k) {
-        DetectOctave &o = tab.o[k];
-        if (o.chunks > 1) {  // taller chunks for the octaves that have several
-          o.rows_per_wave += std::max(1, o.rows_per_wave / 8);
-          o.chunks = idiv_up(o.h, o.rows_per_wave);
-        }
-        o.first_block = (int)blocks;
-        blocks += (long)o.strips * o.chunks * n_images;
-      }
-    }
-  }
   if (blocks > 0x7fffffffL) return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): too many workgroups");
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
   hipLaunchKernelGGL(detect_multi_kernel<kStagedRecBytes>, dim3((unsigned int)blocks), dim3(64),
