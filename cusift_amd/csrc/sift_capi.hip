@@ -30,15 +30,15 @@ template <bool kIdent0, int kRecBytes>
 __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                     LaplaceTapsPk, FindParams, RowWindow, int, int);
 template <int kRecBytes>
-__global__ void detect_multi_kernel(DetectTable, int);
-__global__ void pyramid_small_kernel(PyramidLevels, ScaleDownTaps);
+__global__ void detect_multi_kernel(DetectTable, int, unsigned int *);
+__global__ void pyramid_small_kernel(PyramidLevels, ScaleDownTaps, unsigned int *, int);
 __global__ void find_points_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int, int,
                                    FindParams);
 __global__ void orientations_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                     const unsigned int *, float, float, RowWindow);
 __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_point *, int, const unsigned int *,
                                    const unsigned int *, float, float, float, RowWindow, int, unsigned int *);
-__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, const unsigned int *, int, float, float, int,
+__global__ void describe_all_kernel(OctaveTable, cusift_point *, int, unsigned int *, int, float, float, int,
                                     unsigned int *, SegmentTable, const unsigned int *);
 __global__ void join_counts_kernel(unsigned int *, SegmentTable, unsigned int *, int, int, unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
@@ -939,7 +939,8 @@ static bool wants_small_pyramid(const cusift_ctx *ctx, int n_images, int w, int 
 }
 
 static int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const int *w, const int *h, const int *pitch,
-                              const size_t *stride, int n_levels, int n_images, float variance) {
+                              const size_t *stride, int n_levels, int n_images, float variance, unsigned int *d_zero,
+                              int n_zero) {
   TRY(enter(ctx));
   if (n_levels < 1 || n_levels > kMaxPyramidLevels || n_images < 1)
     return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): 1..%d levels", kMaxPyramidLevels);
@@ -971,7 +972,7 @@ static int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const i
   scale_down_taps(T, variance);
   dim3 grid(idiv_up(w[n_levels], P.tile), idiv_up(h[n_levels], P.tile), n_images);
   StageTimer t(ctx, CUSIFT_STAGE_SCALEDOWN);
-  hipLaunchKernelGGL(pyramid_small_kernel, grid, dim3(256), floats * sizeof(float), ctx->stream, P, T);
+  hipLaunchKernelGGL(pyramid_small_kernel, grid, dim3(256), floats * sizeof(float), ctx->stream, P, T, d_zero, n_zero);
   return check_launch("scale_down (levels)");
 }
 
@@ -1166,7 +1167,7 @@ struct MultiOctave {
 };
 
 static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_octaves, float peak_thresh,
-                             float edge_thresh, int max_pts, int n_images, int concurrent) {
+                             float edge_thresh, int max_pts, int n_images, int concurrent, unsigned int *d_queue) {
   TRY(enter(ctx));
   if (n_octaves < 1 || n_octaves > kMaxMultiOctaves) return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): 1..%d octaves", kMaxMultiOctaves);
   DetectTable tab;
@@ -1206,7 +1207,7 @@ static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_
   if (blocks > 0x7fffffffL) return fail(CUSIFT_ERR_INVALID, "DetectMulti (octaves): too many workgroups");
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
   hipLaunchKernelGGL(detect_multi_kernel<kStagedRecBytes>, dim3((unsigned int)blocks), dim3(64),
-                     kDetectWaveLdsFloats * sizeof(float), ctx->stream, tab, max_pts);
+                     kDetectWaveLdsFloats * sizeof(float), ctx->stream, tab, max_pts, d_queue);
   return check_launch("detect_multi (octaves)");
 }
 
@@ -1601,13 +1602,23 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     G.base[1] = reinterpret_cast<const char *>(list_of(0));
     G.count[1] = seg_counts;
   }
-  // cuSIFT.cu:69: point counter = 0 (with every octave staged join_counts_kernel writes it instead)
+  // A small call's dispatches are most of its time, so its housekeeping rides along: the ScaleDown chain in one launch
+  // (which also clears the lists' counters), all octaves in one detection launch (which also clears describe_all's work
+  // cursors), and describe_all_kernel joins the lists itself -- pyramid, detection, description: three dispatches.
+  const bool small_pyramid = pl.n_oct >= 2 && wants_small_pyramid(ctx, n_images, w, h);
+  int n_one_launch = 0;  // octaves the one detection launch would take
+  if (stage_all && !ctx->knobs.no_multi)
+    for (int o = forked ? 1 : 0; o < pl.n_oct && n_one_launch < kMaxMultiOctaves; ++o) n_one_launch += searched(o) ? 1 : 0;
+  const bool one_launch = n_one_launch >= 2;
+  const bool self_join = stage_all && one_launch;              // no join_counts_kernel: describe_all_kernel joins
+  const bool pyramid_clears = small_pyramid && stage_all && !forked;  // (a forked octave 0 may count before the pyramid runs)
+  // cuSIFT.cu:69: point counter = 0 (with every octave staged the join writes it instead)
   if (!stage_all) HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));
-  if (G.n_seg) {
+  const size_t n_seg_counts = (size_t)n_images * (stage_all ? pl.n_oct : 1);
+  if (G.n_seg && !pyramid_clears) {
     // (a multiple of 64 bytes: the runtime fills an odd size with two dispatches; the region is kMaxOctaves x n_images)
-    const size_t bytes = sizeof(unsigned int) * n_images * (stage_all ? pl.n_oct : 1);
-    HIP_TRY(hipMemsetAsync(seg_counts, 0, std::min(align_up_sz(bytes, 64), sizeof(unsigned int) * n_images * kMaxOctaves),
-                           ctx->stream));
+    HIP_TRY(hipMemsetAsync(seg_counts, 0, std::min(align_up_sz(sizeof(unsigned int) * n_seg_counts, 64),
+                                                   sizeof(unsigned int) * n_images * kMaxOctaves), ctx->stream));
   }
 
   if (forked) {
@@ -1628,16 +1639,17 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   auto on_main = [&]() -> int {
     // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest -- a small call's first levels in one launch
     int built = 0;
-    if (pl.n_oct >= 2 && wants_small_pyramid(ctx, n_images, w, h)) {
+    if (small_pyramid) {
       built = std::min(pl.n_oct - 1, kMaxPyramidLevels);
-      TRY(pyramid_small_impl(ctx, base, pl.w, pl.h, pl.p, stride, built, n_images, 0.5f));
+      TRY(pyramid_small_impl(ctx, base, pl.w, pl.h, pl.p, stride, built, n_images, 0.5f,
+                             pyramid_clears ? seg_counts : nullptr, pyramid_clears ? (int)n_seg_counts : 0));
     }
     for (int o = built + 1; o < pl.n_oct; ++o)
       TRY(cusift_scale_down(ctx, const_cast<float *>(base[o]), pl.p[o], stride[o], base[o - 1], pl.w[o - 1], pl.h[o - 1],
                             pl.p[o - 1], stride[o - 1], n_images, 0.5f));  // cuSIFT.cu:185
     // With a list per octave all octaves (but a forked octave 0) are searched by ONE launch, largest first
     bool in_one_launch[kMaxOctaves] = {false};
-    if (stage_all && !ctx->knobs.no_multi) {
+    if (one_launch) {
       MultiOctave mo[kMaxMultiOctaves];
       int n_mo = 0;
       for (int o = forked ? 1 : 0; o < pl.n_oct && n_mo < kMaxMultiOctaves; ++o)
@@ -1646,11 +1658,8 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
                                    seg_counts + (size_t)o * n_images};
           in_one_launch[o] = true;
         }
-      if (n_mo >= 2)
-        TRY(detect_multi_impl(ctx, mo, n_mo, prm->peak_thresh, prm->edge_thresh, prm->max_pts, n_images,
-                              forked ? 1 : prm->concurrent_batches));
-      else
-        for (int o = 0; o < pl.n_oct; ++o) in_one_launch[o] = false;
+      TRY(detect_multi_impl(ctx, mo, n_mo, prm->peak_thresh, prm->edge_thresh, prm->max_pts, n_images,
+                            forked ? 1 : prm->concurrent_batches, ctx->d_queue));
     }
     // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
     for (int o = pl.n_oct - 1; o >= (forked ? 1 : 0); --o) {
@@ -1713,7 +1722,9 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     const long want = std::max(1L, std::min(cap, (long)ctx->describe_grid));
     dim3 grid((unsigned int)std::max<long>(kQueueShards, want / kQueueShards * kQueueShards));
     unsigned int *queue = ctx->d_queue;  // the kernel's work cursors, zero at launch
-    if (G.n_seg) {
+    if (self_join) {
+      // (the detection launch cleared the cursors; describe_all_kernel joins the lists itself)
+    } else if (G.n_seg) {
       hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counters, G, seg_end, n_images,
                          prm->max_pts, queue);
       TRY(check_launch("join_counts"));
@@ -1722,7 +1733,8 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     }
     StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
     hipLaunchKernelGGL(describe_all_kernel, grid, dim3(64), 0, ctx->stream, T, d_points, prm->max_pts, d_counters,
-                       n_images, q, inv_q, prm->root_sift, queue, G, (const unsigned int *)seg_end);
+                       n_images, q, inv_q, prm->root_sift, queue, G,
+                       self_join ? (const unsigned int *)nullptr : (const unsigned int *)seg_end);
     TRY(check_launch("describe_all"));
   }
   return CUSIFT_OK;

@@ -767,21 +767,31 @@ __device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, c
 // 4 waves per SIMD (<= 128 VGPRs) is what this kernel needs: its LDS read-modify-write chains and dependent taps are
 // latency that only other waves hide (forced to 3 / 2 waves the launch takes 1.25x / 1.8x as long)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) describe_all_kernel(OctaveTable T, cusift_point *__restrict__ points, int max_pts,
-                                                         const unsigned int *__restrict__ counters, int n_images,
+                                                         unsigned int *counters, int n_images,
                                                          float q, float inv_q, int root_sift,
                                                          unsigned int *__restrict__ queue,
                                                          SegmentTable G,
                                                          const unsigned int *__restrict__ seg_end) {
   // G.n_seg == 0: every keypoint was appended to `points` directly.  Otherwise the batch's keypoints wait in segments
   // (sift_types.h) -- octave 0's when cusift_extract_batch ran that octave's detection beside the coarser ones, every
-  // octave's when the coarser octaves were searched by one launch -- and are moved into place here, coarsest octave
-  // first: keypoint k of image i belongs to the first segment r with k < seg_end[i * n_seg + r].
+  // octave's when the octaves were searched by one launch -- and are moved into place here, coarsest octave first:
+  // keypoint k of image i belongs to the first segment r with k < seg_end[i * n_seg + r].  seg_end == NULL (with every
+  // segment staged): no join_counts_kernel ran -- a small call saves that dispatch -- and this kernel forms the running
+  // sums itself from the segments' counters, workgroup 0 also leaving the images' totals in `counters`.
   __shared__ KpShared S;
   __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
   const int lane = threadIdx.x;
   // exclusive prefix sums of the per-image counts (every block computes them: n_images <= kMaxFlatImages)
+  const bool self_join = G.n_seg > 0 && seg_end == nullptr;  // wave-uniform
   for (int i = lane; i < n_images; i += 64) {
-    const unsigned int c = counters[i];
+    unsigned int c;
+    if (self_join) {
+      c = 0;
+      for (int r = 0; r < G.n_seg; ++r) c += G.count[r][i];
+      if (blockIdx.x == 0) counters[i] = c;  // what one stream would have counted (nobody reads it in this launch)
+    } else {
+      c = counters[i];
+    }
     s_prefix[i + 1] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
   }
   wave_sync();
@@ -820,10 +830,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     cusift_point *dst = points + (long)im * max_pts + idx;
     src = dst;
     if (G.n_seg > 0) {
-      const unsigned int *ends = seg_end + im * G.n_seg;  // wave-uniform: scalar loads
       int r = 0;
-      unsigned int first = 0;
-      while (idx >= ends[r]) first = ends[r++];  // ends: idx < this image's total = ends[n_seg - 1]
+      unsigned int first = 0;  // keypoints of this image in the segments before r
+      if (self_join) {
+        for (;; ++r) {  // ends: idx < this image's clamped total
+          const unsigned int c = G.count[r][im], room = (unsigned int)max_pts - first;
+          const unsigned int kept = c < room ? c : room;
+          if (idx < first + kept) break;
+          first += kept;
+        }
+      } else {
+        const unsigned int *ends = seg_end + im * G.n_seg;  // wave-uniform: scalar loads
+        while (idx >= ends[r]) first = ends[r++];  // ends: idx < this image's total = ends[n_seg - 1]
+      }
       const char *base = G.base[r];
       if (base) src = reinterpret_cast<const cusift_point *>(base + ((size_t)im * max_pts + (idx - first)) * kStagedRecBytes);
     }

@@ -903,9 +903,13 @@ struct PyrRange {
   __device__ __forceinline__ int h() const { return y1 - y0; }
 };
 
-__global__ void __launch_bounds__(256) pyramid_small_kernel(PyramidLevels P, ScaleDownTaps T) {
+__global__ void __launch_bounds__(256) pyramid_small_kernel(PyramidLevels P, ScaleDownTaps T, unsigned int *zero,
+                                                            int n_zero) {
   extern __shared__ float s_pyr[];
   const int tid = threadIdx.x;
+  // (the driver's keypoint counters for the detection that follows: saves a small call the memset dispatch)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = tid; i < n_zero; i += 256) zero[i] = 0u;
   const long img = blockIdx.z;
   // what this workgroup owns (writes) and needs (computes) of every level, from the last level down
   PyrRange own[kMaxPyramidLevels + 2], need[kMaxPyramidLevels + 2];
@@ -1003,10 +1007,14 @@ __global__ void __launch_bounds__(256) pyramid_small_kernel(PyramidLevels P, Sca
 // describe_all_kernel joins them.  Same chunk body as detect_fused_kernel (detect_chunk.inc), in both instantiations.
 // ------------------------------------------------------------------------------------------------
 template <int kRecBytes>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) detect_multi_kernel(DetectTable tab, int max_pts) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) detect_multi_kernel(DetectTable tab, int max_pts,
+                                                                                          unsigned int *queue) {
   extern __shared__ float s_cands[];  // the wave's candidate list
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
+  // (describe_all_kernel's work cursors for the launch that follows: saves a small call the memset dispatch)
+  if (b == 0 && queue)
+    for (int i = lane; i < kQueueShards * 32; i += 64) queue[i] = 0u;
   int oi = 0;
   while (oi + 1 < tab.n && b >= tab.o[oi + 1].first_block) ++oi;  // wave-uniform
   const DetectOctave &O = tab.o[oi];
@@ -1035,7 +1043,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) de
   }
 }
 
-template __global__ void detect_multi_kernel<kStagedRecBytes>(DetectTable, int);
+template __global__ void detect_multi_kernel<kStagedRecBytes>(DetectTable, int, unsigned int *);
 
 #define CUSIFT_DETECT_INSTANCE(IDENT, REC)                                                                         \
   template __global__ void detect_fused_kernel<IDENT, REC>(const float *, int, int, int, long, cusift_point *, int,  \

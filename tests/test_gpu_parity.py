@@ -664,7 +664,7 @@ def test_graph_replay_equals_eager(ctx, gray1):
         return canonical(d_pts.to_numpy(SIFT_POINT_DTYPE, (prm.max_pts,))[:n])
 
     graph = ctx.record_graph(d_img.ptr, 1, w, h, p, h * p, prm, d_pts.ptr, d_cnt.ptr)
-    assert graph.nodes >= 5  # memset + the ScaleDown chain and the detection of all octaves in one launch each + join + describe_all
+    assert graph.nodes >= 3  # the ScaleDown chain, the detection of all octaves, description: one launch each
     for f in frames:
         ctx.h2d(d_img.ptr, pitched(f))
         d_pts.zero()
