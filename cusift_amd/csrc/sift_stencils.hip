@@ -961,7 +961,8 @@ __global__ void __launch_bounds__(256) pyramid_small_kernel(PyramidLevels P, Sca
     const float *src0 = P.base[0] + img * P.stride[0];
     const PyrRange S = need[k - 1];  // (k >= 2) where level k-1 sits in LDS
     const int spw = k >= 2 ? S.w() : 0;
-    // (unrolled: level 1 reads HBM, and a thread's ~29 elements would otherwise be 29 memory latencies in a row)
+    // (tried and dropped, same-box A/B on one 1080p frame: unrolling this loop by 8, +1.5 % per frame; a thread per
+    // column that walks the rows -- a third of the instructions -- +4 %: the kernel is latency-, not issue-bound)
     for (int e = tid; e < hrows * nw; e += 256) {
       const int yy = e / nw, cc = e - yy * nw;
       const int y = ry0 + yy, c = N.x0 + cc;
