@@ -136,6 +136,7 @@ SIGNATURES = {
     "cusift_u8_to_f32": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i]),
     "cusift_gaussian3x3": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
     "cusift_scale_down": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
+    "cusift_scale_down_levels": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _vp, _vp, _i, _i, _f]),
     "cusift_laplace_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _vp, _sz, _i]),
     "cusift_laplace_taps": (_i, [_f, _vp]),
     "cusift_find_points_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _vp, _i, _vp, _i]),
@@ -354,6 +355,19 @@ class Context:
         src_stride = h * src_pitch if src_stride is None else src_stride
         check(lib().cusift_scale_down(self.handle, d_dst, dst_pitch, dst_stride, d_src, w, h, src_pitch, src_stride,
                                       n_images, variance))
+
+    def scale_down_levels(self, d_src, w, h, src_pitch, d_levels, pitches, n_images=1, src_stride=None, strides=None,
+                          variance=0.5):
+        """cusift_scale_down_levels: the ScaleDown chain (level k = (w >> k) x (h >> k), k = 1..len(d_levels)) in one launch."""
+        n = len(d_levels)
+        src_stride = h * src_pitch if src_stride is None else src_stride
+        if strides is None:
+            strides = [(h >> (k + 1)) * pitches[k] for k in range(n)]
+        ptrs = (C.c_void_p * n)(*[int(p) for p in d_levels])
+        pit = (C.c_int * n)(*[int(p) for p in pitches])
+        strd = (C.c_size_t * n)(*[int(x) for x in strides])
+        check(lib().cusift_scale_down_levels(self.handle, d_src, w, h, src_pitch, src_stride, ptrs, pit, strd, n,
+                                             n_images, variance))
 
     def laplace_multi(self, d_img, w, h, pitch, init_blur, d_dog, n_images=1, img_stride=None, dog_stride=None):
         img_stride = h * pitch if img_stride is None else img_stride

@@ -976,6 +976,25 @@ static int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const i
   return check_launch("scale_down (levels)");
 }
 
+extern "C" int cusift_scale_down_levels(cusift_ctx *ctx, const float *d_src, int w, int h, int src_pitch,
+                                        size_t src_stride, float *const *d_levels, const int *pitches,
+                                        const size_t *strides, int n_levels, int n_images, float variance) {
+  if (!d_src || !d_levels || !pitches || !strides) return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): NULL argument");
+  if (n_levels < 1 || n_levels > kMaxPyramidLevels)
+    return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): 1..%d levels", kMaxPyramidLevels);
+  const float *base[kMaxPyramidLevels + 1];
+  int ws[kMaxPyramidLevels + 1], hs[kMaxPyramidLevels + 1], ps[kMaxPyramidLevels + 1];
+  size_t st[kMaxPyramidLevels + 1];
+  base[0] = d_src, ws[0] = w, hs[0] = h, ps[0] = src_pitch, st[0] = src_stride;
+  for (int k = 1; k <= n_levels; ++k) {
+    base[k] = d_levels[k - 1], ws[k] = ws[k - 1] / 2, hs[k] = hs[k - 1] / 2, ps[k] = pitches[k - 1], st[k] = strides[k - 1];
+    if (ws[k] < 1 || hs[k] < 1) return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): level %d of %dx%d is empty", k, w, h);
+    if (n_images > 1 && st[k] < (size_t)hs[k] * ps[k]) return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): stride of level %d too small", k);
+  }
+  if (n_images > 1 && src_stride < (size_t)h * src_pitch) return fail(CUSIFT_ERR_INVALID, "ScaleDown (levels): src_stride too small");
+  return pyramid_small_impl(ctx, base, ws, hs, ps, st, n_levels, n_images, variance, nullptr, 0);
+}
+
 extern "C" int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src,
                                  int w, int h, int src_pitch, size_t src_stride, int n_images, float variance) {
   if (h / 2 < 1) return fail(CUSIFT_ERR_INVALID, "ScaleDown: bad geometry w=%d h=%d", w, h);

@@ -171,6 +171,14 @@ int cusift_gaussian3x3(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_
  * dst is (w/2) x (h/2); writes are bounds-checked (the reference's are not). */
 int cusift_scale_down(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w,
                       int h, int src_pitch, size_t src_stride, int n_images, float variance);
+/* The ScaleDown CHAIN of ExtractSiftLoop (cuSIFT.cu:175-192) -- level k (w >> k, h >> k) from level k - 1 for
+ * k = 1 .. n_levels <= 4 -- in ONE launch: same pixels, bit for bit, as n_levels calls of cusift_scale_down.  What the
+ * drivers use for small calls (one 1080p frame: four dependent launches of 6-10 us become one of ~20); it re-reads the
+ * source 2.9 times, so it is not the way to scale down a large batch.  d_levels[k - 1], pitches[k - 1], strides[k - 1]
+ * (host arrays): level k's device buffer, floats per row and floats between images. */
+int cusift_scale_down_levels(cusift_ctx *ctx, const float *d_src, int w, int h, int src_pitch, size_t src_stride,
+                             float *const *d_levels, const int *pitches, const size_t *strides, int n_levels,
+                             int n_images, float variance);
 /* SiftData::LaplaceMulti, cuSIFT.cu:399-422 + LaplaceMulti_D cuSIFT_D.cu:525-553: 8 blurs + 7 DoG
  * planes, planar [7][h][pitch] per image (`dog_stride` floats between images, >= 7*h*pitch). */
 int cusift_laplace_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,

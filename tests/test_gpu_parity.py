@@ -124,6 +124,40 @@ def test_scale_down_batch_strided(ctx, oracle):
         np.testing.assert_array_equal(got[i, :, : w // 2], oracle.scale_down(imgs[i], w, h)[:, : w // 2])
 
 
+@pytest.mark.parametrize("w,h,n_levels,n", [(1920, 1080, 4, 1), (1027, 301, 4, 2), (333, 257, 4, 3), (640, 480, 3, 1),
+                                           (131, 200, 2, 2), (64, 48, 1, 1), (37, 61, 4, 1), (16, 16, 4, 1),
+                                           (1366, 768, 4, 1), (19, 500, 4, 2)])
+def test_scale_down_levels_equals_the_chain(ctx, oracle, w, h, n_levels, n):
+    """cusift_scale_down_levels (the ScaleDown chain of a small call in ONE launch: every workgroup recomputes in LDS
+    what it needs of every level) == the chain of ScaleDowns, bit for bit at every level -- odd sizes, images narrower
+    than a workgroup's needed square, levels that shrink to one pixel, batches."""
+    imgs = np.stack([pitched(rand_image(h, w, 50 + i)) for i in range(n)])
+    p = imgs.shape[2]
+    d_src = DeviceBuffer.from_numpy(ctx, imgs)
+    dims = [(w >> k, h >> k) for k in range(1, n_levels + 1)]
+    assert all(a >= 1 and b >= 1 for a, b in dims)
+    pitches = [capi.ialign_up(a, 128) for a, _ in dims]
+    bufs = [DeviceBuffer(ctx, n * b * pk * 4) for (a, b), pk in zip(dims, pitches)]
+    for b in bufs:
+        b.zero()
+    ctx.scale_down_levels(d_src.ptr, w, h, p, [b.ptr for b in bufs], pitches, n_images=n)
+    ctx.synchronize()
+    for i in range(n):
+        prev, pw, ph = imgs[i], w, h
+        for k, ((a, b), pk) in enumerate(zip(dims, pitches)):
+            want = oracle.scale_down(prev, pw, ph)  # [ph // 2, >= pw // 2]
+            got = bufs[k].to_numpy(np.float32, (n, b, pk))[i]
+            np.testing.assert_array_equal(got[:, :a], want[:b, :a], err_msg="image %d level %d" % (i, k + 1))
+            assert not got[:, a:].any()  # nothing written beyond the level's columns
+            prev = np.zeros((b, capi.ialign_up(a, 128)), dtype=np.float32)
+            prev[:, :a] = want[:b, :a]
+            pw, ph = a, b
+    with pytest.raises(capi.CusiftError):
+        ctx.scale_down_levels(d_src.ptr, w, h, p, [bufs[0].ptr] * 5, [pitches[0]] * 5, n_images=n)  # at most 4 levels
+    for b in bufs + [d_src]:
+        b.free()
+
+
 # ------------------------------------------------------------------------------------------------
 # LaplaceMulti (blur + DoG)
 # ------------------------------------------------------------------------------------------------
