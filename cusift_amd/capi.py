@@ -137,6 +137,7 @@ SIGNATURES = {
     "cusift_gaussian3x3": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
     "cusift_scale_down": (_i, [_vp, _vp, _i, _sz, _vp, _i, _i, _i, _sz, _i, _f]),
     "cusift_scale_down_levels": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _vp, _vp, _i, _i, _f]),
+    "cusift_extract_bands": (_i, [_vp, _vp, _i, _f, _f, _vp, _i, _vp, _i, _i, _vp]),
     "cusift_laplace_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _vp, _sz, _i]),
     "cusift_laplace_taps": (_i, [_f, _vp]),
     "cusift_find_points_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _vp, _i, _vp, _i]),

@@ -41,6 +41,8 @@ __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_po
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, unsigned int *, int, float, float, int,
                                     unsigned int *, SegmentTable, const unsigned int *);
 __global__ void join_counts_kernel(unsigned int *, SegmentTable, unsigned int *, int, int, unsigned int *);
+__global__ void describe_bands_kernel(OctaveTable, BandWindows, cusift_point *, int, SegmentTable, const unsigned int *,
+                                      float, float, int, unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
 template <bool kL2>
 __global__ void match_kernel(cusift_point *, int, const cusift_point *, int, int, MatchPartial *, int);
@@ -1183,6 +1185,8 @@ struct MultiOctave {
   float init_blur, subsampling;
   cusift_point *lists;
   unsigned int *counters;
+  // a band of a larger image (cusift_extract_bands): global row of local row 0, global rows, centre rows; -1: whole image
+  int row0 = 0, hg = -1, cy_begin = 0, cy_end = 0;
 };
 
 static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_octaves, float peak_thresh,
@@ -1217,9 +1221,14 @@ static int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_
     o.w = m.w;
     o.h = m.h;
     o.pitch = m.pitch;
+    o.row0 = m.hg < 0 ? 0 : m.row0;
+    o.hg = m.hg < 0 ? m.h : m.hg;
+    o.cy_begin = m.hg < 0 ? 0 : m.cy_begin;
+    o.cy_end = m.hg < 0 ? m.h : m.cy_end;
+    const int rows_total = o.cy_end - o.cy_begin;
     o.strips = idiv_up(m.w, 240);  // kDetStrip
-    o.rows_per_wave = detect_rows(ctx, m.h, o.strips, n_images, concurrent);
-    o.chunks = idiv_up(m.h, o.rows_per_wave);
+    o.rows_per_wave = detect_rows(ctx, rows_total, o.strips, n_images, concurrent);
+    o.chunks = idiv_up(rows_total, o.rows_per_wave);
     o.first_block = (int)blocks;
     blocks += (long)o.strips * o.chunks * n_images;
   }
@@ -1315,6 +1324,76 @@ extern "C" int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, 
                         tex_frac_bits, 1, rw));
   return descriptors_impl(ctx, d_img, w, h, pitch, (size_t)h * pitch, d_points, max_pts, d_first, d_counter,
                           subsampling, tex_frac_bits, 1, rw, root_sift, d_flags);
+}
+
+// Detection + description of SEVERAL octave bands of one strip-tiled image: one detection launch for all of them
+// (detect_multi_kernel), a join, one description launch (describe_bands_kernel) -- instead of a counter copy and three
+// launches per octave.  bands[0] is the finest octave, bands[k] the next coarser (subsampling doubles).  On entry
+// *d_counter counts the keypoints already in d_points (a root's collapsed coarse octaves, described): they stay where
+// they are and the bands' keypoints follow, coarsest band first -- the list order of cusift_tiled_process.
+extern "C" int cusift_extract_bands(cusift_ctx *ctx, const cusift_band *bands, int n_bands, float peak_thresh,
+                                    float edge_thresh, cusift_point *d_points, int max_pts, unsigned int *d_counter,
+                                    int tex_frac_bits, int root_sift, unsigned int *d_flags) {
+  TRY(enter(ctx));
+  if (!bands || !d_points || !d_counter) return fail(CUSIFT_ERR_INVALID, "ExtractBands: missing data");
+  if (n_bands < 1 || n_bands > kMaxMultiOctaves || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "ExtractBands: 1..%d bands", kMaxMultiOctaves);
+  for (int k = 0; k < n_bands; ++k) {
+    const cusift_band &b = bands[k];
+    if (!b.d_img || b.row0 < 0 || b.h < 1 || b.row0 + b.h > b.h_global || b.cy_begin < b.row0 || b.cy_end > b.row0 + b.h ||
+        b.cy_end <= b.cy_begin)
+      return fail(CUSIFT_ERR_INVALID, "ExtractBands: band %d has bad row geometry", k);
+    // centres need 4 blur rows + 1 extremum row of true data on either side, unless the band ends at the image border
+    if ((b.row0 > 0 && b.cy_begin - b.row0 < 5) || (b.row0 + b.h < b.h_global && b.row0 + b.h - b.cy_end < 5))
+      return fail(CUSIFT_ERR_INVALID, "ExtractBands: band %d: centres [%d,%d) need 5 halo rows inside [%d,%d)", k, b.cy_begin,
+                  b.cy_end, b.row0, b.row0 + b.h);
+    if (k > 0 && !(b.subsampling == 2.0f * bands[k - 1].subsampling))
+      return fail(CUSIFT_ERR_INVALID, "ExtractBands: band %d is not the next octave of band %d", k, k - 1);
+  }
+  // scratch in the arena: [counters of the bands | running sums | a list of heads per band]
+  const size_t list_bytes = (size_t)max_pts * kStagedRecBytes;
+  const size_t lists_off = 512;
+  TRY(ensure_arena(ctx, lists_off + list_bytes * n_bands));
+  unsigned int *seg_counts = (unsigned int *)ctx->arena;
+  unsigned int *seg_end = seg_counts + 32;
+  HIP_TRY(hipMemsetAsync(seg_counts, 0, 128, ctx->stream));
+  MultiOctave mo[kMaxMultiOctaves];
+  OctaveTable T;
+  BandWindows BW;
+  SegmentTable G;
+  memset(&T, 0, sizeof(T));
+  memset(&BW, 0, sizeof(BW));
+  memset(&G, 0, sizeof(G));
+  T.n_oct = n_bands;
+  G.n_seg = n_bands + 1;
+  G.base[0] = nullptr;  // what is in the list already: in place
+  G.count[0] = d_counter;
+  for (int k = 0; k < n_bands; ++k) {
+    const cusift_band &b = bands[k];
+    cusift_point *list = reinterpret_cast<cusift_point *>(ctx->arena + lists_off + (size_t)k * list_bytes);
+    mo[k] = MultiOctave{b.d_img, b.w, b.h, b.pitch, (size_t)b.h * b.pitch, b.init_blur, b.subsampling, list, seg_counts + k,
+                        b.row0, b.h_global, b.cy_begin, b.cy_end};
+    T.base[k] = b.d_img;
+    T.stride[k] = 0;
+    T.w[k] = b.w;
+    T.h[k] = b.h;
+    T.pitch[k] = b.pitch;
+    T.sub[k] = b.subsampling;
+    BW.row0[k] = b.row0;
+    BW.hg[k] = b.h_global;
+    const int r = n_bands - k;  // list order: coarsest band first, behind segment 0
+    G.base[r] = reinterpret_cast<const char *>(list);
+    G.count[r] = seg_counts + k;
+  }
+  TRY(detect_multi_impl(ctx, mo, n_bands, peak_thresh, edge_thresh, max_pts, 1, 1, nullptr));
+  hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counter, G, seg_end, 1, max_pts, ctx->d_queue);
+  TRY(check_launch("join_counts"));
+  float q, inv_q;
+  frac_consts(tex_frac_bits, q, inv_q);
+  StageTimer t(ctx, CUSIFT_STAGE_DESCRIBE_ALL);
+  hipLaunchKernelGGL(describe_bands_kernel, dim3(keypoint_grid_x(max_pts, 1)), dim3(64), 0, ctx->stream, T, BW, d_points,
+                     max_pts, G, (const unsigned int *)seg_end, q, inv_q, root_sift, d_flags);
+  return check_launch("describe_bands");
 }
 
 extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_pts) {

@@ -763,6 +763,20 @@ __device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, c
   if (lane == 0) pt->orientation = ori;
   finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
 }
+// (the same, handing the orientation back: describe_bands_kernel's footprint check wants it.  A function of its own --
+// returning it from describe_keypoint renamed registers all through describe_all_kernel, and that kernel's code is left
+// alone unless a same-box A/B says otherwise)
+template <typename TEX>
+__device__ __forceinline__ float describe_keypoint_ori(KpShared &S, const TEX &tex, const DescLaneConsts &C,
+                                                       cusift_point *pt, float px, float py, float kscale, float sub,
+                                                       int lane, int root_sift) {
+  const float ori = kp_orientation(S, tex, px, py, kscale, lane);
+  float b0, b1;
+  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
+  if (lane == 0) pt->orientation = ori;
+  finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
+  return ori;
+}
 
 // 4 waves per SIMD (<= 128 VGPRs) is what this kernel needs: its LDS read-modify-write chains and dependent taps are
 // latency that only other waves hide (forced to 3 / 2 waves the launch takes 1.25x / 1.8x as long)
@@ -926,6 +940,71 @@ __global__ void __launch_bounds__(256) join_counts_kernel(unsigned int *__restri
       seg_end[i * G.n_seg + r] = kept;
     }
     counters[i] = raw;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orientation + descriptor of the keypoints of ONE strip-tiled image whose octaves are bands (cusift_extract_bands): the
+// band form of describe_all_kernel.  Segment 0 of G is the caller's list as it stands -- keypoints of coarser octaves,
+// already described, left alone -- and segments 1.. are the bands' staging lists, coarsest first; a keypoint's head is
+// read there, its record written at its place in list order.  A rank has a few thousand keypoints: a plain
+// grid-stride walk, none of describe_all_kernel's queue and prefetch.  `flags`: the footprint check of
+// descriptors_kernel (a keypoint whose samples leave the band where the band does not end at the image border).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) describe_bands_kernel(
+    OctaveTable T, BandWindows BW, cusift_point *__restrict__ points, int max_pts, SegmentTable G,
+    const unsigned int *__restrict__ seg_end, float q, float inv_q, int root_sift, unsigned int *__restrict__ flags) {
+  __shared__ KpShared S;
+  const int lane = threadIdx.x;
+  const unsigned int total = seg_end[G.n_seg - 1];
+  const DescLaneConsts C = desc_lane_consts(lane);
+  const int exp0 = (__float_as_int(T.sub[0]) >> 23) & 0xff;
+  for (unsigned int k = seg_end[0] + blockIdx.x; k < total; k += gridDim.x) {  // wave-uniform
+    int r = 1;
+    unsigned int first = seg_end[0];
+    while (k >= seg_end[r]) first = seg_end[r++];
+    const float *src = reinterpret_cast<const float *>(G.base[r] + (size_t)(k - first) * kStagedRecBytes);
+    cusift_point *pt = points + k;
+    const float px = uniform(src[0]), py = uniform(src[1]), kscale = uniform(src[2]);
+    const float sharp = uniform(src[offsetof(cusift_point, sharpness) / 4]);
+    const float edge = uniform(src[offsetof(cusift_point, edgeness) / 4]);
+    const float sub = uniform(src[offsetof(cusift_point, subsampling) / 4]);
+    if (lane == 0) {
+      pt->sharpness = sharp;
+      pt->edgeness = edge;
+      pt->subsampling = sub;
+    }
+    int o = ((__float_as_int(sub) >> 23) & 0xff) - exp0;  // subsampling = sub0 * 2^octave
+    o = clampi(o, 0, T.n_oct - 1);
+    const float *img = T.base[o];
+    const int w = T.w[o], h = T.h[o], pitch = T.pitch[o];
+    const RowWindow rw{BW.row0[o], BW.hg[o]};
+    const float reach = fmaxf(7.5f * (12.0f / 16.0f * kscale) * 1.41422f + 1.0f + 0.01f, 6.0f);
+    PatchGeom pg;
+    int pw, ph;
+    const bool use_patch = patch_for_reach(px, py, reach, pg, pw, ph);
+    if (use_patch) stage_patch(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
+    wave_sync();
+    float ori;
+    if (use_patch) {
+      if (q > 0.0f)
+        ori = describe_keypoint_ori(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
+                                sub, lane, root_sift);
+      else
+        ori = describe_keypoint_ori(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
+                                sub, lane, root_sift);
+    } else {
+      ori = describe_keypoint_ori(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift);
+    }
+    if (flags) {  // as in descriptors_kernel
+      float sn, cs;
+      sm_sincosf(2.0f * 3.1415f / 360.0f * ori, &sn, &cs);
+      const float rr = fmaxf(7.5f * (12.0f / 16.0f * kscale) * (fabsf(sn) + fabsf(cs)), 6.0f) + 2.5f;
+      const bool cut = (rw.row0 > 0 && !(py - rr >= (float)rw.row0)) ||
+                       (rw.row0 + h < rw.hg && !(py + rr <= (float)(rw.row0 + h - 1)));
+      if (cut && lane == 0) atomicAdd(flags, 1u);
+    }
+    wave_sync();
   }
 }
 

@@ -1024,11 +1024,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) de
   const int by = (local / O.strips) % O.chunks;
   const int bz = local / (O.strips * O.chunks);
   const int w = O.w, h = O.h, pitch = O.pitch;
-  const RowWindow rw{0, h};
-  const int gy0 = by * O.rows_per_wave;
-  const int ya = max(gy0, 1);
-  const int yb = min(gy0 + O.rows_per_wave, h - 1);  // local centres [ya, yb)
-  if (ya >= yb) return;                              // wave-uniform
+  const RowWindow rw{O.row0, O.hg};
+  // as in detect_fused_kernel: centres are global rows [cy_begin, cy_end) minus the global border rows, in local indices
+  const int gy0 = O.cy_begin + by * O.rows_per_wave;
+  const int ya = max(max(gy0, 1), O.cy_begin) - rw.row0;
+  const int yb = min(min(gy0 + O.rows_per_wave, rw.hg - 1), O.cy_end) - rw.row0;  // local centres [ya, yb)
+  if (ya >= yb) return;                                                            // wave-uniform
   const float *img = O.img + (long)bz * O.img_stride;
   char *const list = O.lists + (size_t)bz * max_pts * kRecBytes;
   unsigned int *counter = O.counters + bz;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -131,6 +132,7 @@ struct cusift_tiled {
   float *bands[kMaxOctaves] = {nullptr};
   float *full = nullptr;  // the whole collapse octave, on the root
   unsigned int *d_small = nullptr;  // [0] first (fstPts), [1] flags
+  bool per_octave = false;          // $CUSIFT_TILED_PER_OCTAVE (read at creation): the tiled octaves one at a time
   bool loaded = false;
   ~cusift_tiled() {
     (void)hipSetDevice(device);
@@ -225,6 +227,7 @@ extern "C" int cusift_tiled_create(cusift_tiled **out, cusift_ctx *ctx, cusift_c
     sub.num_octaves = pl.n_oct - pl.collapse;
     TRY(cusift_ctx_reserve(ctx, 1, pl.w[pl.collapse], pl.h[pl.collapse], &sub));
   }
+  t->per_octave = getenv("CUSIFT_TILED_PER_OCTAVE") != nullptr;
   HIP_TRY(hipMalloc((void **)&t->d_small, 256));
   HIP_TRY(hipMemsetAsync(t->d_small, 0, 256, t->stream));
   *out = t.release();
@@ -411,6 +414,30 @@ extern "C" int cusift_tiled_process(cusift_tiled *t, cusift_point *d_points, uns
                              d_points, d_counter));
   }
   unsigned int *d_first = t->d_small, *d_flags = t->d_small + 1;
+  // The tiled octaves of this rank: ONE detection launch and ONE description launch for all of them
+  // (cusift_extract_bands) when they are consecutive octaves -- they are, unless lowest_scale drops octaves from the
+  // middle, which it cannot -- and few enough; otherwise octave by octave, coarsest first.
+  {
+    cusift_band bands[16];
+    int n_bands = 0, first_o = -1, last_o = -1;
+    for (int o = 0; o < std::min(pl.collapse, pl.n_oct); ++o) {
+      if (!(p.lowest_scale < t->sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
+      int a, b, lo, hi;
+      pl.own(t->rank, o, a, b);
+      pl.band(t->rank, o, lo, hi);
+      if (b <= a) continue;
+      if (first_o < 0) first_o = o;
+      last_o = o;
+      if (n_bands < 16)
+        bands[n_bands] = cusift_band{t->bands[o], pl.w[o], hi - lo, pl.pitch[o], lo, pl.h[o], a, b, (float)t->blur[o], t->sub[o]};
+      ++n_bands;
+    }
+    const bool consecutive = n_bands > 0 && last_o - first_o + 1 == n_bands;
+    if (consecutive && n_bands <= 8 && !t->per_octave)
+      return cusift_extract_bands(t->ctx, bands, n_bands, p.peak_thresh, p.edge_thresh, d_points, p.max_pts, d_counter,
+                                  p.tex_frac_bits, p.root_sift, d_flags);
+    if (n_bands == 0) return CUSIFT_OK;
+  }
   for (int o = std::min(pl.collapse, pl.n_oct) - 1; o >= 0; --o) {
     if (!(p.lowest_scale < t->sub[o] * 2.0f)) continue;  // cuSIFT.cu:194
     int a, b, lo, hi;

@@ -69,6 +69,10 @@ struct SegmentTable {
   const char *base[kMaxOctaves];      // staging list of segment r ([image][max_pts] heads), or NULL
   const unsigned int *count[kMaxOctaves];  // per-image counters the detection of segment r incremented (unclamped)
 };
+// Row windows of the octaves of describe_bands_kernel (one strip-tiled image: every octave is a band of its own).
+struct BandWindows {
+  int row0[kMaxOctaves], hg[kMaxOctaves];
+};
 constexpr int kQueueShards = 64;      // work cursors of describe_all_kernel (a power of two)
 struct OctaveTable {
   const float *base[kMaxOctaves];  // image 0 of octave o
@@ -109,6 +113,9 @@ struct DetectOctave {
   int strips, chunks;      // workgroups of this octave: strips x chunks x images, strip fastest
   int first_block;         // its first workgroup in the launch
   int ident;               // levels 0 and 1 of T are the identity (initBlur >= their sigma): the pass-through body
+  // the image may be a horizontal band of a larger one (RowWindow): local row 0 = global row row0 of hg rows; extremum
+  // centres are global rows [cy_begin, cy_end).  Whole images: 0, h, 0, h.
+  int row0, hg, cy_begin, cy_end;
   LaplaceTapsPk T;
   FindParams P;
 };

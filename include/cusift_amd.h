@@ -245,6 +245,21 @@ int cusift_describe_band(cusift_ctx *ctx, const float *d_img, int w, int h, int 
                          cusift_point *d_points, int max_pts, const unsigned int *d_first,
                          const unsigned int *d_counter, float subsampling, int tex_frac_bits, int root_sift,
                          unsigned int *d_flags);
+/* One octave of a strip-tiled image as a rank holds it: `h` local rows (global rows row0 .. row0 + h - 1 of h_global),
+ * extremum centres restricted to global rows [cy_begin, cy_end). */
+typedef struct cusift_band {
+  const float *d_img;
+  int w, h, pitch;
+  int row0, h_global, cy_begin, cy_end;
+  float init_blur, subsampling;
+} cusift_band;
+/* cusift_detect_band + cusift_describe_band for SEVERAL consecutive octaves of one image (bands[0] the finest) with one
+ * detection launch and one description launch.  *d_counter (device) counts what d_points holds already -- the coarser
+ * octaves of a root rank, described: left alone -- and the bands' keypoints are appended behind it, coarsest band
+ * first; the same records as the per-octave calls leave.  At most 8 bands.  d_flags as in cusift_describe_band. */
+int cusift_extract_bands(cusift_ctx *ctx, const cusift_band *bands, int n_bands, float peak_thresh, float edge_thresh,
+                         cusift_point *d_points, int max_pts, unsigned int *d_counter, int tex_frac_bits,
+                         int root_sift, unsigned int *d_flags);
 
 /* ---- matcher (first consumer of SiftData) ----------------------------- */
 /* MatchSiftData(data1, data2, distance, ...), extras/matching.cu:232-362: for every point of d_sift1 the best
