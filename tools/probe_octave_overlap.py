@@ -33,7 +33,7 @@ def main():
     base = [np.pad(synth.tile(1000 + i, w, h, 1.0), ((0, 0), (0, p - w))) for i in range(4)]
     prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=3.0, max_pts=32768)
     ctxs = {"one stream": make_ctx(0), "side stream": make_ctx(None)}
-    for B in (1, 4, 16, 64):
+    for B in [int(x) for x in os.environ.get("PROBE_BATCHES", "1,4,16,64").split(",")]:
         imgs = np.stack([base[i % 4] for i in range(B)])
         state = {}
         for name, c in ctxs.items():
