@@ -4,9 +4,8 @@
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace1 -- python3 tools/trace_single_frame.py run
     python3 tools/trace_single_frame.py report gpurun_out/trace1
 
-`run` extracts the same frame 30 times back to back with a wait after each; `report` prints, for the last frame, every
-dispatch with its duration and the gap to the previous one -- how much of a frame's latency is kernels and how much is
-what lies between dependent dispatches."""
+`run` extracts the same frame 30 times back to back with a wait after each; `report` prints the last dispatches of the run
+with their durations and the gaps between them -- how many dispatches a frame is and what each costs."""
 import csv
 import glob
 import os
@@ -33,33 +32,22 @@ def run():
             ctx.synchronize()
 
 
-def report(d):
+def report(d, n_last=24):
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         with open(f, newline="") as fh:
             rows += list(csv.DictReader(fh))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # frames are separated by host waits: split where the gap exceeds 30 us
-    frames, cur, last_end = [], [], None
+    rows = rows[-n_last:]
+    print("%-46s %9s %9s" % ("dispatch", "dur us", "gap us"))
+    prev = None
     for r in rows:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        if last_end is not None and s - last_end > 30000 and cur:
-            frames.append(cur)
-            cur = []
-        cur.append((r["Kernel_Name"].split("(")[0].replace("cusift::", "")[:44], s, e))
-        last_end = e
-    if cur:
-        frames.append(cur)
-    fr = frames[-2] if len(frames) > 1 else frames[-1]
-    t0 = fr[0][1]
-    print("%-46s %9s %9s %9s" % ("dispatch", "start us", "dur us", "gap us"))
-    prev = None
-    busy = 0.0
-    for name, s, e in fr:
-        print("%-46s %9.1f %9.1f %9.1f" % (name, (s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev is None else (s - prev) / 1e3))
-        busy += (e - s) / 1e3
+        name = r["Kernel_Name"].split("(")[0].replace("cusift::", "")[:44]
+        print("%-46s %9.1f %9.1f" % (name, (e - s) / 1e3, 0.0 if prev is None else (s - prev) / 1e3))
         prev = e
-    print("frame: %d dispatches, %.1f us first start to last end, %.1f us inside kernels" % (len(fr), (fr[-1][2] - t0) / 1e3, busy))
+    print("(the last %d dispatches of the run; a frame is the stretch between two long gaps -- the host's wait.  Under the "
+          "profiler dispatches are serialised: durations include the dispatch itself)" % len(rows))
 
 
 if __name__ == "__main__":
