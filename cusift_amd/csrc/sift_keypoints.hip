@@ -171,17 +171,26 @@ __device__ __forceinline__ float uniform(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-// Where descriptor sample (row y, column tx) of the 16x16 grid lives in grad() / angraw().  The gather reads, in one
-// instruction, rows {y0 + 2j} x columns {t0 + 4i} (8 x 4 distinct samples, shared by the lanes of vertically and
-// horizontally adjacent cells).  With the plain index 16 y + tx every second of those rows falls on the same banks
-// (32 j mod 64): a 4-way conflict on each of the 36 gather reads -- PMC: half of this kernel's LDS cycles were bank
-// conflicts.  The skew 5 (y >> 1) moves row pair j to bank 37 j mod 64 = 0, 37, 10, 47, 20, 57, 30, 3: any two rows
-// either differ mod 4 or lie >= 16 banks apart, so the 32 samples of a gather read sit on 32 different banks.
-constexpr int kDescSlots = 16 * 16 + 5 * 7 + 5;  // 296
-constexpr int kAngOffset = 320;                  // >= kDescSlots, a multiple of 64
-__device__ __forceinline__ int desc_slot(int y, int tx) { return 16 * y + tx + 5 * (y >> 1); }
+// Where descriptor sample (row y, column tx) of the 16x16 grid lives in grad() / angfrac().  Two access patterns must
+// both be conflict-free: phase 1 writes rows {q + 4 step} x 16 columns (q = lane / 16) in one instruction, the vertical
+// pass of the gather reads rows {4 vi - 2 + r} x 16 columns (vi = lane / 16) in one instruction -- four rows 4 apart.  With
+// the plain index 16 y + tx rows 4 apart are 64 floats apart: the same banks.  The skew 16 (y >> 2) moves row y to bank
+// 16 (y + (y >> 2)) mod 64: four consecutive rows of one group of four AND four rows 4 apart each cover the 64 banks once.
+constexpr int kDescSlots = 16 * 16 + 16 * 3;  // 304
+constexpr int kAngOffset = 320;               // >= kDescSlots, a multiple of 64
+__device__ __forceinline__ int desc_slot(int y, int tx) { return 16 * y + tx + 16 * (y >> 2); }
 
-// LDS of one keypoint wave (8.75 KB => 16 waves per CU together with the 1 KB prefix table of describe_all).
+// The lane-private angle histograms of the gather's vertical pass: kHistSlots rows of 64 floats, [slot][position], lane
+// (x = lane % 16, vi = lane / 16) at position 16 vi + (x + 2) % 16 -- a bijection of the lanes onto the 64 banks whatever
+// slots they pick; the rotation by 2 makes the 8-column window of a cell, columns 4 hi - 2 .. 4 hi + 5, start on a
+// 16-byte boundary (two ds_read_b128 in the horizontal pass).
+//   slots 0..7  angle bins;   slot 8  bin 0 again (the upper neighbour of bin 7: one address register + an immediate for
+//   both adds);   slot 9  the reference's angle-index 8 (atan2f == +pi: its index 8 + ... is bin 0 of the NEXT linear
+//   cell, cuSIFT_D.cu:233-255) and slot 10 its upper neighbour (bin 0 of the sample's own cell);   slot 11 padding
+constexpr int kHistSlots = 12;
+__device__ __forceinline__ int hist_pos(int x, int vi) { return 16 * vi + ((x + 2) & 15); }
+
+// LDS of one keypoint wave (9.0 KB => 16 waves per CU together with the 1 KB prefix table of describe_all).
 // The descriptor's histogram buffers are only needed after its sampling phase, when the patch is dead, so they
 // live inside the patch storage.
 struct alignas(16) KpShared {
@@ -190,22 +199,21 @@ struct alignas(16) KpShared {
   float pad_[1];        // keeps scratch 16-byte aligned (float4 stores)
   // shared by the two stages (they never overlap in time):
   //   orientation: wmat() = [2 halves][64 samples] (bin, weight) list of the samples being summed
-  //   descriptor : grad() / angraw() = weighted gradient magnitude and 4/pi*atan2 + 4 of the 16x16 samples, stored
-  //                at desc_slot(y, tx) -- a skewed layout, see there; the two arrays lie kAngOffset = 5 x 64 floats
-  //                apart, so one ds_read2st64_b32 / ds_write2st64_b32 moves a sample's pair
+  //   descriptor : grad() / angfrac() = weighted gradient magnitude (its four lowest mantissa bits carry the sample's
+  //                angle code, see kp_descriptor) and the angle fraction of the 16x16 samples, stored at desc_slot(y, tx);
+  //                the two arrays lie kAngOffset = 5 x 64 floats apart, so one ds_read2st64_b32 / ds_write2st64_b32
+  //                moves a sample's pair
   float scratch[kAngOffset + kDescSlots];
   __device__ __forceinline__ float *wmat() { return scratch; }
   __device__ __forceinline__ float *grad() { return scratch; }
-  __device__ __forceinline__ float *angraw() { return scratch + kAngOffset; }
+  __device__ __forceinline__ float *angfrac() { return scratch + kAngOffset; }
   float patch[kDescPatch * kDescPatch];
-  __device__ __forceinline__ float *hist8() { return patch; }              // [9 slots][64 lanes]: slot-major
-  __device__ __forceinline__ float *fin() { return patch + 64 * 9; }       // 128
-  // per sample, next to grad() / angraw(): byte offsets of its two histogram slots (angpk(), see kp_descriptor)
-  __device__ __forceinline__ unsigned int *angpk() { return reinterpret_cast<unsigned int *>(patch + 64 * 9 + 128); }
+  __device__ __forceinline__ float *cellhist() { return patch; }                     // [kHistSlots][64 positions]
+  __device__ __forceinline__ float *fin() { return patch + 64 * kHistSlots; }        // 128
 };
 static_assert(kAngOffset + kDescSlots >= 256 && kAngOffset % 64 == 0 && kAngOffset >= kDescSlots,
               "the orientation stage's sample list lives in the same storage");
-static_assert(64 * 9 + 128 + kDescSlots <= kDescPatch * kDescPatch, "histogram buffers must fit in the patch storage");
+static_assert(64 * kHistSlots + 128 <= kDescPatch * kDescPatch, "histogram buffers must fit in the patch storage");
 
 // LDS of the orientation-only stage kernel
 struct alignas(16) OriShared {
@@ -410,20 +418,31 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
 }
 
 // ------------------------------------------------------------------------------------------------
-// 128-D descriptor.  Reference: ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.  No LDS float atomics
-// (ds_add_f32 retires one lane at a time on gfx950: ~150 cycles per wave instruction, measured):
-//   phase 1  the 16x16 rotated sample grid, 4 samples per lane: gradient magnitude (with the Gaussian
-//            window), angle bin and angle fraction go to LDS.
-//   phase 2  gather: lane l = (cell l/4, row pair l%4) walks its 2x8 share of the 8x8 samples that reach
-//            its histogram cell, forms the same products as the reference (horizontal, vertical, then
-//            angle weight) and accumulates them into a private 8-bin LDS histogram (plain read-add-write,
-//            lane-private, slot-major [slot][lane] -> conflict free).  The reference's column-14 spill into the
-//            next row's first cell (guard `tx<=14`, cuSIFT_D.cu:243) is gathered the same way; its
-//            angle-index-8 spill (atan2f == +pi) is collected in the row's 9th slot and folded into the
-//            next linear cell in phase 3.
-//   phase 3  the 4 partial histograms of each cell are summed in a fixed order; L2-normalise, clamp at
-//            0.2, L2-normalise with the reference's reduction tree.
-// The order of the sums is fixed, so results are reproducible run to run.  Lane l returns elements l, l+64.
+// 128-D descriptor.  Reference: ExtractSiftDescriptors_D, cuSIFT_D.cu:184-297.  The reference adds every sample's eight
+// trilinear shares into the 128 bins with LDS float atomics (:230-255) -- in whatever order the hardware retires them:
+// NO summation order is prescribed for a bin, and the bar is 1e-4 L2 against the oracle (north_star).  What stays
+// operation for operation is everything that DECIDES something: the sample coordinates and the texture model's index /
+// 8-bit fraction (a coordinate on a 1/256 step must round the same way) and the angle index.  What is free -- and used
+// since round 4 -- is the order and association of the sums and the last bit of sqrt / division / rsqrt, whose effect is
+// continuous in the result (measured: largest L2 distance to the oracle ~1e-6 instead of 3e-7).
+//   phase 1  the 16x16 rotated sample grid, 4 samples per lane: the Gaussian-weighted gradient magnitude, the angle
+//            fraction and the angle index (carried in the magnitude's four lowest mantissa bits: 2^-20 relative) go to
+//            LDS.
+//   phase 2  SEPARABLE gather (round 4; until then lane (cell, row pair) walked its 18 samples: 18 dependent LDS
+//            read-modify-writes and ~220 vector instructions).  With A[y][x][b] = the sample's share for angle bin b,
+//            bin[vi][hi][b] = sum_y wy(vi, y) sum_x wx(hi, x) A[y][x][b], and the weights are the same eight numbers in
+//            both directions (1/8, 3/8, 5/8, 7/8, 7/8, 5/8, 3/8, 1/8 over the eight rows / columns around a cell).
+//            vertical   lane (x, vi) walks the 8 rows 4 vi - 2 .. 4 vi + 5 of column x and adds wy * grad * (1 - frac,
+//                       frac) into a lane-private angle histogram in LDS -- the only data-dependent addressing, 8
+//                       read-modify-writes, conflict-free, one ds_read2st64 + one ds_write2st64 each.
+//            horizontal lane (vi, hi, b mod 4) forms bins b and b + 4 of cell (vi, hi): 8 columns x fixed weights read
+//                       with two ds_read_b128 per bin, no data-dependent address, no read-modify-write.
+//            The reference's column-14 quirk (guard `tx <= 14`, :243: the right-hand share of column 14 lands in the
+//            NEXT row's first cell) is one more term, 1/8 of column 14 of the cell row above.  Its angle-index-8 quirk
+//            (atan2f == +pi: index 8 is bin 0 of the next linear cell) is collected in slot 9 and folded in by a branch
+//            that a ballot skips for the keypoints that have no such sample (nearly all).
+//   phase 3  L2-normalise, clamp at 0.2, L2-normalise (v_rsq_f32; the reference calls rsqrtf, :272,:282).
+// Every sum has a fixed order, so results are reproducible run to run.  Lane l returns elements desc_elem(l), + 4.
 // ------------------------------------------------------------------------------------------------
 struct DescLaneConsts {
   int tx1;
@@ -444,44 +463,63 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
   return c;
 }
 
-// The part of the reference's accumulation that depends on the sample alone (cuSIFT_D.cu:231-236: the angle index,
-// its fraction, the neighbouring bin) is done once per sample by split_angle(), not once per visiting cell lane:
-//   angraw()[slot] <- angf, the fraction;   angpk()[slot] <- byte offsets of the two slots in a lane's slot-major
-//   histogram, (angi * 256) | (angp * 256) << 16.
-// angraw = 4/pi*atan2 + 4 lies in [0, 8.0001] for every finite gradient and v_cvt_i32_f32 turns a NaN into 0; the
-// unsigned min is for memory safety only (slots 0..8 exist).  angi == 8 (atan2f == +pi): the reference's index 8 + ...
-// is bin 0 of the NEXT linear cell; it is collected in the lane's slot 8 and folded into that cell in phase 3 -- no
-// branch and no atomic in the loop.
-__device__ __forceinline__ void split_angle(float angraw, float &angf, unsigned int &pk) {
-  const int angc = (int)angraw;
-  angf = angraw - angc;
-  const unsigned int angi = min((unsigned int)angc, 8u);
-  const unsigned int angp = (angi < 7u ? angi + 1u : 0u);
-  pk = (angi << 8) | (angp << 24);
+// element of the descriptor that lane l holds first (the second is 4 further): cell l / 4 = (vi, hi), bin l % 4
+__device__ __forceinline__ int desc_elem(int lane) { return 8 * (lane >> 2) + (lane & 3); }
+
+// sqrt and atan2 of the DESCRIPTOR samples: one hardware instruction (1 ulp) instead of the IEEE-exact expansions
+// (~11 instructions each) the orientation stage needs for its bit-identical histogram bins.  atan2: the quotient by
+// v_rcp_f32; min(., 1) also turns the 0 * inf of a zero gradient (whose weight is zero) into a finite angle.  The +pi
+// of (dy = +0, dx < 0) is exact as in sm_atan2f -- the angle-index-8 path depends on it.
+__device__ __forceinline__ float desc_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float desc_atan2f(float y, float x) {
+  const float ax = sm_abs(x), ay = sm_abs(y);
+  const bool swap = ay > ax;
+  const float mx = swap ? ay : ax;
+  const float mn = swap ? ax : ay;
+  const float a = fminf(mn * __builtin_amdgcn_rcpf(mx), 1.0f);
+  const float s = a * a;
+  float q = 0.0029205884784460068f;
+  q = sm_fma(q, s, -0.016367513686418533f);
+  q = sm_fma(q, s, 0.0432111918926239f);
+  q = sm_fma(q, s, -0.07552158087491989f);
+  q = sm_fma(q, s, 0.10665978491306305f);
+  q = sm_fma(q, s, -0.14211048185825348f);
+  q = sm_fma(q, s, 0.19993771612644196f);
+  q = sm_fma(q, s, -0.33333152532577515f);
+  const float t = q * s;
+  float r = sm_fma(t, a, a);
+  if (swap) r = (1.5707963705062866f - r) + -4.371138828673793e-08f;
+  if (sm_bits(x) & 0x80000000u) r = (3.1415927410125732f - r) + -8.742277657347586e-08f;
+  return sm_float(sm_bits(r) | (sm_bits(y) & 0x80000000u));
 }
 
-__device__ __forceinline__ void gather_sample(float *__restrict__ myhist, float grad, float angf, unsigned int pk,
-                                              float wx, float wy) {
-  const float grad1 = wx * grad;
-  const float grad2 = wy * grad1;
-  const float v1 = (1.0f - angf) * grad2;
-  const float v2 = angf * grad2;
-  // the lane's private histogram is slot-major ([slot][lane]): whatever slots the lanes pick, lane l is on bank l.
-  // angp != angi always, so the two read-modify-writes are independent: both reads first (one LDS round trip per
-  // sample instead of two)
-  float *p1 = reinterpret_cast<float *>(reinterpret_cast<char *>(myhist) + (pk & 0xffffu));
-  float *p2 = reinterpret_cast<float *>(reinterpret_cast<char *>(myhist) + (pk >> 16));
-  const float h1 = *p1, h2 = *p2;
-  *p1 = h1 + v1;
-  *p2 = h2 + v2;
+// sum over the 8-column window of cell column `hi` in histogram row `row` (= cellhist() + 64 slot + 16 vi), plus the
+// column-14 term from the cell row above (`above`: that row's position 0 = column 14; w14 = 1/8 for hi == 0, vi >= 1)
+__device__ __forceinline__ float window_sum(const float *row, int hi, const f4 wa, const f4 wb, const float *above,
+                                            float w14) {
+  const f4 a = *reinterpret_cast<const f4 *>(row + 4 * hi);               // columns 4 hi - 2 .. 4 hi + 1
+  const f4 b = *reinterpret_cast<const f4 *>(row + ((4 * hi + 4) & 15));  // columns 4 hi + 2 .. 4 hi + 5
+  float s = wa.x * a.x;
+  s = fmaf(wa.y, a.y, s);
+  s = fmaf(wa.z, a.z, s);
+  s = fmaf(wa.w, a.w, s);
+  s = fmaf(wb.x, b.x, s);
+  s = fmaf(wb.y, b.y, s);
+  s = fmaf(wb.z, b.z, s);
+  s = fmaf(wb.w, b.w, s);
+  return fmaf(w14, above[0], s);
+}
+// the window's weights for cell column hi: columns outside 0..15 (hi == 0: the first two, hi == 3: the last two) weigh
+// nothing -- the positions they would read hold other columns' (finite) sums
+__device__ __forceinline__ void window_weights(int hi, f4 &wa, f4 &wb) {
+  wa = f4{hi >= 1 ? 0.125f : 0.0f, hi >= 1 ? 0.375f : 0.0f, 0.625f, 0.875f};
+  wb = f4{0.875f, 0.625f, hi <= 2 ? 0.375f : 0.0f, hi <= 2 ? 0.125f : 0.0f};
 }
 
 template <typename TEX>
 __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const DescLaneConsts &C, float px,
                                               float py, float kp_scale, float orientation, int lane, float &out0,
                                               float &out1) {
-  const int cell = lane >> 2, vi = cell >> 2, hi = cell & 3, kq = lane & 3;
-  float *myhist = S.hist8() + lane;
   const float theta = 2.0f * 3.1415f / 360.0f * orientation;
   float sina, cosa;
   sm_sincosf(theta, &sina, &cosa);  // sift_math.h
@@ -490,6 +528,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   const float scosa = scale * cosa;
 
   // ---- phase 1: samples ----
+  unsigned int codes = 0;
 #pragma unroll
   for (int step = 0; step < 4; ++step) {
     const int idx = lane + 64 * step;
@@ -499,98 +538,93 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
     const float dx = tex(xpos + cosa, ypos + sina) - tex(xpos - cosa, ypos - sina);
     const float dy = tex(xpos - sina, ypos + cosa) - tex(xpos + sina, ypos - cosa);
-    const float grad = gy * gx * sqrtf(dx * dx + dy * dy);
+    const float grad = gy * gx * desc_sqrtf(dx * dx + dy * dy);
+    // cuSIFT_D.cu:231-236: angf = 4/pi atan2 + 4 in [0, 8.0001] for every finite gradient (v_cvt_i32_f32 turns a NaN
+    // into 0); angi = (int)angf, fraction angf - angi.  The unsigned min is for memory safety only.  code = angi, or 9
+    // for angi == 8: slot `code` receives the (1 - fraction) share, slot code + 1 the fraction's.
+    const float angraw = 4.0f / 3.1415f * desc_atan2f(dy, dx) + 4.0f;
+    const int angc = (int)angraw;
+    const float angf = angraw - (float)angc;
+    unsigned int code = min((unsigned int)angc, 8u);
+    code += code >> 3;
+    codes |= code;
     const int slot = desc_slot(y, tx);
-    S.grad()[slot] = grad;
-    S.angraw()[slot] = 4.0f / 3.1415f * sm_atan2f(dy, dx) + 4.0f;
+    S.grad()[slot] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned int, grad) & ~15u) | code);
+    S.angfrac()[slot] = angf;
   }
+  const bool spill = __ballot((codes & 8u) != 0u) != 0ull;  // wave-uniform: some sample has angle index 8
   wave_sync();
-  // the patch is dead from here on: its storage becomes the histogram buffers and the samples' slot offsets
-#pragma unroll
-  for (int b = 0; b < 9; ++b) myhist[b * 64] = 0.0f;
+  // the patch is dead from here on: its storage becomes the histogram rows
 
+  // ---- phase 2a: vertical pass ----
+  {
+    const int x = lane & 15, vi = lane >> 4;
+    float *mine = S.cellhist() + hist_pos(x, vi);
 #pragma unroll
-  for (int step = 0; step < 4; ++step) {
-    const int slot = desc_slot((lane >> 4) + 4 * step, C.tx1);
-    float angf;
-    unsigned int pk;
-    split_angle(S.angraw()[slot], angf, pk);
-    S.angraw()[slot] = angf;
-    S.angpk()[slot] = pk;
-  }
-  wave_sync();
-
-  // ---- phase 2: gather into the lane-private histogram ----
-  // Four samples of a row are read first, then accumulated: the compiler cannot move a sample read above the
-  // previous sample's histogram write (a run-time address), and left alone every visit paid two dependent LDS round
-  // trips -- read the sample, then read-modify-write its slots.
+    for (int b = 0; b < kHistSlots; ++b) mine[b * 64] = 0.0f;
+    // the row weights, compile-time constants per visit: wy(vi, 4 vi - 2 + r), r = 0..7
+    constexpr float kW[8] = {0.125f, 0.375f, 0.625f, 0.875f, 0.875f, 0.625f, 0.375f, 0.125f};
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int y = 4 * vi - 2 + 2 * kq + r;
-    if (y >= 0 && y <= 15) {
-      const int veri = (y + 2) / 4 - 1;
-      const float verf = (y - 1.5f) / 4.0f - veri;
-      const float wy = (veri == vi) ? (1.0f - verf) : verf;  // upper add (iverf) or lower add (verf)
+    for (int half = 0; half < 2; ++half) {  // four samples are read first, then accumulated (the compiler cannot move a
+      float sg[4], sf[4];                   // sample read above the previous visit's histogram write)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {  // four samples at a time: register budget
-        float sg[4], sf[4];
-        unsigned int sp[4];
+      for (int c = 0; c < 4; ++c) {
+        const int y = clampi(4 * vi - 2 + 4 * half + c, 0, 15);  // rows outside the grid: a valid slot, the add is skipped
+        const int slot = desc_slot(y, x);
+        sg[c] = S.grad()[slot];
+        sf[c] = S.angfrac()[slot];
+      }
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int tx = 4 * hi - 2 + 4 * half + c;
-          const int idx = desc_slot(y, clampi(tx, 0, 15));  // the row's edge cells read a valid slot and skip the add
-          sg[c] = S.grad()[idx];
-          sf[c] = S.angraw()[idx];
-          sp[c] = S.angpk()[idx];
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int tx = 4 * hi - 2 + 4 * half + c;
-          if (tx >= 0 && tx <= 15) {
-            const int hori = (tx + 2) / 4 - 1;
-            const float horf = (tx - 1.5f) / 4.0f - hori;
-            const float wx = (hori == hi) ? (1.0f - horf) : horf;  // left add (ihorf) or right add (horf)
-            gather_sample(myhist, sg[c], sf[c], sp[c], wx, wy);
-          }
+      for (int c = 0; c < 4; ++c) {
+        const int r = 4 * half + c;
+        const bool live = (r >= 2 || vi >= 1) && (r <= 5 || vi <= 2);  // row 4 vi - 2 + r in 0..15
+        if (live) {
+          const unsigned int code = __builtin_bit_cast(unsigned int, sg[c]) & 15u;
+          float *p = mine + code * 64;
+          const float m = kW[r] * sg[c];
+          const float v2 = sf[c] * m;
+          const float v1 = m - v2;
+          const float h1 = p[0], h2 = p[64];
+          p[0] = h1 + v1;
+          p[64] = h2 + v2;
         }
       }
     }
-  }
-  if (hi == 0 && vi >= 1) {
-    // the reference's right-hand adds of column 14 (hori+1 == 4) land in cell (row+1, 0)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int y = 4 * (vi - 1) - 2 + 2 * kq + r;
-      if (y >= 0 && y <= 15) {
-        const int veri = (y + 2) / 4 - 1;
-        const float verf = (y - 1.5f) / 4.0f - veri;
-        const float wy = (veri == vi - 1) ? (1.0f - verf) : verf;
-        const float horf = (14 - 1.5f) / 4.0f - 3;
-        const int idx = desc_slot(y, 14);
-        gather_sample(myhist, S.grad()[idx], S.angraw()[idx], S.angpk()[idx], horf, wy);
-      }
-    }
+    // bin 0 also received shares as "bin 8" (the upper neighbour of bin 7) and, for angle index 8, in slot 10
+    float fold = mine[8 * 64];
+    if (spill) fold += mine[10 * 64];
+    mine[0] += fold;
   }
   wave_sync();
 
-  // ---- phase 3: cell sums (fixed order) and normalisation ----
-  float bsum[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int b = lane + 64 * r;
-    const float *hc = S.hist8() + (b & 7) * 64 + (b >> 3) * 4;  // bin b & 7 of the four lanes of cell b >> 3
-    bsum[r] = ((hc[0] + hc[1]) + hc[2]) + hc[3];
-    if ((b & 7) == 0 && b >= 8) {  // bin 0 of cell b/8 also receives the angle-index-8 spill of the cell before it
-      const float *hp = S.hist8() + 8 * 64 + ((b >> 3) - 1) * 4;
-      bsum[r] = (((hp[0] + hp[1]) + hp[2]) + hp[3]) + bsum[r];
+  // ---- phase 2b: horizontal pass ----
+  float b0, b1;
+  {
+    const int vi = lane >> 4, hi = (lane >> 2) & 3, bq = lane & 3;
+    f4 wa, wb;
+    window_weights(hi, wa, wb);
+    const float w14 = (hi == 0 && vi >= 1) ? 0.125f : 0.0f;
+    const float *row = S.cellhist() + bq * 64 + 16 * vi;
+    const float *above = S.cellhist() + bq * 64 + 16 * (vi >= 1 ? vi - 1 : 0);  // position 0 = column 14
+    b0 = window_sum(row, hi, wa, wb, above, w14);
+    b1 = window_sum(row + 4 * 64, hi, wa, wb, above + 4 * 64, w14);
+    if (spill && bq == 0 && (vi | hi) != 0) {
+      // bin 0 of this cell also receives the slot-9 sums of the linear cell before it (which for hi == 0 is the last
+      // cell of the row above, with ITS column-14 term from the row above that)
+      const int pc = 4 * vi + hi - 1, pv = pc >> 2, ph = pc & 3;
+      f4 pa, pb;
+      window_weights(ph, pa, pb);
+      const float p14 = (ph == 0 && pv >= 1) ? 0.125f : 0.0f;
+      b0 += window_sum(S.cellhist() + 9 * 64 + 16 * pv, ph, pa, pb, S.cellhist() + 9 * 64 + 16 * (pv >= 1 ? pv - 1 : 0), p14);
     }
   }
-  float b0 = bsum[0], b1 = bsum[1];
+
+  // ---- phase 3: normalisation ----
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const float tsum = tree_sum64(b0 * b0 + b1 * b1);
-    const float r = 1.0f / sqrtf(tsum);
+    const float r = __builtin_amdgcn_rsqf(tsum);
     b0 = b0 * r;
     b1 = b1 * r;
     if (pass == 0) {
@@ -607,13 +641,13 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
 // L1 sum in index order, then sqrtf(max(0.0, x) / sum) (the max promotes to double there).  Every lane forms the
 // same sum from broadcast reads.  Used by the stand-alone kernel and, with cusift_params.root_sift, as the
 // descriptor epilogue (the fusion the reference leaves as a TODO, cuSIFT.cu:376-379) -- same bits either way.
-// Lane l returns elements l and l+64.
+// The lane returns elements e0 and e1.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rootsift_lanes(const float *v, int lane, float &o0, float &o1) {
+__device__ __forceinline__ void rootsift_lanes(const float *v, int e0, int e1, float &o0, float &o1) {
   float sum = 0.0f;
 #pragma unroll 16
   for (int i = 0; i < 128; ++i) sum += v[i];
-  const float x0 = v[lane], x1 = v[lane + 64];
+  const float x0 = v[e0], x1 = v[e1];
   const double m0 = x0 > 0.0 ? (double)x0 : 0.0;
   const double m1 = x1 > 0.0 ? (double)x1 : 0.0;
   o0 = sqrtf((float)(m0 / sum));
@@ -672,16 +706,17 @@ __global__ void __launch_bounds__(64) orientations_kernel(const float *__restric
 // RootSIFT epilogue (wave-uniform flag) + the record stores of ExtractSiftDescriptors_D, cuSIFT_D.cu:288-296
 __device__ __forceinline__ void finish_descriptor(KpShared &S, cusift_point *pt, float b0, float b1, float px,
                                                   float py, float kscale, float sub, int lane, int root_sift) {
+  const int e0 = desc_elem(lane);  // kp_descriptor's element of this lane (and e0 + 4)
   if (root_sift) {
     float *v = S.fin();
-    v[lane] = b0;
-    v[lane + 64] = b1;
+    v[e0] = b0;
+    v[e0 + 4] = b1;
     wave_sync();
-    rootsift_lanes(v, lane, b0, b1);
+    rootsift_lanes(v, e0, e0 + 4, b0, b1);
   }
   {
-    pt->data[lane] = b0;
-    pt->data[lane + 64] = b1;
+    pt->data[e0] = b0;
+    pt->data[e0 + 4] = b1;
   }
   if (lane == 0) {
     pt->coords2D[0] = px * sub;
@@ -1021,7 +1056,7 @@ __global__ void __launch_bounds__(64) rootsift_kernel(cusift_point *__restrict__
     v[lane + 64] = pt->data[lane + 64];
     __syncthreads();
     float o0, o1;
-    rootsift_lanes(v, lane, o0, o1);
+    rootsift_lanes(v, lane, lane + 64, o0, o1);
     pt->data[lane] = o0;
     pt->data[lane + 64] = o1;
     __syncthreads();
