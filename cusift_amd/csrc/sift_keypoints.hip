@@ -128,6 +128,43 @@ __device__ __forceinline__ float tex2d_patch(const float *lds, int x0, int y0, f
   return t;
 }
 
+// The DESCRIPTOR's tap (round 4): tex2d_patch operation for operation -- same index, same 8-bit fractions, same four
+// products in the same chain -- with x and y travelling as one register pair through packed fp32 operations (one v_pk_*
+// at 4.2 cycles for two fast-class operations at 2.65 each, and for two SGPR-operand ones at 4.2 each).
+// (Tried and dropped: the interpolation as three lerps -- two packed operations on the row pairs + one fma, five
+// instructions fewer per tap.  A flat neighbourhood then interpolates to EXACTLY its value, while the reference's
+// four-product form leaves +-1 ulp of the pixel value: for low-contrast keypoints -- gradients of ~0.05 grey levels on
+// pixels of ~100 -- that ulp is 2e-4 of the gradient and the descriptors left the 1e-4 bar.)
+template <int kStride, bool kQuant>
+__device__ __forceinline__ float tex2d_patch_desc(const float *lds, int x0, int y0, f2 p, float q, float inv_q) {
+  const f2 pb = p - f2{0.5f, 0.5f};
+  const f2 fl = f2{floorf(pb.x), floorf(pb.y)};
+  f2 ab = pb - fl;
+  if (kQuant) {
+    const f2 t = __builtin_elementwise_fma(ab, f2{q, q}, f2{0.5f, 0.5f});
+    ab = f2{floorf(t.x), floorf(t.y)} * f2{inv_q, inv_q};
+  }
+  const int e = (int)fmaf(fl.y, (float)kStride, fl.x) - (y0 * kStride + x0);
+  const float *p0 = lds + e;
+  const float *p1 = p0 + kStride;
+  const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
+  float w00, w10, w01, w11;
+  if (kQuant) {  // bilinear_weights<true>, the two middle subtractions as one packed operation
+    w11 = ab.x * ab.y;
+    const f2 wm = ab - f2{w11, w11};
+    w10 = wm.x;
+    w01 = wm.y;
+    w00 = (1.0f - ab.x) - w01;
+  } else {
+    bilinear_weights<false>(ab.x, ab.y, w00, w10, w01, w11);
+  }
+  float t = w00 * s00;
+  t = fmaf(w10, s10, t);
+  t = fmaf(w01, s01, t);
+  t = fmaf(w11, s11, t);
+  return t;
+}
+
 // The keypoint kernels run ONE wave per workgroup, so "all threads of the block have written LDS" only needs
 // this wave's LDS operations to have completed (they execute in order): wait for lgkmcnt, not for outstanding
 // global loads/stores as __syncthreads() would (its vmcnt(0) drain cost ~1-2 us per keypoint).
@@ -151,6 +188,8 @@ struct PatchSampler {
   __device__ __forceinline__ float operator()(float x, float y) const {
     return tex2d_patch<kStride, kQuant>(patch, x0, y0, x, y, q, inv_q);
   }
+  // a descriptor tap at p = (x, y): the same operations with x and y as a register pair (tex2d_patch_desc)
+  __device__ __forceinline__ float desc(f2 p) const { return tex2d_patch_desc<kStride, kQuant>(patch, x0, y0, p, q, inv_q); }
 };
 struct GlobalSampler {
   static constexpr bool kIsPatch = false;
@@ -163,6 +202,7 @@ struct GlobalSampler {
   __device__ __forceinline__ float operator()(float x, float y) const {
     return tex2d(img, w, h, pitch, rw, x, y, q, inv_q);
   }
+  __device__ __forceinline__ float desc(f2 p) const { return tex2d(img, w, h, pitch, rw, p.x, p.y, q, inv_q); }
 };
 
 // A value every lane loaded from the same address, declared wave-uniform: it then lives in an SGPR and whatever
@@ -194,6 +234,9 @@ __device__ __forceinline__ int hist_pos(int x, int vi) { return 16 * vi + ((x + 
 // The descriptor's histogram buffers are only needed after its sampling phase, when the patch is dead, so they
 // live inside the patch storage.
 struct alignas(16) KpShared {
+  // first, i.e. at LDS address 0 (the compiler places this 16-byte aligned object before the prefix table): a tap's four
+  // pixels are then offset0:0/1 and offset0:40/41 of ONE address register, with no base to add (-2 instructions per tap)
+  float patch[kDescPatch * kDescPatch];
   float hist[64];
   float gauss[11];      // orientation window; gauss[0] also carries the finished orientation to all lanes
   float pad_[1];        // keeps scratch 16-byte aligned (float4 stores)
@@ -207,7 +250,6 @@ struct alignas(16) KpShared {
   __device__ __forceinline__ float *wmat() { return scratch; }
   __device__ __forceinline__ float *grad() { return scratch; }
   __device__ __forceinline__ float *angfrac() { return scratch + kAngOffset; }
-  float patch[kDescPatch * kDescPatch];
   __device__ __forceinline__ float *cellhist() { return patch; }                     // [kHistSlots][64 positions]
   __device__ __forceinline__ float *fin() { return patch + 64 * kHistSlots; }        // 128
 };
@@ -217,12 +259,12 @@ static_assert(64 * kHistSlots + 128 <= kDescPatch * kDescPatch, "histogram buffe
 
 // LDS of the orientation-only stage kernel
 struct alignas(16) OriShared {
+  float patch[16 * 16];
   float hist[64];
   float gauss[11];
   float pad_[1];
   float scratch[256];  // the (bin, weight) list of the 128 sample slots (kp_orientation)
   __device__ __forceinline__ float *wmat() { return scratch; }
-  float patch[16 * 16];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -534,10 +576,12 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     const int idx = lane + 64 * step;
     const int y = idx >> 4, tx = C.tx1;
     const float gy = C.gy1[step], gx = C.gx1;
-    const float xpos = px + (tx - 7.5f) * scosa - (y - 7.5f) * ssina;
-    const float ypos = py + (tx - 7.5f) * ssina + (y - 7.5f) * scosa;
-    const float dx = tex(xpos + cosa, ypos + sina) - tex(xpos - cosa, ypos - sina);
-    const float dy = tex(xpos - sina, ypos + cosa) - tex(xpos + sina, ypos - cosa);
+    // cuSIFT_D.cu:216-229, x and y as a pair: xpos = (px + (tx - 7.5) scosa) - (y - 7.5) ssina, ypos = (py + (tx - 7.5)
+    // ssina) + (y - 7.5) scosa; the taps at pos +- (cosa, sina) and pos +- (-sina, cosa).  a - b == a + (-b) bit for bit.
+    const f2 pos = (f2{px, py} + (tx - 7.5f) * f2{scosa, ssina}) + (y - 7.5f) * f2{-ssina, scosa};
+    const f2 u = f2{cosa, sina}, v = f2{-sina, cosa};
+    const float dx = tex.desc(pos + u) - tex.desc(pos - u);
+    const float dy = tex.desc(pos + v) - tex.desc(pos - v);
     const float grad = gy * gx * desc_sqrtf(dx * dx + dy * dy);
     // cuSIFT_D.cu:231-236: angf = 4/pi atan2 + 4 in [0, 8.0001] for every finite gradient (v_cvt_i32_f32 turns a NaN
     // into 0); angi = (int)angf, fraction angf - angi.  The unsigned min is for memory safety only.  code = angi, or 9
