@@ -26,6 +26,10 @@ leg says otherwise), `--legs` selects them:
              algorithmic bytes / HIP-event time vs 8 TB/s, the north-star gate)
   host       SiftData made host-visible: packed records copied to pinned memory on a copy stream, overlapped with
              the next step (`keypoints_per_s_host_visible`; SURVEY.md section 8d's end-to-end definition)
+  host_in    HOST to HOST: the batch starts as 8-bit pixels in pinned host memory (and, second variant, as float32 --
+             what the reference's entry point takes, cuSIFT.cu:61-62), is uploaded every step, converted on the device,
+             extracted, and its SiftData copied back to pinned memory; upload, extraction and read-back of consecutive
+             steps overlap (`host_to_host`: ms/step, Mpix/s, keypoints/s, both PCIe rates, and the bound they set)
   repeat     the timed region four more times: min / median / max ms per step (the spread of `ms_per_step`)
   content    the same pipeline on other image content (`blobs`, un-pre-blurred `tile`), single stream AND pipelined
              like the timed region: keypoints/step, the fraction of octave-0 wave-rows the threshold pre-test skips,
@@ -62,7 +66,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 FP32_VALU_PEAK_TF = 157.3  # ibid. "Peak FP32 (vector)": 256 CUs x 4 SIMDs x 32 lanes x 2 flop (FMA) x 2.4 GHz
 PRETEST_SKIP_HEADLINE = 0.73  # octave-0 wave-rows of the headline images the threshold pre-test skips (content leg)
-ALL_LEGS = ("single", "repeat", "two_stage", "host", "content", "initblur0", "ragged", "match", "cpu")
+ALL_LEGS = ("single", "repeat", "two_stage", "host", "host_in", "content", "initblur0", "ragged", "match", "cpu")
 
 
 def octave_dims(w, h, n_oct):
@@ -112,34 +116,41 @@ def cpu_baseline(w, h, params_kw, preblur, budget_s):
     threads = int(os.environ.get("CUSIFT_CPU_THREADS", "0")) or max(1, min(cores, usable + usable // 2, 48))
     oracle = Oracle()
     imgs = [synth.tile(5000 + i, w, h, preblur) for i in range(threads)]
-    oracle.extract(imgs[0], **params_kw)  # warm-up (page-in, first-touch)
+    # wall-clock median of >= 5 runs after one warm-up.  A run = every thread extracts one image, all at the
+    # same time (the C code releases the GIL); runs repeat until the budget is spent.
     counts = [0] * threads
-    done = [0] * threads
-    t_end = time.perf_counter() + budget_s
 
-    def work(i):
-        while True:
-            counts[i] += len(oracle.extract(imgs[i], **params_kw))
-            done[i] += 1
-            if time.perf_counter() >= t_end:
-                break
+    def one_pass():
+        def work(i):
+            counts[i] = len(oracle.extract(imgs[i], **params_kw))
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    dt = time.perf_counter() - t0
-    n_img = sum(done)
+    one_pass()  # warm-up (page-in, first-touch)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 or (time.perf_counter() - t_start < budget_s and len(times) < 200):
+        times.append(one_pass())
+    dt = sum(times)
+    n_img = threads * len(times)
+    rates = sorted(threads * w * h / t / 1e6 for t in times)
+    med = rates[len(rates) // 2]
     out = {
-        "value": round(n_img * w * h / dt / 1e6, 3),
+        "value": round(med, 3),
         "unit": "Mpix/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d x %dx%d images (same generator/params), %d threads, %.1f s wall; CPU restatement of the "
-                  "cuSIFT algorithm (oracle/sift_oracle.c), not OpenCV" % (n_img, w, h, threads, dt),
-        "keypoints_per_s": round(sum(counts) / dt, 1),
+        "sample": "median of %d runs after 1 warm-up, each %d x %dx%d images at once on %d threads (same generator/"
+                  "params), %.1f s wall in all; CPU restatement of the cuSIFT algorithm (oracle/sift_oracle.c), not OpenCV"
+                  % (len(times), threads, w, h, threads, dt),
+        "runs": len(times),
+        "spread_mpix_per_s": {"min": round(rates[0], 3), "median": round(med, 3), "max": round(rates[-1], 3)},
+        "keypoints_per_s": round(sum(counts) * med * 1e6 / (threads * w * h), 1),
         "host_cores": cores,
         "usable_cpus": usable,
     }
@@ -238,6 +249,50 @@ def dry_launch(args):
                           "dry_launch": True, "images_total": int(n_img.item()), "data": "none (launch rehearsal)"}),
               flush=True)
     return 0
+
+
+XGMI_LINK_GBPS_PER_DIRECTION = 76.8  # one xGMI link of an MI355X: 153.6 GB/s bidirectional = 76.8 GB/s each way
+
+
+def gather_model(kp_per_rank_step, rec_bytes, step_ms, lag_steps):
+    """A PREDICTION of the all-gatherv step at 2 / 4 / 8 ranks, committed before any multi-GPU hardware has run it (no
+    8-GPU node was reachable from the build box): the first measured scaling curve is to be read against these numbers.
+    Exchange of one step: every rank sends its whole shard to each of its W - 1 peers, one dedicated point-to-point xGMI
+    link per peer, all links at once (one ncclGroup of ncclSend / ncclRecv) -- so the time is one shard over one link,
+    whatever W >= 2, and the same number of bytes arrives over the link's other direction."""
+    shard = kp_per_rank_step * rec_bytes
+    out = {"records_per_rank_per_step": int(kp_per_rank_step), "record_bytes": int(rec_bytes),
+           "bytes_per_rank_per_step": int(shard), "bytes_per_peer_link_per_direction_per_step": int(shard),
+           "assumed_link_GBps_per_direction": XGMI_LINK_GBPS_PER_DIRECTION,
+           "assumed_rccl_p2p_efficiency": [1.0, 0.7],
+           "extraction_ms_per_step": round(step_ms, 4), "finish_lags_begin_by_steps": lag_steps, "ranks": {}}
+    for W in (2, 4, 8):
+        row = {"bytes_received_per_rank_per_step": int(shard * (W - 1))}
+        for eff in (1.0, 0.7):
+            ex_ms = shard / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9 * eff) * 1e3
+            row["eff_%.1f" % eff] = {
+                "exchange_ms": round(ex_ms, 4),
+                # own stream, finish lagging begin: latency is hidden, bandwidth is not -- a step cannot be shorter than
+                # its exchange
+                "ms_per_step_overlapped": round(max(step_ms, ex_ms), 4),
+                "weak_scaling_efficiency_overlapped": round(step_ms / max(step_ms, ex_ms), 4),
+                "ms_per_step_serial": round(step_ms + ex_ms, 4),
+                "weak_scaling_efficiency_serial": round(step_ms / (step_ms + ex_ms), 4)}
+        out["ranks"][str(W)] = row
+    ex1 = shard / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3
+    out["verdict"] = ("link-bound: one shard over one link takes %.2f ms at link peak against %.2f ms of extraction -- the "
+                      "exchange, not the GPU, sets the step from 2 ranks up" % (ex1, step_ms)) if ex1 > step_ms else (
+                      "extraction-bound at link peak (%.2f ms exchange against %.2f ms); link-bound below %.0f %% RCCL "
+                      "efficiency" % (ex1, step_ms, 100.0 * ex1 / step_ms))
+    out["not_modelled"] = ("the counts all-gather (a few tens of microseconds, hidden by the lag), the CUs RCCL's send / "
+                           "receive kernels take from the extraction, HBM traffic of the arriving shards (%.2f GB per step "
+                           "at 8 ranks: ~0.1 ms of HBM time)" % (shard * 7 / 1e9))
+    out["options"] = {"compact 160-byte wire record (--gather-compact; 8-bit descriptor, lossy)":
+                      round(kp_per_rank_step * 160 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3, 4),
+                      "only the 135 floats extraction writes (540 B, exact; not built)":
+                      round(kp_per_rank_step * 540 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3, 4),
+                      "unit": "exchange ms per step at link peak"}
+    return out
 
 
 def load_profile_json(name):
@@ -366,12 +421,16 @@ def main():
             return np.stack(list(pool.map(fn, seeds)))
 
     seeds = [1000 + rank * B + i for i in range(B)]
-    d_imgs = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, args.init_blur), seeds))
+    np_imgs = make_images(lambda s: synth.tile(s, w, h, args.init_blur), seeds)
+    d_imgs = ex.images_from_numpy(np_imgs)
 
     # N > 1: the all-gatherv of step i runs on a side stream (its own context + communicator).  begin(i) -- counts
     # exchange + the local shard packed into its region -- is enqueued right after step i; finish(i) -- the one host READ
-    # of the counts, then the grouped ncclSend/ncclRecv -- after step i + LAG has been enqueued, by which time the counts
-    # have long arrived: no host wait anywhere in the loop (config.gather_host_waits counts the exceptions).
+    # of the counts, then the grouped ncclSend/ncclRecv -- after step i + LAG has been enqueued.  The host runs AHEAD of
+    # the device (enqueueing a step takes ~0.1 ms, executing it ~1.2), so finish(i) usually finds the counts flag not yet
+    # set and spins on it: that wait is the host's throttle, not device idle time -- the device still has LAG steps
+    # queued.  config.gather_host_waits counts those finishes (round 3 measured 60 of 60) and config.gather_host_wait_ms
+    # is the time spent in them.
     main_stream = torch.cuda.current_stream()
     side_stream = torch.cuda.Stream() if use_dist else None
     LAG = E
@@ -454,23 +513,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    timers = bool(legs)
+    # The timed region runs the PRODUCT: stage timers off (two hipEventRecord per launch, and a driver that pins the
+    # per-octave launch sequence while they are on), whatever legs follow -- `--legs none` takes the same path, and
+    # config.timed_region_forks / _timers say so.  The kernel-span table of the overlapped streams comes from a REPEAT of
+    # the region with the timers on (`timed_region_kernel_spans_ms_per_step`, with that repeat's own ms per step).
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
-    if timers:
-        for x in exs:
-            x.ctx.timing_enable(True)
-            x.ctx.timing_reset()
+    forks_before = sum(x.ctx.forks() for x in exs)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    forks_timed = sum(x.ctx.forks() for x in exs) - forks_before
     gathered = state["gathered"]
+    gather_waits = (comm.host_waits(), comm.host_wait_ms()) if comm is not None else None
     stage_overlapped = None
-    if timers:
+    spans_ms_per_step = None
+    if legs and not use_dist:
+        for x in exs:
+            x.ctx.timing_enable(True)
+            x.ctx.timing_reset()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        spans_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
         for x in exs:  # kernel spans of all streams (with E > 1 they overlap in time: their sum exceeds the wall time)
             t = x.ctx.timing_read()
             stage_overlapped = t if stage_overlapped is None else {
@@ -522,17 +592,23 @@ def main():
                 "parallelism": "image-sharded x%d" % world,
                 "streams_per_gpu": E,
                 "pipeline": "two-stage (DoG in HBM)" if args.two_stage else "fused detection (DoG on chip)",
+                "timed_region_timers": False,
+                "timed_region_forks": int(forks_timed),
             },
             "keypoints_per_s_in_hbm": round(total_kp / (elapsed / K), 1),
             "keypoints_per_step": total_kp,
         }
+        rec_b = 160 if (args.gather_compact and gatherer is not None) else 588
+        out["gather_model"] = gather_model(local_kp, rec_b, ms_per_step, LAG if use_dist else E)
+        out["gather_model"]["step_of_this_run_includes_an_exchange"] = bool(use_dist)
         if use_dist:
             out["config"]["gather_impl"] = gather_impl
             out["config"]["rccl_library"] = capi.Comm.library()
             out["config"]["gather_region_records"] = region_cap
             out["config"]["gather_record_bytes"] = 160 if (args.gather_compact and gatherer is not None) else 588
-            if comm is not None:
-                out["config"]["gather_host_waits"] = comm.host_waits()
+            if gather_waits is not None:
+                out["config"]["gather_host_waits"] = gather_waits[0]
+                out["config"]["gather_host_wait_ms"] = round(gather_waits[1], 3)
 
     # ================================================================================================================
     # Extra legs (rank 0's GPU only; not part of `value`).  With N > 1 the other ranks wait at the final barrier.
@@ -596,7 +672,9 @@ def main():
                                          "note": "the timed region (`ms_per_step`) and 4 repeats of it, K steps each"}
         ex.params.concurrent_batches = 1  # the single-stream legs below run one batch at a time on one stream
         if stage_overlapped is not None and E > 1:
-            out["timed_region_kernel_spans_ms_per_step"] = stage_table(stage_overlapped, K)
+            out["timed_region_kernel_spans_ms_per_step"] = dict(
+                stage_table(stage_overlapped, K), ms_per_step_of_this_repeat=round(spans_ms_per_step, 4),
+                note="a repeat of the timed region WITH the stage timers on (the timed region itself runs without them)")
 
         # ---- single-stream leg: per-stage table, VALU rooflines of the two kernels that own the step ----
         stage = None
@@ -644,6 +722,9 @@ def main():
                      "valu_wave_insts_per_step": int(insts_per_step), "launches_per_step": n // K,
                      "ms_per_step": round(ms / K, 4),
                      "hbm_traffic_bytes_per_launch": traffic.get(kernel, {}).get("hbm_bytes_per_launch"),
+                     "counters_source": "profiles/valu.json, profiles/traffic.json: the builder's rocprofv3 --pmc passes "
+                                        "of this command, committed with the kernels they count -- NOT collected in this "
+                                        "run (only the times are)",
                      "note": note}
                 # The spec peak prices every wave-instruction at 2 cycles per SIMD; only the plain fp32 / integer add,
                 # multiply, fma, logic and move forms with no SGPR operand come near it (2.65), every other form --
@@ -717,6 +798,8 @@ def main():
                     "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get("laplace_multi_fast_kernel", {}).get("hbm_bytes_per_launch"),
+                    "traffic_source": "profiles/traffic.json (the builder's FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                      "gfx950 corrections applied; committed, not collected in this run)",
                     "algorithmic_bytes_per_launch": int(blur_b * K / lap_n),
                     "avg_launch_ms": round(lap_ms / lap_n, 5),
                     "launches": lap_n,
@@ -774,6 +857,39 @@ def main():
             out["host_visible_compact_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank,
                                                                dev, total_local_kp=local_kp, compact=True)
             out["keypoints_per_s_host_visible_compact"] = out["host_visible_compact_leg"]["keypoints_per_s"]
+            ex.params.concurrent_batches = 1
+
+        # ---- host-to-host legs: what a caller of the reference's entry point (host image in, host SiftData out) gets ----
+        if "host_in" in legs:
+            ex.params.concurrent_batches = E
+            h2h = {}
+            u8_np = np.clip(np.rint(np_imgs), 0, 255).astype(np.uint8)
+            variants = (("u8", torch.from_numpy(u8_np).pin_memory()), ("f32", torch.from_numpy(np_imgs).pin_memory()))
+            for tag, h_src in variants:
+                leg = host_visible_leg(torch, capi, pipe, d_imgs, K if tag == "u8" else max(8, K // 4), B, args.max_pts,
+                                       local_rank, dev, total_local_kp=local_kp, h_src=h_src)
+                # the three things that can bound a step: the upload, the extraction, the read-back -- each as measured
+                # in this run (PCIe rates with the leg's own buffers while the OTHER direction is busy too, as in the leg;
+                # extraction = the timed region)
+                parts = {"h2d_ms": leg["h2d_bytes_per_step"] / (leg["h2d_duplex_GBps"] * 1e9) * 1e3,
+                         "extract_ms": ms_per_step,
+                         "d2h_ms": leg["d2h_bytes_per_step"] / (leg["d2h_duplex_GBps"] * 1e9) * 1e3}
+                bound = max(parts.values())
+                leg["bound"] = {k: round(v, 4) for k, v in parts.items()}
+                leg["bound"]["slowest"] = max(parts, key=parts.get)
+                leg["bound"]["frac_of_bound"] = round(bound / leg["ms_per_step"], 4)
+                h2h[tag] = leg
+                del h_src
+            if "u8" in h2h:
+                same = bool(np.array_equal(u8_np.astype(np.float32), np_imgs))
+                h2h["u8"]["images"] = ("the timed images as 8-bit pixels (what a decoded frame holds): " +
+                                       ("the generator rounds to integers, so they ARE the timed images" if same else
+                                        "rounded, so keypoints per step differ slightly from the timed region's"))
+            out["host_to_host"] = h2h
+            out["end_to_end_host_u8_mpix_per_s"] = h2h["u8"]["Mpix_per_s"]
+            out["end_to_end_host_u8_keypoints_per_s"] = h2h["u8"]["keypoints_per_s"]
+            out["end_to_end_host_f32_mpix_per_s"] = h2h["f32"]["Mpix_per_s"]
+            del u8_np, variants
             ex.params.concurrent_batches = 1
 
         # ---- content legs ----
@@ -852,6 +968,16 @@ def main():
         if "match" in legs:
             out["match_leg"] = match_leg(capi, ex.ctx, 16384)
 
+        # the headline is ONE content; the number to carry is the range over the survey's generators
+        rates = {"tile_preblurred (timed region)": out["value"]}
+        for key, label in (("value_blobs_mpix_per_s", "blobs"), ("value_tile_raw_mpix_per_s", "tile_raw (every image "
+                           "saturates maxPts)"), ("value_initblur0_mpix_per_s", "tile_preblurred, initBlur=0")):
+            if key in out:
+                rates[label] = out[key]
+        if len(rates) > 1:
+            out["value_range_mpix_per_s"] = [min(rates.values()), max(rates.values())]
+            out["value_by_content_mpix_per_s"] = rates
+
         if "cpu" in legs:
             out["cpu_baseline"] = cpu_baseline(w, h, dict(prm_kw), args.init_blur, args.cpu_seconds)
             if world > 1:
@@ -905,7 +1031,8 @@ def match_leg(capi, ctx, n):
             "self_match_ok": ok}
 
 
-def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact=False):
+def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact=False,
+                     h_src=None):
     """Steps as in the timed region, but each step's SiftData is packed on the device (pack stream) and copied to pinned
     host memory (copy stream) while the next steps are extracted; the region ends when the last record is on the host.
     The copy size is a host argument, so a step's counts travel first (4 bytes x images) and its records one step
@@ -919,7 +1046,8 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     for x in pipe.extractors:
         x.params.concurrent_batches = len(pipe.streams)
     try:
-        return _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact)
+        return _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact,
+                                 h_src)
     finally:
         pipe.streams, pipe.extractors = all_streams, all_extractors
         for x in pipe.extractors:
@@ -927,14 +1055,45 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
         torch.cuda.synchronize()
 
 
-def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact):
+def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev, total_local_kp, compact, h_src=None):
+    """h_src: None -- the input is the HBM-resident batch d_imgs (the `host` leg); a pinned host tensor [B, h, w], uint8
+    or float32 -- every step UPLOADS its batch first (the `host_in` legs: what a caller of the reference's entry point,
+    which takes a host image, cuSIFT.cu:61-62, gets).  8-bit pixels are converted on the device (cusift_u8_to_f32, the
+    front-end of SURVEY section 8f rank 2) on the extraction stream of their step."""
     pack_stream, copy_stream = torch.cuda.Stream(), torch.cuda.Stream()
+    ingest = h_src is not None
+    n_in = 3  # input buffers in flight: upload of step i+1 and i+2 beside the extraction of step i
+    if ingest:
+        h2d_stream = torch.cuda.Stream()
+        h_img, w_img, pitch = pipe.h, pipe.w, pipe.pitch
+        as_u8 = h_src.dtype == torch.uint8
+        d_in = [torch.zeros((B, h_img, pitch), dtype=torch.float32, device=dev) for _ in range(n_in)]
+        d_u8 = [torch.empty((B, h_img, w_img), dtype=torch.uint8, device=dev) for _ in range(n_in)] if as_u8 else None
+        ev_in_free = [None] * n_in  # the extraction that read input buffer b has finished
+        in_bytes = h_src.numel() * h_src.element_size()
+
+    def upload(i):
+        """enqueue the upload of step i's batch; returns (device images, event after which they are complete)"""
+        b = i % n_in
+        with torch.cuda.stream(h2d_stream):
+            if ev_in_free[b] is not None:
+                h2d_stream.wait_event(ev_in_free[b])
+            if as_u8:
+                d_u8[b].copy_(h_src, non_blocking=True)
+            elif pitch == w_img:
+                d_in[b].copy_(h_src, non_blocking=True)  # dense rows == pitched rows: one copy
+            else:
+                d_in[b][:, :, :w_img].copy_(h_src, non_blocking=True)
+            up = torch.cuda.Event()
+            up.record(h2d_stream)
+        return b, up
+
     cctx = capi.Context(device_index, stream=pack_stream.cuda_stream)
     cap = int(max(1.5 * total_local_kp, 4096))  # records per step the staging buffers hold
     # staging slots: a step's records leave depth - 2 steps after it was enqueued.  The exact records are bound by the
     # copy itself (99 MB per step over PCIe); the compact ones are not, and need the host to stay further ahead than the
     # 4-stream extraction pipeline is deep
-    depth = 8 if compact else 4
+    depth = 8 if compact else (6 if h_src is not None else 4)
     rec_bytes = capi.COMPACT_POINT_BYTES if compact else capi.SIFT_POINT_BYTES
     packed = [torch.empty((cap, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]
     offs = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
@@ -961,8 +1120,20 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
 
     def one(i):
         j = i % depth
-        key = (pipe.submitted % E, (pipe.submitted // E) % pipe.n_slots)
-        pts, cnt, ev = pipe.submit(d_imgs, ready=ev_slot.pop(key, None))
+        e = pipe.submitted % E
+        key = (e, (pipe.submitted // E) % pipe.n_slots)
+        imgs = d_imgs
+        if ingest:
+            b, up = upload(i)
+            imgs = d_in[b]
+            with torch.cuda.stream(pipe.streams[e]):
+                pipe.streams[e].wait_event(up)
+                if as_u8:
+                    pipe.extractors[e].ctx.u8_to_f32(d_in[b].data_ptr(), pitch, d_u8[b].data_ptr(), w_img, h_img, w_img,
+                                                     n_images=B)
+        pts, cnt, ev = pipe.submit(imgs, ready=ev_slot.pop(key, None))
+        if ingest:
+            ev_in_free[b] = ev
         with torch.cuda.stream(pack_stream):
             pack_stream.wait_event(ev)
             if ev_copied[j] is not None:
@@ -994,13 +1165,67 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
     # spot check: the last step's host records are real (first record of image 0 has a finite, in-range location)
     rec = h_rec[(K - 1) % depth][:1].numpy().view(capi.COMPACT_POINT_DTYPE if compact else capi.SIFT_POINT_DTYPE)
     assert np.isfinite(rec["coords2D"]).all() and rec["subsampling"][0] >= 1.0
+    res = {"ms_per_step": round(dt / K * 1e3, 4), "keypoints_per_s": round(got["records"] / dt, 1),
+           "d2h_GBps": round(got["bytes"] / dt / 1e9, 2), "d2h_bytes_per_step": int(got["bytes"] / K),
+           "record_bytes": rec_bytes, "extraction_streams": E,
+           "note": "device-resident input -> SiftData records in pinned host memory (packed on the device, copied on "
+                   "a copy stream, overlapped with the following steps); bounded by the D2H copy when d2h_bytes_per_step "
+                   "/ PCIe rate exceeds the extraction time"}
+    if ingest:
+        # each direction alone, same buffers and sizes: what PCIe gives this process on this box
+        reps = max(4, K // 4)
+        per_step = max(1, int(got["records"] / K))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for r in range(reps):
+            with torch.cuda.stream(h2d_stream):
+                (d_u8 if as_u8 else d_in)[r % n_in].copy_(h_src, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_alone = in_bytes * reps / (time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        for r in range(reps):
+            with torch.cuda.stream(copy_stream):
+                h_rec[r % depth][:per_step].copy_(packed[r % depth][:per_step], non_blocking=True)
+        torch.cuda.synchronize()
+        d2h_alone = per_step * rec_bytes * reps / (time.perf_counter() - t1)
+        # ... and both at once, as in the leg (PCIe is full duplex, but the two directions share the root complex and the
+        # host memory controller): the rates the bound below is priced with
+        t1 = time.perf_counter()
+        for r in range(reps):
+            with torch.cuda.stream(h2d_stream):
+                (d_u8 if as_u8 else d_in)[r % n_in].copy_(h_src, non_blocking=True)
+            with torch.cuda.stream(copy_stream):
+                for _ in range(max(1, round(in_bytes / (per_step * rec_bytes)))):  # keep the read-back busy throughout
+                    h_rec[r % depth][:per_step].copy_(packed[r % depth][:per_step], non_blocking=True)
+        h2d_stream.synchronize()
+        h2d_duplex = in_bytes * reps / (time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for r in range(reps):
+            with torch.cuda.stream(copy_stream):
+                h_rec[r % depth][:per_step].copy_(packed[r % depth][:per_step], non_blocking=True)
+            with torch.cuda.stream(h2d_stream):
+                for _ in range(max(1, round(per_step * rec_bytes / in_bytes))):
+                    (d_u8 if as_u8 else d_in)[r % n_in].copy_(h_src, non_blocking=True)
+        copy_stream.synchronize()
+        d2h_duplex = per_step * rec_bytes * reps / (time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        px = B * pipe.w * pipe.h
+        res.update({
+            "input": "%d x %dx%d %s in pinned host memory, uploaded every step" % (B, pipe.w, pipe.h,
+                                                                                   "uint8" if as_u8 else "float32"),
+            "Mpix_per_s": round(px / (dt / K) / 1e6, 1),
+            "keypoints_per_step": int(got["records"] / K),
+            "h2d_bytes_per_step": int(in_bytes), "h2d_GBps": round(in_bytes * K / dt / 1e9, 2),
+            "h2d_alone_GBps": round(h2d_alone / 1e9, 2), "d2h_alone_GBps": round(d2h_alone / 1e9, 2),
+            "h2d_duplex_GBps": round(h2d_duplex / 1e9, 2), "d2h_duplex_GBps": round(d2h_duplex / 1e9, 2),
+            "upload_buffers_in_flight": n_in,
+            "note": "pinned host pixels -> H2D on an upload stream%s -> extraction (rotating over %d streams) -> records "
+                    "packed on the device -> D2H on a copy stream into pinned host memory; upload, extraction and "
+                    "read-back of consecutive steps overlap; the region ends when the last record is on the host"
+                    % (" -> 8-bit to float on the device (cusift_u8_to_f32)" if as_u8 else "", E)})
     cctx.close()
-    return {"ms_per_step": round(dt / K * 1e3, 4), "keypoints_per_s": round(got["records"] / dt, 1),
-            "d2h_GBps": round(got["bytes"] / dt / 1e9, 2), "d2h_bytes_per_step": int(got["bytes"] / K),
-            "record_bytes": rec_bytes, "extraction_streams": E,
-            "note": "device-resident input -> SiftData records in pinned host memory (packed on the device, copied on "
-                    "a copy stream, overlapped with the following steps); bounded by the D2H copy when d2h_bytes_per_step "
-                    "/ PCIe rate exceeds the extraction time"}
+    return res
 
 
 def content_stats(torch, capi, ex, d_imgs, run_single_stream, w, h, B, args, steps):

@@ -96,6 +96,7 @@ SIGNATURES = {
     "cusift_comm_set_fixed_size": (_i, [_vp, _i]),
     "cusift_comm_set_wire_format": (_i, [_vp, _i]),
     "cusift_comm_host_waits": (C.c_ulonglong, [_vp]),
+    "cusift_comm_host_wait_ms": (C.c_double, [_vp]),
     "cusift_comm_hip_syncs": (C.c_ulonglong, [_vp]),
     "cusift_allgatherv_begin": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz]),
     "cusift_allgatherv_finish": (_i, [_vp, _vp, _vp]),
@@ -113,9 +114,10 @@ SIGNATURES = {
     "cusift_tiled_process": (_i, [_vp, _vp, _vp]),
     "cusift_tiled_extract": (_i, [_vp, _vp, _i, _vp, _vp]),
     "cusift_tiled_check": (_i, [_vp, C.POINTER(C.c_uint)]),
-    "cusift_exchange_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cusift_exchange_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cusift_exchange_halos": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
+    "cusift_ctx_reserve_bands": (_i, [_vp, _i, _i]),
     "cusift_ctx_arena_bytes": (_sz, [_vp]),
     "cusift_ctx_forks": (C.c_ulong, [_vp]),
     "cusift_ctx_timing_enable": (_i, [_vp, _i]),
@@ -538,6 +540,9 @@ class Comm:
     def host_waits(self):
         return int(lib().cusift_comm_host_waits(self._h))
 
+    def host_wait_ms(self):
+        return float(lib().cusift_comm_host_wait_ms(self._h))
+
     def hip_syncs(self):
         return int(lib().cusift_comm_hip_syncs(self._h))
 
@@ -565,11 +570,11 @@ class Comm:
         self.allgatherv_begin(d_points, d_counters, n_images, max_pts, n_images_max, d_gathered, region_cap, producer)
         return self.allgatherv_finish()
 
-    def exchange_rows(self, d_band, pitch, ops):
-        """ops: list of (peer, send_row, send_rows, recv_row, recv_rows)."""
+    def exchange_rows(self, d_band, pitch, band_rows, ops):
+        """ops: list of (peer, send_row, send_rows, recv_row, recv_rows); d_band holds band_rows rows."""
         a = np.ascontiguousarray(np.array(ops, dtype=np.int32).reshape(-1, 5).T)
         n = a.shape[1]
-        check(lib().cusift_exchange_rows(self._h, d_band, pitch, n, a[0].ctypes.data, a[1].ctypes.data,
+        check(lib().cusift_exchange_rows(self._h, d_band, pitch, band_rows, n, a[0].ctypes.data, a[1].ctypes.data,
                                          a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data))
 
     def exchange_halos(self, d_band, pitch, top_halo, own_rows, bottom_halo, send_rows):

@@ -701,6 +701,16 @@ extern "C" int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, c
   return ensure_arena(ctx, pl.total + align_up_sz((size_t)h * ialign_up(w, 128) * sizeof(float), 256));
 }
 
+// scratch of cusift_extract_bands: [counters of the bands | running sums | a list of heads per band]
+static size_t bands_arena_bytes(int n_bands, int max_pts) { return 512 + (size_t)max_pts * kStagedRecBytes * (size_t)n_bands; }
+
+extern "C" int cusift_ctx_reserve_bands(cusift_ctx *ctx, int n_bands, int max_pts) {
+  TRY(enter(ctx));
+  if (n_bands < 0 || n_bands > kMaxMultiOctaves || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "reserve_bands: 0..%d bands, max_pts >= 1", kMaxMultiOctaves);
+  return n_bands ? ensure_arena(ctx, bands_arena_bytes(n_bands, max_pts)) : CUSIFT_OK;
+}
+
 extern "C" size_t cusift_ctx_arena_bytes(cusift_ctx *ctx) { return ctx ? ctx->arena_bytes + ctx->dog_bytes : 0; }
 extern "C" unsigned long cusift_ctx_forks(cusift_ctx *ctx) { return ctx ? ctx->forks : 0; }
 
@@ -1350,10 +1360,12 @@ extern "C" int cusift_extract_bands(cusift_ctx *ctx, const cusift_band *bands, i
     if (k > 0 && !(b.subsampling == 2.0f * bands[k - 1].subsampling))
       return fail(CUSIFT_ERR_INVALID, "ExtractBands: band %d is not the next octave of band %d", k, k - 1);
   }
-  // scratch in the arena: [counters of the bands | running sums | a list of heads per band]
+  // scratch in the arena: [counters of the bands | running sums | a list of heads per band]; a no-op after
+  // cusift_ctx_reserve_bands (the tiled driver reserves at create: growing here synchronises the stream and frees the
+  // old arena in the middle of a rank's collective sequence)
   const size_t list_bytes = (size_t)max_pts * kStagedRecBytes;
   const size_t lists_off = 512;
-  TRY(ensure_arena(ctx, lists_off + list_bytes * n_bands));
+  TRY(ensure_arena(ctx, bands_arena_bytes(n_bands, max_pts)));
   unsigned int *seg_counts = (unsigned int *)ctx->arena;
   unsigned int *seg_end = seg_counts + 32;
   HIP_TRY(hipMemsetAsync(seg_counts, 0, 128, ctx->stream));

@@ -185,6 +185,7 @@ struct GatherTicket {
   size_t region_cap = 0;   // records per region
   size_t rec_bytes = 0;    // 588 (cusift_point) or 160 (cusift_compact_point)
   int slots = 0;  // count slots per rank of THIS exchange (<= comm n_slots)
+  const char *stage = nullptr;  // self_p2p: this ticket's slice of the staging buffer (its packed local shard)
 };
 
 struct cusift_comm {
@@ -201,8 +202,13 @@ struct cusift_comm {
   unsigned int next_seq = 1;
   std::vector<GatherTicket> tickets;
   unsigned int *d_block = nullptr, *h_block = nullptr;
-  cusift_point *d_stage = nullptr;  // self_p2p only: the packed local shard before it is "sent" into its region
+  // self_p2p only: the packed local shards before they are "sent" into their regions -- ONE SLICE PER TICKET
+  // (stage_depth slices of stage_cap records): begin(i + 1) packs while the shard of ticket i is still unsent
+  cusift_point *d_stage = nullptr;
   size_t stage_cap = 0;
+  int stage_depth = 0;
+  bool failed = false;  // an exchange timed out: device work of unknown state may still reference the tickets
+  double host_wait_ms = 0.0;          // time finish() spent waiting for counts (diagnostic)
   unsigned long long host_waits = 0;  // finish() calls that found their counts not yet arrived (diagnostic)
   unsigned long long hip_syncs = 0;   // synchronising HIP calls this object has made (only ever while (re)sizing)
 };
@@ -282,15 +288,23 @@ int reserve_tickets(cusift_comm *c, int n_slots, int depth) {
   return CUSIFT_OK;
 }
 
+// `records` per ticket, one slice for each ticket of the ring (call after reserve_tickets)
 int reserve_stage(cusift_comm *c, size_t records) {
-  if (records <= c->stage_cap) return CUSIFT_OK;
+  if (records <= c->stage_cap && c->depth <= c->stage_depth) return CUSIFT_OK;
+  if (c->pending)
+    return cusift_fail(CUSIFT_ERR_INVALID, "comm: cannot grow the self-send staging (%zu -> %zu records per ticket) with "
+                                           "exchanges in flight: an unsent shard lives there (cusift_comm_reserve first)",
+                       c->stage_cap, records);
+  records = std::max(records, c->stage_cap);
   c->hip_syncs++;
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->d_stage) HIP_TRY(hipFree(c->d_stage));
   c->d_stage = nullptr;
   c->stage_cap = 0;
-  HIP_TRY(hipMalloc((void **)&c->d_stage, sizeof(cusift_point) * records));
+  c->stage_depth = 0;
+  HIP_TRY(hipMalloc((void **)&c->d_stage, sizeof(cusift_point) * records * (size_t)c->depth));
   c->stage_cap = records;
+  c->stage_depth = c->depth;
   return CUSIFT_OK;
 }
 
@@ -302,7 +316,7 @@ int post_shards(cusift_comm *c, const GatherTicket &k, const size_t *n_records) 
   if (first >= W) return CUSIFT_OK;
   const size_t mine = n_records[c->rank];
   const size_t words = k.rec_bytes / 4, region_bytes = k.region_cap * k.rec_bytes;
-  const char *src = c->self_p2p ? (const char *)c->d_stage : k.d_gathered + (size_t)c->rank * region_bytes;
+  const char *src = c->self_p2p ? k.stage : k.d_gathered + (size_t)c->rank * region_bytes;
   GroupScope g(c->lib);
   NCCL_TRY(c, g.start());
   for (int step = first; step < W; ++step) {
@@ -417,6 +431,7 @@ extern "C" int cusift_comm_reserve(cusift_comm *c, int n_images_max, int tickets
 }
 
 extern "C" unsigned long long cusift_comm_host_waits(cusift_comm *c) { return c ? c->host_waits : 0; }
+extern "C" double cusift_comm_host_wait_ms(cusift_comm *c) { return c ? c->host_wait_ms : 0.0; }
 extern "C" unsigned long long cusift_comm_hip_syncs(cusift_comm *c) { return c ? c->hip_syncs : 0; }
 
 extern "C" const char *cusift_comm_library(void) {
@@ -433,6 +448,8 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
                                        const unsigned int *d_counters, int n_images, int max_pts, int n_images_max,
                                        void *d_gathered, size_t region_cap) {
   TRY(comm_enter(c));
+  if (c->failed)
+    return cusift_fail(CUSIFT_ERR_HIP, "allgatherv: an earlier exchange of this communicator timed out; destroy it");
   if ((n_images > 0 && (!d_points || !d_counters)) || !d_gathered)
     return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: missing data");
   if (n_images < 0 || n_images > cusift::kMaxFlatImages || max_pts < 1 || n_images_max < std::max(1, n_images) ||
@@ -451,7 +468,9 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
                        c->depth);
   // the records are produced on another stream: order this exchange after everything enqueued there so far
   if (producer) TRY(cusift_ctx_wait(c->ctx, producer));
-  GatherTicket &k = c->tickets[(c->head + c->pending) % c->depth];
+  const int slot = (c->head + c->pending) % c->depth;
+  GatherTicket &k = c->tickets[slot];
+  k.stage = c->self_p2p ? (const char *)(c->d_stage + (size_t)slot * c->stage_cap) : nullptr;
   k.seq = c->next_seq++;
   k.rec_bytes = c->compact ? sizeof(cusift_compact_point) : sizeof(cusift_point);
   k.d_gathered = (char *)d_gathered;
@@ -463,7 +482,7 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
   // the local shard is packed straight into its region of the gathered buffer and sent from there: once this has run
   // the caller's d_points / d_counters are free again
   if (n_images > 0) {
-    char *dst = c->self_p2p ? (char *)c->d_stage : k.d_gathered + (size_t)c->rank * region_cap * k.rec_bytes;
+    char *dst = c->self_p2p ? const_cast<char *>(k.stage) : k.d_gathered + (size_t)c->rank * region_cap * k.rec_bytes;
     if (c->compact)
       TRY(cusift_pack_points_compact(c->ctx, d_points, d_counters, n_images, max_pts, (cusift_compact_point *)dst,
                                      region_cap, nullptr));
@@ -484,6 +503,8 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
 
 extern "C" int cusift_allgatherv_finish(cusift_comm *c, unsigned int *h_counts, size_t *h_totals) {
   TRY(comm_enter(c));
+  if (c->failed)
+    return cusift_fail(CUSIFT_ERR_HIP, "allgatherv: an earlier exchange of this communicator timed out; destroy it");
   if (!c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "allgatherv: finish() without begin()");
   GatherTicket &k = c->tickets[c->head];
   // The sizes of ncclSend/ncclRecv are host arguments, so the counts are READ here; they are not WAITED for when the
@@ -498,13 +519,16 @@ extern "C" int cusift_allgatherv_finish(cusift_comm *c, unsigned int *h_counts, 
       if ((++spins & 1023) == 0) {
         sched_yield();
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-          c->head = (c->head + 1) % c->depth;
-          c->pending--;
+          // The ticket is NOT recycled: its clamp / AllGather / publish kernels may still be queued and would write
+          // under a later begin().  The communicator is dead from here on (every later begin / finish fails); the
+          // caller destroys it, which waits for the stream.
+          c->failed = true;
           return cusift_fail(CUSIFT_ERR_HIP, "allgatherv: the gathered counts never arrived (a rank missing from the "
-                                             "exchange, or the device is hung)");
+                                             "exchange, or the device is hung); the communicator must be destroyed");
         }
       }
     }
+    c->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   c->head = (c->head + 1) % c->depth;
   c->pending--;
@@ -554,17 +578,23 @@ extern "C" int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_ga
 // ------------------------------------------------------------------------------------------------
 // rows of a pitched float image between ranks: halo exchange of the strip tiling, and gather/scatter of bands
 // ------------------------------------------------------------------------------------------------
-extern "C" int cusift_exchange_rows(cusift_comm *c, float *d_band, int pitch, int n_ops, const int *peers,
+extern "C" int cusift_exchange_rows(cusift_comm *c, float *d_band, int pitch, int band_rows, int n_ops, const int *peers,
                                     const int *send_row, const int *send_rows, const int *recv_row,
                                     const int *recv_rows) {
   TRY(comm_enter(c));
-  if (n_ops < 0 || (n_ops > 0 && (!d_band || !peers || !send_row || !send_rows || !recv_row || !recv_rows)) || pitch < 1)
+  if (n_ops < 0 || (n_ops > 0 && (!d_band || !peers || !send_row || !send_rows || !recv_row || !recv_rows)) || pitch < 1 ||
+      band_rows < 0)
     return cusift_fail(CUSIFT_ERR_INVALID, "exchange_rows: bad argument");
   bool any = false;
   for (int i = 0; i < n_ops; ++i) {
     if (peers[i] < 0 || peers[i] >= c->world || send_rows[i] < 0 || recv_rows[i] < 0 || send_row[i] < 0 ||
         recv_row[i] < 0)
       return cusift_fail(CUSIFT_ERR_INVALID, "exchange_rows: op %d: bad peer or rows", i);
+    // the rows are read / written by RCCL on the device: a range outside the band is a memory fault, not an error code
+    if ((long)send_row[i] + send_rows[i] > band_rows || (long)recv_row[i] + recv_rows[i] > band_rows)
+      return cusift_fail(CUSIFT_ERR_INVALID, "exchange_rows: op %d: rows [%d, %d) sent / [%d, %d) received lie outside the "
+                                             "band's %d rows", i, send_row[i], send_row[i] + send_rows[i], recv_row[i],
+                         recv_row[i] + recv_rows[i], band_rows);
     if (peers[i] == c->rank && !c->self_p2p)
       return cusift_fail(CUSIFT_ERR_INVALID, "exchange_rows: op %d addresses this rank", i);
     any = any || send_rows[i] > 0 || recv_rows[i] > 0;
@@ -606,5 +636,5 @@ extern "C" int cusift_exchange_halos(cusift_comm *c, float *d_band, int pitch, i
     rrows[n] = bottom_halo;
     ++n;
   }
-  return cusift_exchange_rows(c, d_band, pitch, n, peers, srow, srows, rrow, rrows);
+  return cusift_exchange_rows(c, d_band, pitch, top_halo + own_rows + bottom_halo, n, peers, srow, srows, rrow, rrows);
 }

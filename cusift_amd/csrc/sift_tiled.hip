@@ -227,6 +227,8 @@ extern "C" int cusift_tiled_create(cusift_tiled **out, cusift_ctx *ctx, cusift_c
     sub.num_octaves = pl.n_oct - pl.collapse;
     TRY(cusift_ctx_reserve(ctx, 1, pl.w[pl.collapse], pl.h[pl.collapse], &sub));
   }
+  // every rank: the scratch of cusift_extract_bands for its tiled octaves (the root's arena is the larger of the two)
+  TRY(cusift_ctx_reserve_bands(ctx, std::min(std::min(pl.collapse, pl.n_oct), 8), prm->max_pts));
   t->per_octave = getenv("CUSIFT_TILED_PER_OCTAVE") != nullptr;
   HIP_TRY(hipMalloc((void **)&t->d_small, 256));
   HIP_TRY(hipMemsetAsync(t->d_small, 0, 256, t->stream));
@@ -331,13 +333,13 @@ extern "C" int cusift_tiled_exchange(cusift_tiled *t, int o) {
     }
     if (peer.empty()) return CUSIFT_OK;
     if (!t->comm) return cusift_fail(CUSIFT_ERR_INVALID, "tiled: world %d needs a communicator", pl.world);
-    return cusift_exchange_rows(t->comm, t->full, pl.pitch[o], (int)peer.size(), peer.data(), srow.data(), srows.data(),
-                                rrow.data(), rrows.data());
+    return cusift_exchange_rows(t->comm, t->full, pl.pitch[o], pl.h[o], (int)peer.size(), peer.data(), srow.data(),
+                                srows.data(), rrow.data(), rrows.data());
   }
   if (b <= a) return CUSIFT_OK;
   if (!t->comm) return cusift_fail(CUSIFT_ERR_INVALID, "tiled: world %d needs a communicator", pl.world);
   const int peer = pl.root, srow = a - lo, srows = b - a, zero = 0;
-  return cusift_exchange_rows(t->comm, t->bands[o], pl.pitch[o], 1, &peer, &srow, &srows, &zero, &zero);
+  return cusift_exchange_rows(t->comm, t->bands[o], pl.pitch[o], hi - lo, 1, &peer, &srow, &srows, &zero, &zero);
 }
 
 // The exchange of octave o among P extractors of ONE process (no communicator): device copies, enqueued on the

@@ -208,7 +208,7 @@ def run_virtual(exts, strips):
         if o > 0:
             for e in exts:
                 e.tiled.build_octave(o)
-        if len(exts) > 1:
+        if len(exts) > 1 or o == pl.collapse:  # one extractor: the collapse octave still moves its band into `full`
             capi.tiled_exchange_virtual(tiles, o)
     for e in exts:
         e.process()

@@ -113,6 +113,9 @@ int cusift_ctx_device(cusift_ctx *ctx);
 int cusift_ctx_wait(cusift_ctx *ctx, cusift_ctx *other);
 /* Pre-size the scratch arena for batches of n_images w x h images (otherwise grown on demand). */
 int cusift_ctx_reserve(cusift_ctx *ctx, int n_images, int w, int h, const cusift_params *p);
+/* Pre-size the arena for cusift_extract_bands over up to n_bands bands of one image with max_pts records (the strip
+ * tiling's per-rank step; cusift_tiled_create calls it on every rank so that no extraction allocates). */
+int cusift_ctx_reserve_bands(cusift_ctx *ctx, int n_bands, int max_pts);
 /* Bytes of HBM currently held by the arena. */
 size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
 /* How many extractions of this context ran octave 0's detection on the context's second stream (see
@@ -362,6 +365,8 @@ int cusift_comm_set_wire_format(cusift_comm *comm, int compact);
 /* Diagnostic: how many finish() calls found their counts not yet there, i.e. the host was ahead of the GPU (in a
  * GPU-bound pipelined loop that is the normal case and costs nothing: the device has the caller's other steps queued). */
 unsigned long long cusift_comm_host_waits(cusift_comm *comm);
+/* ... and the wall time those finish() calls spent waiting, in milliseconds. */
+double cusift_comm_host_wait_ms(cusift_comm *comm);
 /* Diagnostic: synchronising HIP calls (hipStreamSynchronize) this communicator has made so far -- they only happen while
  * its buffers are (re)sized: after cusift_comm_reserve the number stays put through any number of begin / finish. */
 unsigned long long cusift_comm_hip_syncs(cusift_comm *comm);
@@ -395,13 +400,14 @@ int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_gathered, siz
 
 /* Rows of a pitched float image between ranks, as one ncclGroup: op i sends send_rows[i] rows starting at local row
  * send_row[i] of d_band to peers[i] and receives recv_rows[i] rows from it into local row recv_row[i] (`pitch` floats
- * per row; the peer must post the mirror image).  Asynchronous.
+ * per row; the peer must post the mirror image; d_band holds `band_rows` rows and every op is checked against that --
+ * RCCL reads and writes the rows on the device, where a range outside the allocation is a fault).  Asynchronous.
  * cusift_exchange_halos is the strip tiling's per-octave step (cusift_*_band entry points, BASELINE configs[4]): a band
  * is [top_halo rows of the neighbour above][own_rows][bottom_halo rows of the neighbour below]; the first / last
  * `send_rows` owned rows go to rank-1 / rank+1 and their counterparts arrive in the halo rows (every interior rank
  * uses the same send_rows == its neighbours' halo depth; rank 0 has top_halo = 0, the last rank bottom_halo = 0). */
-int cusift_exchange_rows(cusift_comm *comm, float *d_band, int pitch, int n_ops, const int *peers, const int *send_row,
-                         const int *send_rows, const int *recv_row, const int *recv_rows);
+int cusift_exchange_rows(cusift_comm *comm, float *d_band, int pitch, int band_rows, int n_ops, const int *peers,
+                         const int *send_row, const int *send_rows, const int *recv_row, const int *recv_rows);
 int cusift_exchange_halos(cusift_comm *comm, float *d_band, int pitch, int top_halo, int own_rows, int bottom_halo,
                           int send_rows);
 

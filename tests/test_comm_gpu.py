@@ -48,15 +48,24 @@ def test_allgatherv_world1_equals_pack_points(extracted, self_p2p):
         assert not counts[0, 5:].any()
         assert int(totals[0]) == total
         assert torch.equal(gathered[0, :total].cpu(), want.cpu()), rep
-    # two exchanges in flight, finished oldest first
+    # two exchanges in flight with DIFFERENT contents, finished oldest first: with self_p2p each ticket's packed shard
+    # waits in a staging slice of its own until finish() posts it (one shared buffer sent the LATER step's records)
+    cnt_b = cnt.clone()
+    cnt_b[0] = cnt_b[0] // 2
+    cnt_b[2] = 0
+    want_b, valid_b = pack_points(pts, cnt_b, ex.max_pts)
+    total_b = int(valid_b.sum())
+    assert 0 < total_b < total
+    torch.cuda.synchronize()
     g.begin(pts, cnt, producer=ex.ctx)
-    g.begin(pts, cnt, producer=ex.ctx)
+    g.begin(pts, cnt_b, producer=ex.ctx)
     with pytest.raises(capi.CusiftError, match="in flight"):
         g.begin(pts, cnt, producer=ex.ctx)
-    for _ in range(2):
+    for want_i, total_i in ((want, total), (want_b, total_b)):
         counts, gathered, totals = g.finish()
         side.synchronize()
-        assert torch.equal(gathered[0, :total].cpu(), want.cpu())
+        assert int(totals[0]) == total_i
+        assert torch.equal(gathered[0, :total_i].cpu(), want_i.cpu())
     # saturated counters are clamped on the device
     cnt2 = cnt.clone()
     cnt2[1] = 10 ** 6
@@ -95,7 +104,7 @@ def test_exchange_rows_self(ctx):
     with torch.cuda.stream(st):
         st.wait_stream(torch.cuda.current_stream())
         # first 2 owned rows -> top halo, last 2 owned rows -> bottom halo (what a neighbour would receive)
-        comm.exchange_rows(band.data_ptr(), pitch, [(0, 2, 2, 0, 2), (0, 6, 2, 8, 2)])
+        comm.exchange_rows(band.data_ptr(), pitch, rows, [(0, 2, 2, 0, 2), (0, 6, 2, 8, 2)])
     st.synchronize()
     assert torch.equal(band[0:2], before[2:4]) and torch.equal(band[8:10], before[6:8])
     assert torch.equal(band[2:8], before[2:8])
@@ -104,7 +113,12 @@ def test_exchange_rows_self(ctx):
     # without self_p2p a self-addressed op is refused
     comm2 = make_comm(c)
     with pytest.raises(capi.CusiftError, match="addresses this rank"):
-        comm2.exchange_rows(band.data_ptr(), pitch, [(0, 2, 2, 0, 2)])
+        comm2.exchange_rows(band.data_ptr(), pitch, rows, [(0, 2, 2, 0, 2)])
+    # rows outside the band are refused on the host (RCCL would read / write them on the device)
+    with pytest.raises(capi.CusiftError, match="outside the band"):
+        comm.exchange_rows(band.data_ptr(), pitch, rows, [(0, 2, 2, 9, 2)])
+    with pytest.raises(capi.CusiftError, match="outside the band"):
+        comm.exchange_rows(band.data_ptr(), pitch, rows, [(0, 9, 2, 0, 2)])
     comm2.close()
     comm.close()
     c.close()
