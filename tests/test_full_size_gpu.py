@@ -4,8 +4,8 @@ configs[2]  batch of 64 x 1920x1080 (5 octaves, initBlur 1.0, thresh 3.0): exact
             cusift_extract_batch.  The arena of this size (cuSIFT.cu:74-98 sizes the reference's per image) crosses
             2^31-byte offsets that an 8-image batch never touches.  Sampled images are compared with the CPU oracle
             keypoint by keypoint; all 64 counts must equal the single-image extractions.
-configs[4]  one 8192x8192 image over 8 ranks (strip tiling + halo exchange): 8 virtual ranks on one GPU, the union of
-            their SiftData must equal the whole-image extraction bit for bit.
+configs[4]  one 8192x8192 image over 8 ranks (strip tiling + halo exchange): the whole-image extraction against the CPU
+            oracle keypoint by keypoint, then 8 virtual ranks on one GPU whose SiftData united must equal it bit for bit.
 """
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -64,6 +64,24 @@ def test_batch64_1080p_matches_oracle(ctx, oracle):
         compare_sets(want, got)
     for b in (d_imgs, d_pts, d_cnt):
         b.free()
+
+
+def test_whole_8192_matches_oracle(ctx, oracle):
+    """configs[4]'s image at full size against the ORACLE, every keypoint (the strip test below compares the tiled result
+    with this whole-image extraction, i.e. the HIP path with itself: until round 4 the largest oracle-checked image was
+    4096 x 3072).  The oracle needs ~15 s for the 67 Mpx on one host core."""
+    W = H = 8192
+    img = synth.tile(4242, W, H, preblur=1.0)
+    kw = dict(num_octaves=5, init_blur=1.0, peak_thresh=3.0, edge_thresh=10.0, max_pts=1 << 18)
+    want = oracle.extract(img, **kw)
+    prm = capi.default_params(**kw)
+    d_pts = DeviceBuffer(ctx, prm.max_pts * 588)
+    h_pts = np.zeros(prm.max_pts, dtype=SIFT_POINT_DTYPE)
+    n = ctx.extract_host(img, prm, d_pts.ptr, h_pts)
+    d_pts.free()
+    assert 50000 < n == len(want) < prm.max_pts
+    assert np.all(np.diff(h_pts[:n]["subsampling"]) <= 0)
+    compare_sets(want, h_pts[:n])
 
 
 @pytest.mark.parametrize("n_oct", [5, 7])

@@ -17,7 +17,7 @@ from cusift_amd import capi
 from cusift_amd import synth
 from cusift_amd.capi import SIFT_POINT_DTYPE, DeviceBuffer
 from oracle_binding import pitched
-from parity_utils import ang_diff, canonical_order, match_nearest, xys
+from parity_utils import golden_gates, ang_diff, canonical_order, match_nearest, xys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -567,17 +567,14 @@ def test_extract_fixture_matches_oracle(ctx, oracle, gray1):
     compare_sets(want, got)
 
 
-def test_extract_fixture_vs_reference_golden(ctx, gray1, golden_check):
-    """The HIP path itself against the reference's golden file (same gates as the oracle's pin)."""
+@pytest.mark.parametrize("which", ["cusift1_check", "cusift1"])
+def test_extract_fixture_vs_reference_golden(ctx, gray1, golden_check, golden_run2, which, record_property):
+    """The HIP path itself against BOTH of the reference's golden files, all 4096 rows of each: the gates of the oracle's
+    pin (tests/parity_utils.golden_gates -- location + scale, and orientation on the coarse AND the octave-0 rows)."""
     got = gpu_extract(ctx, gray1, **REF_PARAMS)
-    gold = golden_check.astype(np.float64)
-    idx, dist = match_nearest(gold[:1555, :3], xys(got), 1e-2)
-    assert (dist < 1e-2).all()
-    assert (dist < 1e-3).mean() >= 0.98
-    d = ang_diff(gold[:1555, 3], got["orientation"][idx].astype(np.float64))
-    assert (d < 0.1).mean() >= 0.90 and (d < 1.0).mean() >= 0.97
-    idx0, dist0 = match_nearest(gold[1555:, :3], xys(got), 1e-2)
-    assert (dist0 < 1e-2).mean() >= 0.995
+    res = golden_gates(golden_check if which == "cusift1_check" else golden_run2, got, "HIP path")
+    for k, v in res.items():
+        record_property(k, v)
 
 
 def test_canonical_sort_makes_runs_identical_arrays(ctx, gray1):
