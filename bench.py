@@ -346,10 +346,6 @@ def main():
                     help="rehearse the launch only: ranks rendezvous over gloo on the CPU, shard the batch, barrier, "
                          "reduce a time and rank 0 prints a line -- no GPU, no extraction (tests the --gpus N spawn)")
     args = ap.parse_args()
-    if args.profile_run:
-        # one launch sequence per step under the profiler (its per-kernel figures are means per launch): no side stream
-        # for octave 0 (read when a context is created), no probe kernels
-        os.environ["CUSIFT_OCTAVE_OVERLAP"] = "0"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as a plain command: this process has not touched a GPU (no torch import, no HIP
         # call so far) and never will -- it starts the N ranks as CHILDREN and relays rank 0's line
@@ -685,6 +681,8 @@ def main():
             # detection on the context's second stream beside the ScaleDown chain and the coarser octaves
             forks0 = ex.ctx.forks()
             lone_steps = 0 if args.profile_run else K  # (not under the profiler: its per-kernel averages are per launch)
+            if lone_steps:  # the side stream is opt-in (nothing in the timed region or any other leg uses it)
+                ex.ctx.set_policy(capi.POLICY_SIDE_STREAM, 2)  # after the probe: four other streams are in use here
             for _ in range(2 if lone_steps else 0):
                 ex.extract(d_imgs)
             torch.cuda.synchronize()
@@ -693,6 +691,7 @@ def main():
                 ex.extract(d_imgs)
             torch.cuda.synchronize()
             lone_ms = (time.perf_counter() - t1) / max(1, lone_steps) * 1e3
+            ex.ctx.set_policy(capi.POLICY_SIDE_STREAM, 0)
             out["single_stream_leg"] = {
                 "ms_per_step": round(single_ms, 4),
                 "lone_caller_ms_per_step": round(lone_ms, 4) if lone_steps else None,
@@ -869,11 +868,12 @@ def main():
                 leg = host_visible_leg(torch, capi, pipe, d_imgs, K if tag == "u8" else max(8, K // 4), B, args.max_pts,
                                        local_rank, dev, total_local_kp=local_kp, h_src=h_src)
                 # the three things that can bound a step: the upload, the extraction, the read-back -- each as measured
-                # in this run (PCIe rates with the leg's own buffers while the OTHER direction is busy too, as in the leg;
-                # extraction = the timed region)
-                parts = {"h2d_ms": leg["h2d_bytes_per_step"] / (leg["h2d_duplex_GBps"] * 1e9) * 1e3,
+                # in this run (PCIe rates with the leg's own buffers, each direction ALONE -- in the leg the two directions
+                # run at once and share the host side of the link, so this bound is optimistic; extraction = the timed
+                # region)
+                parts = {"h2d_ms": leg["h2d_bytes_per_step"] / (leg["h2d_alone_GBps"] * 1e9) * 1e3,
                          "extract_ms": ms_per_step,
-                         "d2h_ms": leg["d2h_bytes_per_step"] / (leg["d2h_duplex_GBps"] * 1e9) * 1e3}
+                         "d2h_ms": leg["d2h_bytes_per_step"] / (leg["d2h_alone_GBps"] * 1e9) * 1e3}
                 bound = max(parts.values())
                 leg["bound"] = {k: round(v, 4) for k, v in parts.items()}
                 leg["bound"]["slowest"] = max(parts, key=parts.get)
@@ -1093,7 +1093,7 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
     # staging slots: a step's records leave depth - 2 steps after it was enqueued.  The exact records are bound by the
     # copy itself (99 MB per step over PCIe); the compact ones are not, and need the host to stay further ahead than the
     # 4-stream extraction pipeline is deep
-    depth = 8 if compact else (6 if h_src is not None else 4)
+    depth = 8 if compact else 4
     rec_bytes = capi.COMPACT_POINT_BYTES if compact else capi.SIFT_POINT_BYTES
     packed = [torch.empty((cap, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]
     offs = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
@@ -1188,28 +1188,6 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
                 h_rec[r % depth][:per_step].copy_(packed[r % depth][:per_step], non_blocking=True)
         torch.cuda.synchronize()
         d2h_alone = per_step * rec_bytes * reps / (time.perf_counter() - t1)
-        # ... and both at once, as in the leg (PCIe is full duplex, but the two directions share the root complex and the
-        # host memory controller): the rates the bound below is priced with
-        t1 = time.perf_counter()
-        for r in range(reps):
-            with torch.cuda.stream(h2d_stream):
-                (d_u8 if as_u8 else d_in)[r % n_in].copy_(h_src, non_blocking=True)
-            with torch.cuda.stream(copy_stream):
-                for _ in range(max(1, round(in_bytes / (per_step * rec_bytes)))):  # keep the read-back busy throughout
-                    h_rec[r % depth][:per_step].copy_(packed[r % depth][:per_step], non_blocking=True)
-        h2d_stream.synchronize()
-        h2d_duplex = in_bytes * reps / (time.perf_counter() - t1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for r in range(reps):
-            with torch.cuda.stream(copy_stream):
-                h_rec[r % depth][:per_step].copy_(packed[r % depth][:per_step], non_blocking=True)
-            with torch.cuda.stream(h2d_stream):
-                for _ in range(max(1, round(per_step * rec_bytes / in_bytes))):
-                    (d_u8 if as_u8 else d_in)[r % n_in].copy_(h_src, non_blocking=True)
-        copy_stream.synchronize()
-        d2h_duplex = per_step * rec_bytes * reps / (time.perf_counter() - t1)
-        torch.cuda.synchronize()
         px = B * pipe.w * pipe.h
         res.update({
             "input": "%d x %dx%d %s in pinned host memory, uploaded every step" % (B, pipe.w, pipe.h,
@@ -1218,7 +1196,6 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
             "keypoints_per_step": int(got["records"] / K),
             "h2d_bytes_per_step": int(in_bytes), "h2d_GBps": round(in_bytes * K / dt / 1e9, 2),
             "h2d_alone_GBps": round(h2d_alone / 1e9, 2), "d2h_alone_GBps": round(d2h_alone / 1e9, 2),
-            "h2d_duplex_GBps": round(h2d_duplex / 1e9, 2), "d2h_duplex_GBps": round(d2h_duplex / 1e9, 2),
             "upload_buffers_in_flight": n_in,
             "note": "pinned host pixels -> H2D on an upload stream%s -> extraction (rotating over %d streams) -> records "
                     "packed on the device -> D2H on a copy stream into pinned host memory; upload, extraction and "

@@ -1,6 +1,10 @@
 """Builds libcusift_amd.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
 
-    python -m cusift_amd.build [--force]
+    python -m cusift_amd.build [--force] [--lab]
+
+--lab builds libcusift_amd_lab.so with -DCUSIFT_LAB: the same kernels, plus the tuning overrides the A/B scripts under
+tools/ read from the environment (CUSIFT_*_ROWS_*, CUSIFT_DETECT_WAVES, ...; select it with CUSIFT_AMD_LIB=<path>).  The
+product library reads none of them.
 
 The shared object lands next to this file so that it travels to the GPU box with the source tree.
 """
@@ -12,9 +16,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcusift_amd.so")
-SOURCES = ["sift_capi.hip", "sift_stencils.hip", "sift_keypoints.hip", "sift_match.hip",
+SOURCES = ["sift_context.hip", "sift_stages.hip", "sift_driver.hip", "sift_stencils.hip", "sift_keypoints.hip", "sift_match.hip",
            "sift_frontend.hip", "sift_homography.hip", "sift_comm.hip", "sift_tiled.hip"]
-HEADERS = [os.path.join(CSRC, "detect_chunk.inc"), os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"), os.path.join(CSRC, "sift_internal.h"),
+HEADERS = [os.path.join(CSRC, "detect_chunk.inc"), os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"), os.path.join(CSRC, "sift_internal.h"), os.path.join(CSRC, "sift_host.h"),
            os.path.join(HERE, "..", "include", "cusift_amd.h")]
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).
@@ -51,8 +55,17 @@ def is_stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+LAB_LIB = os.path.join(HERE, "libcusift_amd_lab.so")
+
+
+def build(force=False, verbose=False, lab=False):
     """Compile the HIP extension for gfx950 if missing or older than its sources. Returns the path."""
+    if lab:
+        cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DCUSIFT_LAB", "-o", LAB_LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return LAB_LIB
     if not force and not is_stale():
         return LIB
     # build into a temporary file and rename it onto LIB: a concurrent rank that loads the library (or builds it too)
@@ -71,4 +84,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))

@@ -118,6 +118,8 @@ SIGNATURES = {
     "cusift_exchange_halos": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
     "cusift_ctx_reserve_bands": (_i, [_vp, _i, _i]),
+    "cusift_ctx_set_policy": (_i, [_vp, _i, _i]),
+    "cusift_ctx_get_policy": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "cusift_ctx_arena_bytes": (_sz, [_vp]),
     "cusift_ctx_forks": (C.c_ulong, [_vp]),
     "cusift_ctx_timing_enable": (_i, [_vp, _i]),
@@ -241,6 +243,11 @@ def ialign_up(a, b):
     return (a - a % b + b) if (a % b != 0) else a
 
 
+# cusift_ctx_set_policy keys (include/cusift_amd.h)
+POLICY_SIDE_STREAM, POLICY_OCTAVE_LISTS, POLICY_GENERIC_KERNELS, POLICY_LAUNCH_PER_OCTAVE, POLICY_MATCH_SPLITS, \
+    POLICY_TILED_PER_OCTAVE = range(6)
+
+
 class Context:
     """cusift_ctx: one device + one HIP stream + the scratch arena."""
 
@@ -294,6 +301,14 @@ class Context:
 
     def arena_bytes(self):
         return lib().cusift_ctx_arena_bytes(self.handle)
+
+    def set_policy(self, key, value):
+        check(lib().cusift_ctx_set_policy(self.handle, int(key), int(value)))
+
+    def get_policy(self, key):
+        v = C.c_int(0)
+        check(lib().cusift_ctx_get_policy(self.handle, int(key), C.byref(v)))
+        return v.value
 
     def forks(self):
         """cusift_ctx_forks: extractions that ran octave 0's detection on the context's second stream."""

@@ -369,7 +369,6 @@ extern "C" int cusift_comm_create(cusift_comm **out, cusift_ctx *ctx, const char
   c->rank = rank;
   c->world = world;
   c->lib = lib;
-  if (const char *e = getenv("CUSIFT_COMM_SELF_P2P")) c->self_p2p = atoi(e) != 0;
   ncclUniqueId u;
   memcpy(u.internal, id, CUSIFT_UNIQUE_ID_BYTES);
   ncclResult_t r = lib->CommInitRank(&c->nccl, world, u, rank);

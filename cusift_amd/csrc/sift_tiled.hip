@@ -229,7 +229,9 @@ extern "C" int cusift_tiled_create(cusift_tiled **out, cusift_ctx *ctx, cusift_c
   }
   // every rank: the scratch of cusift_extract_bands for its tiled octaves (the root's arena is the larger of the two)
   TRY(cusift_ctx_reserve_bands(ctx, std::min(std::min(pl.collapse, pl.n_oct), 8), prm->max_pts));
-  t->per_octave = getenv("CUSIFT_TILED_PER_OCTAVE") != nullptr;
+  int per_octave = 0;
+  TRY(cusift_ctx_get_policy(ctx, CUSIFT_POLICY_TILED_PER_OCTAVE, &per_octave));
+  t->per_octave = per_octave != 0;
   HIP_TRY(hipMalloc((void **)&t->d_small, 256));
   HIP_TRY(hipMemsetAsync(t->d_small, 0, 256, t->stream));
   *out = t.release();

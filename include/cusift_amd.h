@@ -119,8 +119,31 @@ int cusift_ctx_reserve_bands(cusift_ctx *ctx, int n_bands, int max_pts);
 /* Bytes of HBM currently held by the arena. */
 size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
 /* How many extractions of this context ran octave 0's detection on the context's second stream (see
- * cusift_params.concurrent_batches; $CUSIFT_OCTAVE_OVERLAP, read when the context is created: 0 never, 2 always). */
+ * CUSIFT_POLICY_SIDE_STREAM below). */
 unsigned long cusift_ctx_forks(cusift_ctx *ctx);
+/* Launch policy of a context (new; the reference has one fixed launch sequence, cuSIFT.cu:175-270).  Results never
+ * depend on it -- only which kernels run on which stream in which order.  The defaults are deterministic functions of
+ * the call's size and of cusift_params.concurrent_batches; nothing is decided by timing unless asked for (value 2 of
+ * the first key).  The only environment variable the library's extraction code reads is CUSIFT_OCTAVE_OVERLAP (= the
+ * first key's value, read when a context is created) so that an unchanged caller of the C++ shim can opt in. */
+enum {
+  /* Octave 0's detection on a second stream of the context beside the ScaleDown chain and the coarser octaves, for
+   * callers that keep ONE batch in flight (concurrent_batches < 2) and calls of >= 6 Mpixel: 0 never (default),
+   * 1 yes, 2 yes if a one-time probe finds that the device runs the two streams side by side (HIP maps streams onto
+   * a few hardware queues; which one a new stream lands on depends on what else the process created), 3 every call
+   * whatever its size (tests). */
+  CUSIFT_POLICY_SIDE_STREAM = 0,
+  /* Keypoints of every octave to lists of their own, joined by the description kernel, so that all octaves are
+   * searched by one launch: -1 by size (default: lone callers always, pipelining callers up to 16 Mpixel per call),
+   * 0 never, 1 whenever the lists fit. */
+  CUSIFT_POLICY_OCTAVE_LISTS = 1,
+  CUSIFT_POLICY_GENERIC_KERNELS = 2,   /* 1: the generic (any pitch / alignment) kernels even where the fast ones apply */
+  CUSIFT_POLICY_LAUNCH_PER_OCTAVE = 3, /* 1: with lists, still one detection launch per coarser octave */
+  CUSIFT_POLICY_MATCH_SPLITS = 4,      /* cusift_match: column splits of the second set (0: by size) */
+  CUSIFT_POLICY_TILED_PER_OCTAVE = 5   /* cusift_tiled_*: one detection + description launch per tiled octave */
+};
+int cusift_ctx_set_policy(cusift_ctx *ctx, int key, int value);
+int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value);
 /* Per-stage GPU timing with HIP events on the context's stream (TimerGPU, cutils.h:94-114, used at
  * cuSIFT.cu:64,177,208,238,249).  Stages: 0 ScaleDown, 1 LaplaceMulti, 2 FindPointsMulti,
  * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call, 6 fused detection, 7 orientation+descriptor of all octaves in one launch.  Accumulates

@@ -62,5 +62,8 @@ def ctx():
     if capi.device_count() < 1:
         pytest.fail("gpu test selected but no HIP device is visible")
     c = capi.Context(0)
+    # CUSIFT_FORCE_GENERIC=1 pytest -m gpu ...: the whole GPU suite on the generic (any pitch / alignment) kernels
+    if os.environ.get("CUSIFT_FORCE_GENERIC"):
+        c.set_policy(capi.POLICY_GENERIC_KERNELS, 1)
     yield c
     c.close()

@@ -151,9 +151,11 @@ def test_gpu_matcher_signed_descriptors_hit_the_l2_clamp(ctx, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n1,n2", [(3000, 2900), (200, 5000), (5000, 130)])
-def test_gpu_matcher_column_splits_fold_to_the_single_scan(ctx, oracle, monkeypatch, n1, n2):
+def test_gpu_matcher_column_splits_fold_to_the_single_scan(ctx, oracle, n1, n2):
     """The matcher splits image 2's columns over the grid (auto: several splits at these sizes) and folds the splits
     in column order; forced to one split it is the plain scan.  Both must agree with each other and the oracle."""
+    from cusift_amd import capi
+
     rng = np.random.default_rng(n1 + n2)
 
     def rand_pts(n):
@@ -167,12 +169,9 @@ def test_gpu_matcher_column_splits_fold_to_the_single_scan(ctx, oracle, monkeypa
     for distance in (1, 0):
         runs = {}
         for splits in ("auto", "1", "7", "1000"):
-            if splits == "auto":
-                monkeypatch.delenv("CUSIFT_MATCH_SPLITS", raising=False)
-            else:
-                monkeypatch.setenv("CUSIFT_MATCH_SPLITS", splits)
+            ctx.set_policy(capi.POLICY_MATCH_SPLITS, 0 if splits == "auto" else int(splits))
             runs[splits] = gpu_match(ctx, s1, s2, distance)
-        monkeypatch.delenv("CUSIFT_MATCH_SPLITS", raising=False)
+        ctx.set_policy(capi.POLICY_MATCH_SPLITS, 0)
         for k in ("auto", "7", "1000"):
             for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos"):
                 np.testing.assert_array_equal(runs[k][f], runs["1"][f], err_msg="%s splits, %s" % (k, f))

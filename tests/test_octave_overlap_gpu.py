@@ -50,40 +50,36 @@ def same_records(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f], equal_nan=True) for f in FIELDS)
 
 
-def context_with(monkeypatch, overlap, stage_all=None, no_multi=False):
-    """The knobs are read when the context is created."""
-    env = {"CUSIFT_OCTAVE_OVERLAP": str(overlap)}
-    if stage_all is not None:
-        env["CUSIFT_STAGE_ALL"] = str(stage_all)
-    if no_multi:
-        env["CUSIFT_NO_MULTI"] = "1"
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def context_with(overlap, stage_all=None, no_multi=False):
+    """A context with the launch policy forced (cusift_ctx_set_policy)."""
     c = capi.Context(0)
-    for k in env:
-        monkeypatch.delenv(k)
+    c.set_policy(capi.POLICY_SIDE_STREAM, overlap)
+    if stage_all is not None:
+        c.set_policy(capi.POLICY_OCTAVE_LISTS, stage_all)
+    if no_multi:
+        c.set_policy(capi.POLICY_LAUNCH_PER_OCTAVE, 1)
     return c
 
 
 # how the keypoints of a call reach SiftData (cusift_extract_batch): octave 0 on the side stream with a list of its own
 # and the coarser octaves in place; every octave to a list of its own and the coarser octaves searched by one launch
 # (or by a launch each); both
-MODES = {"fork": (2, 0), "lists": (0, 1), "lists, a launch per octave": (0, 1, True), "fork+lists": (2, 1)}
+MODES = {"fork": (3, 0), "lists": (0, 1), "lists, a launch per octave": (0, 1, True), "fork+lists": (3, 1)}
 
 
 @pytest.fixture(params=sorted(MODES))
-def ctx(request, monkeypatch):
+def ctx(request):
     """This module's `ctx`: one of the staged drivers, forced whatever the size of the call."""
-    c = context_with(monkeypatch, *MODES[request.param])
+    c = context_with(*MODES[request.param])
     c.mode = request.param
     yield c
     c.close()
 
 
 @pytest.fixture
-def one_stream(monkeypatch):
+def one_stream():
     """The plain driver: one stream, every keypoint appended in place."""
-    c = context_with(monkeypatch, 0, 0)
+    c = context_with(0, 0)
     yield c
     c.close()
 
@@ -168,7 +164,7 @@ def test_cases_without_a_fork_and_with_other_parameters(ctx, one_stream, kw):
         assert same_records(canonical_order(pts_f[i, : cnt_f[i]]), canonical_order(pts_s[i, : cnt_s[i]]))
 
 
-def test_host_entry_point_and_graph_replay(ctx, one_stream, monkeypatch):
+def test_host_entry_point_and_graph_replay(ctx, one_stream):
     """cusift_extract_host keeps its upload image clear of the staging list; a recorded graph holds the fork and the join."""
     img = images(1, 800, 600)[0]
     prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=2.0, max_pts=8192)
@@ -184,7 +180,7 @@ def test_host_entry_point_and_graph_replay(ctx, one_stream, monkeypatch):
     src = pitched(img)
     h, w = img.shape
     p = src.shape[1]
-    with context_with(monkeypatch, *MODES[ctx.mode]) as c:
+    with context_with(*MODES[ctx.mode]) as c:
         d_img = DeviceBuffer.from_numpy(c, src)
         d_pts = DeviceBuffer(c, prm.max_pts * 588)
         d_cnt = DeviceBuffer(c, 4)
@@ -232,16 +228,34 @@ def test_back_to_back_calls_do_not_race_on_the_staging_list(ctx, one_stream):
 
 
 def test_default_policy(one_stream):
-    """Without the knob: a lone caller's call forks from three 1080p frames' worth of pixels up -- not below, not for a
-    caller that pipelines (concurrent_batches >= 2), not with the stage timers on, not inside a recording."""
+    """A context never forks unless asked to (round 4: the side stream is opt-in, nothing is decided by timing).  Asked
+    (policy 1 = trust the caller, 2 = after the concurrency probe -- which may refuse on a box whose queues are taken):
+    a lone caller's call forks from three 1080p frames' worth of pixels up -- not below, not for a caller that pipelines
+    (concurrent_batches >= 2), not with the stage timers on, not inside a recording."""
     one = images(1, 1920, 1080)
     four = one * 4
     prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=3.0, max_pts=8192)
     with capi.Context(0) as c:
+        assert c.get_policy(capi.POLICY_SIDE_STREAM) == 0
+        run_batch(c, four, prm)
+        assert c.forks() == 0  # the default
+        c.set_policy(capi.POLICY_SIDE_STREAM, 2)
+        cnt_p, pts_p = run_batch(c, four, prm)
+        assert c.forks() in (0, 1)  # the probe decides; either way the records are the same
+        c.set_policy(capi.POLICY_SIDE_STREAM, 0)
+        with pytest.raises(capi.CusiftError):
+            c.set_policy(capi.POLICY_SIDE_STREAM, 7)
+        with pytest.raises(capi.CusiftError):
+            c.set_policy(99, 1)
+    with capi.Context(0) as c:
+        c.set_policy(capi.POLICY_SIDE_STREAM, 1)
         cnt1, pts1 = run_batch(c, one, prm)
         assert c.forks() == 0
         cnt4, pts4 = run_batch(c, four, prm)
         assert c.forks() == 1
+        np.testing.assert_array_equal(cnt4, cnt_p)
+        for i in range(4):
+            assert same_records(canonical_order(pts4[i, : cnt4[i]]), canonical_order(pts_p[i, : cnt_p[i]]))
         piped = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=3.0, max_pts=8192, concurrent_batches=4)
         run_batch(c, four, piped)
         assert c.forks() == 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the LAB build: python -m cusift_amd.build --lab && export CUSIFT_AMD_LIB=$PWD/cusift_amd/libcusift_amd_lab.so (the product library reads no tuning knob)
 # chunk height of detect_fused_kernel: r = coef * sqrt(rows*strips*images), clamped to [2, HI]; timed region (2 streams) + single stream
 for rep in 1 2; do for cfg in ${CFGS:-"0.022 24" "0.045 48" "0.06 64" "0.08 96" "0.1 128" "0.15 192"}; do
   set -- $cfg

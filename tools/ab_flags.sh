@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize
 i=0
 declare -a NAMES
 while IFS= read -r extra; do
-  /opt/rocm/bin/hipcc $FLAGS $extra -o /tmp/libflag$i.so $SRC/sift_capi.hip $SRC/sift_stencils.hip $SRC/sift_keypoints.hip \
+  /opt/rocm/bin/hipcc $FLAGS $extra -o /tmp/libflag$i.so $SRC/sift_context.hip $SRC/sift_stages.hip $SRC/sift_driver.hip $SRC/sift_stencils.hip $SRC/sift_keypoints.hip \
       $SRC/sift_match.hip $SRC/sift_frontend.hip $SRC/sift_homography.hip $SRC/sift_comm.hip 2>/dev/null || { echo "build failed: $extra"; continue; }
   NAMES[$i]="$extra"; i=$((i+1))
 done <<'LIST'

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One extraction on ONE stream (a lone caller: cusift_params.concurrent_batches = 1) with and without the side stream
-for octave 0's detection (CUSIFT_OCTAVE_OVERLAP=0 / default), interleaved on one box: ms per cusift_extract_batch of
+for octave 0's detection (cusift_ctx_set_policy(CUSIFT_POLICY_SIDE_STREAM, 0 / 1)), interleaved on one box: ms per cusift_extract_batch of
 B x 1080p (5 octaves, the benchmark's images), back to back, and the latency of one call.
 
     python tools/probe_octave_overlap.py [reps]
@@ -17,12 +17,8 @@ from cusift_amd import capi, synth  # noqa: E402
 
 
 def make_ctx(mode):
-    if mode is None:
-        os.environ.pop("CUSIFT_OCTAVE_OVERLAP", None)
-    else:
-        os.environ["CUSIFT_OCTAVE_OVERLAP"] = str(mode)
-    c = capi.Context(0)  # the knob is read here
-    os.environ.pop("CUSIFT_OCTAVE_OVERLAP", None)
+    c = capi.Context(0)
+    c.set_policy(capi.POLICY_SIDE_STREAM, mode)
     return c
 
 
@@ -32,7 +28,7 @@ def main():
     p = capi.ialign_up(w, 128)
     base = [np.pad(synth.tile(1000 + i, w, h, 1.0), ((0, 0), (0, p - w))) for i in range(4)]
     prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=3.0, max_pts=32768)
-    ctxs = {"one stream": make_ctx(0), "side stream": make_ctx(None)}
+    ctxs = {"one stream": make_ctx(0), "side stream": make_ctx(1)}
     for B in [int(x) for x in os.environ.get("PROBE_BATCHES", "1,4,16,64").split(",")]:
         imgs = np.stack([base[i % 4] for i in range(B)])
         state = {}

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where does a context's side stream land?  `n` extraction streams (a PipelinedExtractor, as bench.py builds it) are
 used first, then each of its extractors is driven as a lone caller (concurrent_batches = 1, 64 x 1080p): the context
-creates its side stream, probes whether it runs beside its own stream (printed: CUSIFT_SIDE_DEBUG) and forks.
+creates its side stream after the concurrency probe (policy CUSIFT_POLICY_SIDE_STREAM = 2; the probe's timings are
+printed by a -DCUSIFT_LAB build with CUSIFT_SIDE_DEBUG=1) and forks.
 
     GPU_MAX_HW_QUEUES=8 python tools/probe_side_stream.py 4
 
@@ -26,6 +27,7 @@ exs=pipe.extractors
 d=exs[0].images_from_numpy(imgs)
 def lone(ex,n=30):
     ex.params.concurrent_batches=1
+    ex.ctx.set_policy(capi.POLICY_SIDE_STREAM, 2)
     for _ in range(3): ex.extract(d)
     torch.cuda.synchronize(); t0=time.perf_counter()
     for _ in range(n): ex.extract(d)
