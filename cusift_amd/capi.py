@@ -118,6 +118,10 @@ SIGNATURES = {
     "cusift_exchange_halos": (_i, [_vp, _vp, _i, _i, _i, _i, _i]),
     "cusift_ctx_reserve": (_i, [_vp, _i, _i, _i, _PP]),
     "cusift_ctx_reserve_bands": (_i, [_vp, _i, _i]),
+    "cusift_event_create": (_i, [_vp, C.POINTER(_vp)]),
+    "cusift_event_record": (_i, [_vp, _vp]),
+    "cusift_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+    "cusift_event_destroy": (_i, [_vp]),
     "cusift_ctx_set_policy": (_i, [_vp, _i, _i]),
     "cusift_ctx_get_policy": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "cusift_ctx_arena_bytes": (_sz, [_vp]),

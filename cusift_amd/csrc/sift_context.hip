@@ -566,6 +566,50 @@ extern "C" int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value) {
   return fail(CUSIFT_ERR_INVALID, "unknown policy key %d", key);
 }
 
+// ---- events on a context's stream: what TimerGPU (cutils.h:94-114) is made of ----
+struct cusift_event {
+  hipEvent_t ev = nullptr;
+  int device = 0;
+};
+
+extern "C" int cusift_event_create(cusift_ctx *ctx, cusift_event **out) {
+  if (!out) return fail(CUSIFT_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  TRY(enter(ctx));
+  cusift_event *e = new cusift_event();
+  e->device = ctx->device;
+  hipError_t r = hipEventCreate(&e->ev);
+  if (r != hipSuccess) {
+    delete e;
+    return fail(CUSIFT_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(r));
+  }
+  *out = e;
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_event_record(cusift_event *ev, cusift_ctx *ctx) {
+  if (!ev) return fail(CUSIFT_ERR_INVALID, "event is NULL");
+  TRY(enter(ctx));
+  HIP_TRY(hipEventRecord(ev->ev, ctx->stream));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_event_elapsed_ms(cusift_event *start, cusift_event *stop, float *ms) {
+  if (!start || !stop || !ms) return fail(CUSIFT_ERR_INVALID, "event / ms is NULL");
+  HIP_TRY(hipSetDevice(stop->device));
+  HIP_TRY(hipEventSynchronize(stop->ev));
+  HIP_TRY(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return CUSIFT_OK;
+}
+
+extern "C" int cusift_event_destroy(cusift_event *ev) {
+  if (!ev) return CUSIFT_OK;
+  (void)hipSetDevice(ev->device);
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_ctx_timing_enable(cusift_ctx *ctx, int on) {
   TRY(enter(ctx));
   if (!on && ctx->timing) TRY(fold_spans(ctx));

@@ -116,18 +116,33 @@ inline bool deviceInit(int dev) {
 }
 
 // ---- cutils.h:94-140 ------------------------------------------------------------------------------
-// The reference brackets work with cudaEvents on the default stream; every entry point of this shim
-// blocks until its GPU work is done, so wall-clock between construction and read() measures the same span.
+// As in the reference: an event is recorded on the stream at construction, read() records a second one, waits for it and
+// returns the GPU time between the two in milliseconds (cudaEventRecord / cudaEventSynchronize / cudaEventElapsedTime,
+// cutils.h:98-113).  The stream is the drop-in context's: every kernel of this shim runs there, and a `cudaStream_t`
+// of the caller has no meaning on this side (the argument is kept so that `TimerGPU timer(0)` compiles).
 class TimerGPU {
  public:
-  explicit TimerGPU(void * /*stream*/ = nullptr) : t0(std::chrono::steady_clock::now()) {}
+  explicit TimerGPU(void * /*stream*/ = nullptr) {
+    cusift_event_create(cusift_dropin::ctx(), &start);
+    cusift_event_create(cusift_dropin::ctx(), &stop);
+    if (start) cusift_event_record(start, cusift_dropin::ctx());
+  }
+  ~TimerGPU() {
+    cusift_event_destroy(start);
+    cusift_event_destroy(stop);
+  }
+  TimerGPU(const TimerGPU &) = delete;
+  TimerGPU &operator=(const TimerGPU &) = delete;
   float read() {
-    cusift_ctx_synchronize(cusift_dropin::ctx());
-    return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    float ms = 0.0f;
+    if (!start || !stop || cusift_event_record(stop, cusift_dropin::ctx()) != CUSIFT_OK ||
+        cusift_event_elapsed_ms(start, stop, &ms) != CUSIFT_OK)
+      return 0.0f;
+    return ms;
   }
 
  private:
-  std::chrono::steady_clock::time_point t0;
+  cusift_event *start = nullptr, *stop = nullptr;
 };
 
 class TimerCPU {

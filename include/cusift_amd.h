@@ -144,6 +144,13 @@ enum {
 };
 int cusift_ctx_set_policy(cusift_ctx *ctx, int key, int value);
 int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value);
+/* An event on a context's stream: record, then the GPU time between two of them (blocks until `stop` has happened).
+ * What the reference's TimerGPU does with cudaEvents (cutils.h:94-114); include/cuSIFT.h builds TimerGPU on these. */
+typedef struct cusift_event cusift_event;
+int cusift_event_create(cusift_ctx *ctx, cusift_event **out);
+int cusift_event_record(cusift_event *ev, cusift_ctx *ctx);
+int cusift_event_elapsed_ms(cusift_event *start, cusift_event *stop, float *ms);
+int cusift_event_destroy(cusift_event *ev);
 /* Per-stage GPU timing with HIP events on the context's stream (TimerGPU, cutils.h:94-114, used at
  * cuSIFT.cu:64,177,208,238,249).  Stages: 0 ScaleDown, 1 LaplaceMulti, 2 FindPointsMulti,
  * 3 ComputeOrientations, 4 ExtractSiftDescriptors, 5 whole extract call, 6 fused detection, 7 orientation+descriptor of all octaves in one launch.  Accumulates

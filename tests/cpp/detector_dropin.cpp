@@ -45,7 +45,15 @@ int main(int argc, char **argv) {
   siftData->edgeThresh = 10.0f;
   siftData->lowestScale = 0.0f;
   siftData->initSubsampling = 1.0f;
+  TimerCPU wall(0.0f);
+  TimerGPU gpu(0);  // cutils.h:94-114: events on the stream, as the reference brackets its stages (cuSIFT.cu:64)
   siftData->Extract(im.data(), w, h);
+  const float gpu_ms = gpu.read(), wall_ms = wall.read();
+  std::printf("Extract: TimerGPU %.3f ms inside TimerCPU %.3f ms\n", gpu_ms, wall_ms);
+  if (!(gpu_ms > 0.0f && gpu_ms <= wall_ms + 0.05f)) {
+    std::printf("TimerGPU out of range\n");
+    return 3;
+  }
 
   FILE *fp = std::fopen(argv[2], "rb");
   if (!fp) return 2;
