@@ -345,20 +345,31 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     }
   }
   wave_sync();
-  int sbin[2] = {0, 0};            // this lane's samples tx and tx + 64: histogram bin ...
-  float swgt[2] = {0.0f, 0.0f};    // ... and weight (sample tx + 64 exists for tx < 57)
-  // Both samples are computed without a branch between them (lanes 57..63 repeat sample 120; their second weight is
+  int sbin[2] = {0, 0};            // this lane's two samples: histogram bin ...
+  float swgt[2] = {0.0f, 0.0f};    // ... and weight (a second sample exists for tx < 57)
+  // Both samples are computed without a branch between them (lanes 57..63 repeat a sample; their second weight is
   // never posted), so that the two gradient / atan2f / sqrtf chains -- each a long run of dependent operations --
   // interleave instead of running one after the other.
   constexpr int kReps = 2;
   int xd[2], yd[2];
   float dx[2], dy[2];
-#pragma unroll
-  for (int rep = 0; rep < kReps; ++rep) {
-    const int t = min(tx + 64 * rep, 120);
-    yd[rep] = t / 11;
-    xd[rep] = t - yd[rep] * 11;
+  // Which two of the 121 samples a lane computes is free -- only the LIST below is in sample order.  Round 4: the first
+  // 64 lanes' samples are rows 0..7 x columns 0..7 of the window: in the 40-float patch rows those are 8 groups of 8
+  // consecutive banks (40 yd mod 64 = 0, 40, 16, 56, 32, 8, 48, 24) -- every tap read of the first sample is
+  // conflict-free (sample t = lane put row pairs on the same banks: ~2-way conflicts on all of them).  Second samples:
+  // rows 8..10 complete (lanes 0..32), then columns 8..10 of rows 0..7 (lanes 33..56); lanes 57..63 repeat the last one
+  // and post weight 0 at the list's padding slots 121..127.
+  int tidx[2];  // sample index t = 11 yd + xd: where the sample goes in the list
+  yd[0] = tx >> 3;
+  xd[0] = tx & 7;
+  {
+    const int k = tx < 33 ? tx : min(tx, 56) - 33;
+    const int q = tx < 33 ? k / 11 : k / 3;
+    yd[1] = tx < 33 ? 8 + q : q;
+    xd[1] = tx < 33 ? k - 11 * q : 8 + (k - 3 * q);
   }
+  tidx[0] = 11 * yd[0] + xd[0];
+  tidx[1] = tx < 57 ? 11 * yd[1] + xd[1] : 64 + tx;
   bool done = false;
   if constexpr (TEX::kIsPatch) {
     if (lattice) {  // wave-uniform
@@ -411,10 +422,10 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     // The accesses are scalar on purpose: with f2 stores / f4 loads of the same words this compiler selected the wrong
     // vector components (seen in the ISA: one compare used for both samples of a ds_read_b128).
     unsigned int *list = reinterpret_cast<unsigned int *>(S.wmat());  // [128][2]: bin, weight bits
-    list[2 * tx] = (unsigned int)sbin[0];
-    list[2 * tx + 1] = __builtin_bit_cast(unsigned int, swgt[0]);
-    list[128 + 2 * tx] = (unsigned int)sbin[1];
-    list[128 + 2 * tx + 1] = tx < 57 ? __builtin_bit_cast(unsigned int, swgt[1]) : 0u;
+    list[2 * tidx[0]] = (unsigned int)sbin[0];
+    list[2 * tidx[0] + 1] = __builtin_bit_cast(unsigned int, swgt[0]);
+    list[2 * tidx[1]] = (unsigned int)sbin[1];
+    list[2 * tidx[1] + 1] = tx < 57 ? __builtin_bit_cast(unsigned int, swgt[1]) : 0u;
     wave_sync();
     const unsigned int mybin = (unsigned int)(tx & 31);
     const unsigned int *src = list + (tx >> 5) * 128;
@@ -477,7 +488,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
 //            vertical   lane (x, vi) walks the 8 rows 4 vi - 2 .. 4 vi + 5 of column x and adds wy * grad * (1 - frac,
 //                       frac) into a lane-private angle histogram in LDS -- the only data-dependent addressing, 8
 //                       read-modify-writes, conflict-free, one ds_read2st64 + one ds_write2st64 each.
-//            horizontal lane (vi, hi, b mod 4) forms bins b and b + 4 of cell (vi, hi): 8 columns x fixed weights read
+//            horizontal lane (b mod 4, vi, hi) forms bins b and b + 4 of cell (vi, hi): 8 columns x fixed weights read
 //                       with two ds_read_b128 per bin, no data-dependent address, no read-modify-write.
 //            The reference's column-14 quirk (guard `tx <= 14`, :243: the right-hand share of column 14 lands in the
 //            NEXT row's first cell) is one more term, 1/8 of column 14 of the cell row above.  Its angle-index-8 quirk
@@ -505,8 +516,11 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
   return c;
 }
 
-// element of the descriptor that lane l holds first (the second is 4 further): cell l / 4 = (vi, hi), bin l % 4
-__device__ __forceinline__ int desc_elem(int lane) { return 8 * (lane >> 2) + (lane & 3); }
+// element of the descriptor that lane l holds first (the second is 4 further): cell l % 16 = (vi, hi), bin l / 16.
+// (Cells vary fastest so that the 16 lanes the LDS serves together in a ds_read_b128 read 16 different 16-byte groups of
+// one histogram row; with the bins fastest, four lanes at a time read the same positions of four different rows -- the
+// same banks -- and a quarter of this kernel's bank-conflict cycles came from these four reads.)
+__device__ __forceinline__ int desc_elem(int lane) { return 8 * (lane & 15) + (lane >> 4); }
 
 // sqrt and atan2 of the DESCRIPTOR samples: one hardware instruction (1 ulp) instead of the IEEE-exact expansions
 // (~11 instructions each) the orientation stage needs for its bit-identical histogram bins.  atan2: the quotient by
@@ -645,7 +659,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   // ---- phase 2b: horizontal pass ----
   float b0, b1;
   {
-    const int vi = lane >> 4, hi = (lane >> 2) & 3, bq = lane & 3;
+    const int bq = lane >> 4, vi = (lane >> 2) & 3, hi = lane & 3;  // desc_elem(lane) = 8 (4 vi + hi) + bq
     f4 wa, wb;
     window_weights(hi, wa, wb);
     const float w14 = (hi == 0 && vi >= 1) ? 0.125f : 0.0f;

@@ -13,6 +13,9 @@ BENCH_ARGS="--steps 5 --warmup 2 --legs single,two_stage --profile-run $*"
 echo "bench args: $BENCH_ARGS" > "$OUT/command.txt"
 python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/trace.log" 2>&1
+# ONE stream only (timed region and single-stream leg both on one stream): kernel spans do not overlap, so this table's
+# averages are the HIP-event figures of bench.py's stage_ms_per_step (the pass above mixes overlapped and lone launches)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 bench.py --steps 10 --warmup 3 --streams 1 --legs single --profile-run $* > "$OUT/trace_single.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq2.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1

@@ -46,6 +46,16 @@ def main():
             lines.append("%-62s %6s %12.2f %12.2f %12.2f %7s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                                float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
                                                                r["Percentage"][:6]))
+    single = glob.glob(os.path.join(src, "trace_single", "**", "*_kernel_stats.csv"), recursive=True)
+    if single:
+        lines.append("")
+        lines.append("== rocprofv3 --kernel-trace --stats, ONE stream only (python3 bench.py --steps 10 --warmup 3 --streams 1 "
+                     "--legs single --profile-run): no launch overlaps another, the averages are bench.py's HIP-event figures ==")
+        lines.append("%-62s %6s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+        for r in read_csv(single[0]):
+            lines.append("%-62s %6s %12.2f %12.2f %12.2f %7s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                                                               r["Percentage"][:6]))
     # PMC passes
     per_kernel = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [values per dispatch]
     per_dispatch = defaultdict(dict)  # (pass, dispatch) -> info
