@@ -289,7 +289,7 @@ def gather_model(kp_per_rank_step, rec_bytes, step_ms, lag_steps):
                            "at 8 ranks: ~0.1 ms of HBM time)" % (shard * 7 / 1e9))
     out["options"] = {"compact 160-byte wire record (--gather-compact; 8-bit descriptor, lossy)":
                       round(kp_per_rank_step * 160 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3, 4),
-                      "only the 135 floats extraction writes (540 B, exact; not built)":
+                      "trimmed 540-byte wire record (--gather-trimmed; the 135 floats extraction writes, EXACT)":
                       round(kp_per_rank_step * 540 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3, 4),
                       "unit": "exchange ms per step at link peak"}
     return out
@@ -332,6 +332,9 @@ def main():
     ap.add_argument("--gather-compact", action="store_true",
                     help="N > 1: exchange 160-byte compact records (exact header fields, 8-bit descriptor) instead of the "
                          "exact 588-byte SiftPoint records -- NOT the default: the metric is the all-gatherv of SiftData")
+    ap.add_argument("--gather-trimmed", action="store_true",
+                    help="N > 1: exchange 540-byte trimmed records (the 135 floats extraction writes: EXACT, 8 %% fewer "
+                         "bytes per link than the 588-byte SiftPoint) -- not the default either")
     ap.add_argument("--no-self-p2p", action="store_true",
                     help="with --force-gather at one rank: do not route the local shard through ncclSend/ncclRecv to self "
                          "(what remains is what every rank does for ITS OWN shard at any N: clamp, pack into its region, "
@@ -444,7 +447,8 @@ def main():
             side_ctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
             comm = make_comm(side_ctx, self_p2p=(world == 1 and not args.no_self_p2p))
             gatherer = SiftGatherer(comm, B, args.max_pts, region_cap=region_cap, device=dev, n_out=LAG + 2,
-                                    depth=LAG + 1, compact=args.gather_compact)
+                                    depth=LAG + 1, wire_format="compact" if args.gather_compact else (
+                                        "trimmed" if args.gather_trimmed else "exact"))
         except Exception as e:  # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
@@ -594,14 +598,14 @@ def main():
             "keypoints_per_s_in_hbm": round(total_kp / (elapsed / K), 1),
             "keypoints_per_step": total_kp,
         }
-        rec_b = 160 if (args.gather_compact and gatherer is not None) else 588
+        rec_b = gatherer.record_bytes if gatherer is not None else 588
         out["gather_model"] = gather_model(local_kp, rec_b, ms_per_step, LAG if use_dist else E)
         out["gather_model"]["step_of_this_run_includes_an_exchange"] = bool(use_dist)
         if use_dist:
             out["config"]["gather_impl"] = gather_impl
             out["config"]["rccl_library"] = capi.Comm.library()
             out["config"]["gather_region_records"] = region_cap
-            out["config"]["gather_record_bytes"] = 160 if (args.gather_compact and gatherer is not None) else 588
+            out["config"]["gather_record_bytes"] = rec_b
             if gather_waits is not None:
                 out["config"]["gather_host_waits"] = gather_waits[0]
                 out["config"]["gather_host_wait_ms"] = round(gather_waits[1], 3)

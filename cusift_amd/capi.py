@@ -45,6 +45,13 @@ COMPACT_POINT_DTYPE = np.dtype([("coords2D", "<f4", (2,)), ("scale", "<f4"), ("s
 COMPACT_POINT_BYTES = 160
 assert COMPACT_POINT_DTYPE.itemsize == COMPACT_POINT_BYTES
 
+# cusift_trimmed_point: the 135 floats extraction writes, exact (optional 540-byte wire record)
+TRIMMED_POINT_DTYPE = np.dtype([("coords2D", "<f4", (2,)), ("scale", "<f4"), ("sharpness", "<f4"), ("edgeness", "<f4"),
+                                ("orientation", "<f4"), ("subsampling", "<f4"), ("data", "<f4", (128,))])
+TRIMMED_POINT_BYTES = 540
+assert TRIMMED_POINT_DTYPE.itemsize == TRIMMED_POINT_BYTES
+WIRE_FORMATS = {"exact": (0, SIFT_POINT_BYTES), "compact": (1, COMPACT_POINT_BYTES), "trimmed": (2, TRIMMED_POINT_BYTES)}
+
 
 class Params(C.Structure):
     """cusift_params (include/cusift_amd.h); the public parameter fields of SiftData, cuSIFT.h:44-51."""
@@ -162,6 +169,9 @@ SIGNATURES = {
     "cusift_find_homography": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, C.POINTER(_i), _vp, _vp]),
     "cusift_pack_points": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "cusift_pack_points_compact": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "cusift_pack_points_trimmed": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "cusift_expand_trimmed": (_i, [_vp, _vp, _sz, _vp]),
+    "cusift_expand_trimmed_host": (_i, [_vp, _sz, _vp]),
     "cusift_expand_points_host": (_i, [_vp, _sz, _vp]),
     "cusift_sort_points_host": (_i, [_vp, _i]),
     "cusift_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _PP, _vp, _vp]),
@@ -449,6 +459,13 @@ class Context:
                                        d_offsets))
 
     # ---- matcher ----
+    def pack_points_trimmed(self, d_points, d_counters, n_images, max_pts, d_packed, capacity, d_offsets=None):
+        check(lib().cusift_pack_points_trimmed(self.handle, d_points, d_counters, n_images, max_pts, d_packed, capacity,
+                                               d_offsets))
+
+    def expand_trimmed(self, d_trimmed, n, d_points):
+        check(lib().cusift_expand_trimmed(self.handle, d_trimmed, n, d_points))
+
     def pack_points_compact(self, d_points, d_counters, n_images, max_pts, d_packed, capacity, d_offsets=None):
         check(lib().cusift_pack_points_compact(self.handle, d_points, d_counters, n_images, max_pts, d_packed, capacity,
                                                d_offsets))
@@ -553,8 +570,11 @@ class Comm:
     def set_fixed_size(self, on=True):
         check(lib().cusift_comm_set_fixed_size(self._h, 1 if on else 0))
 
-    def set_wire_format(self, compact=True):
-        check(lib().cusift_comm_set_wire_format(self._h, 1 if compact else 0))
+    def set_wire_format(self, fmt=True):
+        """fmt: "exact" / "compact" / "trimmed" (or the number; True / False = compact / exact)."""
+        if isinstance(fmt, str):
+            fmt = WIRE_FORMATS[fmt][0]
+        check(lib().cusift_comm_set_wire_format(self._h, int(fmt)))
 
     def host_waits(self):
         return int(lib().cusift_comm_host_waits(self._h))
@@ -755,6 +775,15 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def expand_trimmed(trimmed):
+    """cusift_expand_trimmed_host: 540-byte trimmed records -> SiftPoint records (exact; unwritten fields zero)."""
+    trimmed = np.ascontiguousarray(trimmed)
+    assert trimmed.dtype == TRIMMED_POINT_DTYPE
+    out = np.zeros(len(trimmed), dtype=SIFT_POINT_DTYPE)
+    check(lib().cusift_expand_trimmed_host(trimmed.ctypes.data, len(trimmed), out.ctypes.data))
+    return out
 
 
 def expand_points(compact):

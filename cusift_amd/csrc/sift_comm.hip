@@ -143,7 +143,8 @@ int load_rccl(Rccl **out) {
 }
 
 static_assert(CUSIFT_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "cusift_comm ids are ncclUniqueId");
-static_assert(sizeof(cusift_point) % 4 == 0 && sizeof(cusift_compact_point) % 4 == 0, "records travel as 32-bit words");
+static_assert(sizeof(cusift_point) % 4 == 0 && sizeof(cusift_compact_point) % 4 == 0 && sizeof(cusift_trimmed_point) % 4 == 0,
+              "records travel as 32-bit words");
 constexpr size_t kWordsPerPoint = sizeof(cusift_point) / 4;  // 147
 constexpr int kSeqWords = 32;  // a ticket's arrival flag sits on a 128-byte line of its own
 
@@ -196,7 +197,7 @@ struct cusift_comm {
   ncclComm_t nccl = nullptr;
   int self_p2p = 0;  // world 1 / tests: route the local shard through ncclSend/ncclRecv to self as well
   int fixed = 0;     // 1: whole regions travel (region_cap records per peer), posted by begin(); no host read at all
-  int compact = 0;   // 1: records travel as cusift_compact_point (160 B) instead of cusift_point (588 B)
+  int compact = 0;   // wire format: 0 cusift_point (588 B), 1 cusift_compact_point (160 B), 2 cusift_trimmed_point (540 B)
   // ring of tickets: [head, head + pending) are in flight, oldest first
   int n_slots = 0, depth = 0, head = 0, pending = 0;
   unsigned int next_seq = 1;
@@ -412,10 +413,11 @@ extern "C" int cusift_comm_set_fixed_size(cusift_comm *c, int on) {
   return CUSIFT_OK;
 }
 
-extern "C" int cusift_comm_set_wire_format(cusift_comm *c, int compact) {
+extern "C" int cusift_comm_set_wire_format(cusift_comm *c, int format) {
   if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
   if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: exchanges in flight");
-  c->compact = compact != 0;
+  if (format < 0 || format > 2) return cusift_fail(CUSIFT_ERR_INVALID, "wire format: 0 exact, 1 compact, 2 trimmed");
+  c->compact = format;
   return CUSIFT_OK;
 }
 
@@ -471,7 +473,8 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
   GatherTicket &k = c->tickets[slot];
   k.stage = c->self_p2p ? (const char *)(c->d_stage + (size_t)slot * c->stage_cap) : nullptr;
   k.seq = c->next_seq++;
-  k.rec_bytes = c->compact ? sizeof(cusift_compact_point) : sizeof(cusift_point);
+  k.rec_bytes = c->compact == 1 ? sizeof(cusift_compact_point)
+                                : (c->compact == 2 ? sizeof(cusift_trimmed_point) : sizeof(cusift_point));
   k.d_gathered = (char *)d_gathered;
   k.region_cap = region_cap;
   k.slots = n_images_max;
@@ -482,8 +485,11 @@ extern "C" int cusift_allgatherv_begin(cusift_comm *c, cusift_ctx *producer, con
   // the caller's d_points / d_counters are free again
   if (n_images > 0) {
     char *dst = c->self_p2p ? const_cast<char *>(k.stage) : k.d_gathered + (size_t)c->rank * region_cap * k.rec_bytes;
-    if (c->compact)
+    if (c->compact == 1)
       TRY(cusift_pack_points_compact(c->ctx, d_points, d_counters, n_images, max_pts, (cusift_compact_point *)dst,
+                                     region_cap, nullptr));
+    else if (c->compact == 2)
+      TRY(cusift_pack_points_trimmed(c->ctx, d_points, d_counters, n_images, max_pts, (cusift_trimmed_point *)dst,
                                      region_cap, nullptr));
     else
       TRY(cusift_pack_points(c->ctx, d_points, d_counters, n_images, max_pts, (cusift_point *)dst, region_cap, nullptr));

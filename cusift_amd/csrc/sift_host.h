@@ -61,6 +61,9 @@ __global__ void gaussian3x3_kernel(float *, int, long, const float *, int, int, 
 __global__ void math_eval_kernel(int, const float *, const float *, float *, float *, long);
 __global__ void pack_points_kernel(const cusift_point *, const unsigned int *, int, int, cusift_point *, unsigned int,
                                    unsigned int *);
+__global__ void pack_points_trimmed_kernel(const cusift_point *, const unsigned int *, int, int, cusift_trimmed_point *,
+                                           unsigned int, unsigned int *);
+__global__ void expand_trimmed_kernel(const cusift_trimmed_point *, size_t, cusift_point *);
 __global__ void pack_points_compact_kernel(const cusift_point *, const unsigned int *, int, int, cusift_compact_point *,
                                            unsigned int, unsigned int *);
 }  // namespace cusift

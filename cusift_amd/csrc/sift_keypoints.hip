@@ -1167,6 +1167,69 @@ __global__ void __launch_bounds__(64) pack_points_kernel(const cusift_point *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Trimmed wire format (round 4): the 135 floats of a record that extraction writes -- its first six floats, subsampling
+// (float 12) and data[128] (floats 16..143) -- as a 540-byte cusift_trimmed_point: EXACT, 8 % fewer bytes over a link
+// than the 588-byte record, whose other 12 floats are whatever the caller's buffer held (cuSIFT.cu:24,29).
+// Same walk as pack_points_kernel; one wave per record.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) pack_points_trimmed_kernel(const cusift_point *__restrict__ points,
+                                                                const unsigned int *__restrict__ counters,
+                                                                int n_images, int max_pts,
+                                                                cusift_trimmed_point *__restrict__ packed,
+                                                                unsigned int capacity,
+                                                                unsigned int *__restrict__ offsets) {
+  __shared__ unsigned int s_prefix[kMaxFlatImages + 1];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n_images; i += 64) {
+    const unsigned int c = counters[i];
+    s_prefix[i + 1] = c < (unsigned int)max_pts ? c : (unsigned int)max_pts;
+  }
+  wave_sync();
+  if (lane == 0) {
+    unsigned int acc = 0;
+    s_prefix[0] = 0;
+    for (int i = 1; i <= n_images; ++i) {
+      acc += s_prefix[i];
+      s_prefix[i] = acc;
+    }
+  }
+  wave_sync();
+  if (blockIdx.x == 0 && offsets)
+    for (int i = lane; i <= n_images; i += 64) offsets[i] = s_prefix[i];
+  const unsigned int total = min(s_prefix[n_images], capacity);
+  constexpr int kData = (int)(offsetof(cusift_point, data) / 4), kSub = (int)(offsetof(cusift_point, subsampling) / 4);
+  for (unsigned int g = blockIdx.x; g < total; g += gridDim.x) {
+    int lo = 0, hi_ = n_images;
+    while (hi_ - lo > 1) {
+      const int mid = (lo + hi_) >> 1;
+      if (s_prefix[mid] <= g) lo = mid; else hi_ = mid;
+    }
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(points + (long)lo * max_pts + (g - s_prefix[lo]));
+    unsigned int *dst = reinterpret_cast<unsigned int *>(packed + g);
+    // trimmed dword e <- record dword: 0..5 as they are, 6 <- subsampling, 7 + k <- data[k]
+    dst[7 + lane] = src[kData + lane];
+    dst[7 + 64 + lane] = src[kData + 64 + lane];
+    if (lane < 7) dst[lane] = src[lane < 6 ? lane : kSub];
+  }
+}
+
+// trimmed records -> full records on the device (the 12 floats extraction never writes are zeroed); one wave per record
+__global__ void __launch_bounds__(64) expand_trimmed_kernel(const cusift_trimmed_point *__restrict__ trimmed, size_t n,
+                                                           cusift_point *__restrict__ points) {
+  const int lane = threadIdx.x;
+  constexpr int kData = (int)(offsetof(cusift_point, data) / 4), kSub = (int)(offsetof(cusift_point, subsampling) / 4);
+  constexpr int kDwords = sizeof(cusift_point) / 4;
+  for (size_t g = blockIdx.x; g < n; g += gridDim.x) {
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(trimmed + g);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(points + g);
+    dst[kData + lane] = src[7 + lane];
+    dst[kData + 64 + lane] = src[7 + 64 + lane];
+    if (lane < kData) dst[lane] = lane < 6 ? src[lane] : (lane == kSub ? src[6] : 0u);
+    if (lane < kDwords - kData - 128) dst[kData + 128 + lane] = 0u;  // coords3D
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Compact wire format of extracted SiftData (new: the reference copies whole 588-byte records, cuSIFT.cu:52-59).
 // Same walk as pack_points_kernel, but a record leaves as a cusift_compact_point (160 B): the seven fields extraction
 // writes, exactly, and the descriptor as 128 bytes with one step per record -- q[i] = min(255, floor(data[i] / step +

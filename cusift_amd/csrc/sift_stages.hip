@@ -756,6 +756,46 @@ extern "C" int cusift_pack_points_compact(cusift_ctx *ctx, const cusift_point *d
   return check_launch("pack_points_compact");
 }
 
+static_assert(sizeof(cusift_trimmed_point) == 540, "the trimmed wire record is 135 floats");
+
+extern "C" int cusift_pack_points_trimmed(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
+                                          int n_images, int max_pts, cusift_trimmed_point *d_packed, size_t capacity,
+                                          unsigned int *d_offsets) {
+  TRY(enter(ctx));
+  if (!d_points || !d_counters || !d_packed) return fail(CUSIFT_ERR_INVALID, "pack (trimmed): missing data");
+  if (n_images < 1 || n_images > kMaxFlatImages || max_pts < 1)
+    return fail(CUSIFT_ERR_INVALID, "pack (trimmed): n_images must be in [1, %d]", kMaxFlatImages);
+  const size_t cap = std::min(capacity, (size_t)0xffffffffu);
+  dim3 grid((unsigned int)std::max<size_t>(1, std::min<size_t>(std::max<size_t>(cap, 1), 256 * 32)));
+  hipLaunchKernelGGL(pack_points_trimmed_kernel, grid, dim3(64), 0, ctx->stream, d_points, d_counters, n_images, max_pts,
+                     d_packed, (unsigned int)cap, d_offsets);
+  return check_launch("pack_points_trimmed");
+}
+
+extern "C" int cusift_expand_trimmed(cusift_ctx *ctx, const cusift_trimmed_point *d_trimmed, size_t n,
+                                     cusift_point *d_points) {
+  TRY(enter(ctx));
+  if (n == 0) return CUSIFT_OK;
+  if (!d_trimmed || !d_points) return fail(CUSIFT_ERR_INVALID, "expand (trimmed): NULL argument");
+  dim3 grid((unsigned int)std::min<size_t>(n, 256 * 32));
+  hipLaunchKernelGGL(expand_trimmed_kernel, grid, dim3(64), 0, ctx->stream, d_trimmed, n, d_points);
+  return check_launch("expand_trimmed");
+}
+
+extern "C" int cusift_expand_trimmed_host(const cusift_trimmed_point *h_trimmed, size_t n, cusift_point *h_points) {
+  if (n == 0) return CUSIFT_OK;
+  if (!h_trimmed || !h_points) return fail(CUSIFT_ERR_INVALID, "expand (trimmed): NULL argument");
+  for (size_t i = 0; i < n; ++i) {
+    const cusift_trimmed_point &t = h_trimmed[i];
+    cusift_point &p = h_points[i];
+    memset(&p, 0, sizeof(p));
+    memcpy(&p.coords2D[0], &t.coords2D[0], 6 * sizeof(float));  // coords2D, scale, sharpness, edgeness, orientation
+    p.subsampling = t.subsampling;
+    memcpy(p.data, t.data, sizeof(p.data));
+  }
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_expand_points_host(const cusift_compact_point *h_compact, size_t n, cusift_point *h_points) {
   if (n == 0) return CUSIFT_OK;
   if (!h_compact || !h_points) return fail(CUSIFT_ERR_INVALID, "expand: NULL argument");

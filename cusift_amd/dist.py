@@ -52,23 +52,25 @@ class SiftGatherer:
     until n_out begins later; rank r's records are gathered[r, :totals[r]] in image order (`regions()` lists them).
     `region_cap` = records one rank's region holds (default: the worst case n_images_max * max_pts).
     `compact=True`: the records travel and arrive as 160-byte cusift_compact_point (capi.COMPACT_POINT_DTYPE; exact
-    header fields, 8-bit descriptor) -- `gathered` is then [world, region_cap, 160].
+    header fields, 8-bit descriptor) -- `gathered` is then [world, region_cap, 160].  `wire_format="trimmed"`: as 540-byte
+    cusift_trimmed_point (the 135 floats extraction writes: exact; capi.TRIMMED_POINT_DTYPE, capi.expand_trimmed).
     The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: begin()
     returns an event recorded behind it -- `producer_stream.wait_event(ev)` (or `producer_ctx.wait(comm.ctx)`) orders
     the producer's next write after the pack without a host wait.  The tensors themselves are kept alive by this object
     until that event has fired."""
 
     def __init__(self, comm, n_images_max, max_pts, region_cap=None, device=None, n_out=2, depth=1, fixed_size=False,
-                 compact=False):
+                 compact=False, wire_format=None):
         self.comm, self.n_max, self.max_pts = comm, int(n_images_max), int(max_pts)
         self.region_cap = int(region_cap) if region_cap else self.n_max * self.max_pts
         self.device = torch.device("cuda", comm.ctx.device) if device is None else torch.device(device)
         self.depth = max(1, int(depth))
         n_out = max(int(n_out), self.depth)
-        self.record_bytes = capi.COMPACT_POINT_BYTES if compact else SIFT_POINT_BYTES
+        self.wire_format = wire_format or ("compact" if compact else "exact")
+        fmt_code, self.record_bytes = capi.WIRE_FORMATS[self.wire_format]
         self.out = [torch.empty((comm.world, self.region_cap, self.record_bytes), dtype=torch.uint8, device=self.device)
                     for _ in range(n_out)]
-        comm.set_wire_format(compact)
+        comm.set_wire_format(fmt_code)
         comm.reserve(self.n_max, self.depth, self.region_cap)
         if fixed_size:
             comm.set_fixed_size(True)

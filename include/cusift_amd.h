@@ -351,6 +351,26 @@ int cusift_pack_points_compact(cusift_ctx *ctx, const cusift_point *d_points, co
                                unsigned int *d_offsets);
 int cusift_expand_points_host(const cusift_compact_point *h_compact, size_t n, cusift_point *h_points);
 
+/* Trimmed wire format (new; optional): the 135 floats of a record that extraction WRITES -- the seven header fields and
+ * the descriptor -- and nothing else: 540 B instead of 588, bit-exact (the other 12 floats of a SiftPoint are whatever
+ * the caller's buffer held, cuSIFT.cu:24,29, so nothing is lost).  8 % fewer bytes per record over PCIe / xGMI.
+ * cusift_pack_points_trimmed: as cusift_pack_points.  cusift_expand_trimmed (device, asynchronous) /
+ * cusift_expand_trimmed_host: trimmed -> SiftPoint records, the 12 unwritten floats zeroed. */
+typedef struct cusift_trimmed_point {
+  float coords2D[2];
+  float scale;
+  float sharpness;
+  float edgeness;
+  float orientation;
+  float subsampling;
+  float data[128];
+} cusift_trimmed_point; /* 540 bytes */
+int cusift_pack_points_trimmed(cusift_ctx *ctx, const cusift_point *d_points, const unsigned int *d_counters,
+                               int n_images, int max_pts, cusift_trimmed_point *d_packed, size_t capacity,
+                               unsigned int *d_offsets);
+int cusift_expand_trimmed(cusift_ctx *ctx, const cusift_trimmed_point *d_trimmed, size_t n, cusift_point *d_points);
+int cusift_expand_trimmed_host(const cusift_trimmed_point *h_trimmed, size_t n, cusift_point *h_points);
+
 /* Canonical order of extracted records, on the HOST copy: octave blocks coarsest first (as emitted), inside an octave
  * by y, x, scale.  The append order inside an octave is that of an atomic counter -- racy in the reference as well
  * (atomicInc, cuSIFT_D.cu:512) -- so callers that need run-to-run identical arrays, not just identical sets, sort. */
@@ -387,11 +407,12 @@ int cusift_comm_reserve(cusift_comm *comm, int n_images_max, int tickets, size_t
  * valid records.  1: whole regions travel (region_cap records per peer whatever the counts), posted by begin(): the
  * exchange needs no host read at all, at the price of the bytes; for small capacities (a tiled image's merge). */
 int cusift_comm_set_fixed_size(cusift_comm *comm, int on);
-/* 0 (default): the gathered records are cusift_point (588 B, exact).  1: they travel -- and arrive -- as
+/* Wire format of the gathered records.  0 (default): cusift_point (588 B, exact).  1: they travel -- and arrive -- as
  * cusift_compact_point (160 B: exact header fields, 8-bit descriptor; see cusift_pack_points_compact): 3.7x fewer bytes
- * over xGMI when the exchange, not the extraction, bounds a step.  d_gathered then holds world * region_cap compact
- * records. */
-int cusift_comm_set_wire_format(cusift_comm *comm, int compact);
+ * over xGMI when the exchange, not the extraction, bounds a step.  2: as cusift_trimmed_point (540 B: the 135 floats
+ * extraction writes, EXACT; cusift_expand_trimmed makes SiftPoint records of them).  d_gathered then holds
+ * world * region_cap records of that format. */
+int cusift_comm_set_wire_format(cusift_comm *comm, int format);
 /* Diagnostic: how many finish() calls found their counts not yet there, i.e. the host was ahead of the GPU (in a
  * GPU-bound pipelined loop that is the normal case and costs nothing: the device has the caller's other steps queued). */
 unsigned long long cusift_comm_host_waits(cusift_comm *comm);

@@ -87,7 +87,19 @@ def test_allgatherv_world1_equals_pack_points(extracted, self_p2p):
     capi.compact_gathered(ctx, gathered.data_ptr(), g2.region_cap, totals, flat.data_ptr(), total)
     side.synchronize()
     assert torch.equal(flat.cpu(), want.cpu())
-    assert comm.host_waits() >= 0
+    assert comm.host_waits() >= 0 and comm.host_wait_ms() >= 0.0
+    # the trimmed wire format: the same records arrive as their 135 written floats (540 B), bit for bit
+    g4 = SiftGatherer(comm, 5, ex.max_pts, region_cap=total + 3, wire_format="trimmed")
+    counts, gathered, totals = g4.gather(pts, cnt, producer=ex.ctx)
+    side.synchronize()
+    assert gathered.shape == (1, total + 3, 540) and int(totals[0]) == total
+    got = capi.expand_trimmed(gathered[0, :total].cpu().numpy().view(capi.TRIMMED_POINT_DTYPE).reshape(-1))
+    ref = want.cpu().numpy().view(capi.SIFT_POINT_DTYPE).reshape(-1)
+    for f in ("coords2D", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"):
+        assert np.ascontiguousarray(got[f]).tobytes() == np.ascontiguousarray(ref[f]).tobytes(), f
+    comm.set_wire_format("exact")
+    with pytest.raises(capi.CusiftError):
+        comm.set_wire_format(5)
     comm.close()
     ctx.close()
 

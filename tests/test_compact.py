@@ -83,3 +83,67 @@ def test_compact_pack_matches_the_formula_and_bounds_the_error(ctx, gray1):
     l2 = np.linalg.norm(err.astype(np.float64), axis=1)
     assert l2.max() < 1e-2 and np.median(l2) < 5e-3
     assert np.isnan(back["data"][5]).all() and not back["data"][6].any()
+
+
+# ---- the trimmed 540-byte record: the 135 floats extraction writes, exact ----
+WRITTEN = ("coords2D", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data")
+UNWRITTEN = ("score", "ambiguity", "match", "match_xpos", "match_ypos", "match_error", "empty", "coords3D")
+
+
+def test_expand_trimmed_host_round_trip():
+    rng = np.random.default_rng(4)
+    t = np.zeros(40, dtype=capi.TRIMMED_POINT_DTYPE)
+    for f in ("coords2D", "scale", "sharpness", "edgeness", "orientation", "data"):
+        t[f] = rng.normal(size=t[f].shape).astype(np.float32)
+    t["subsampling"] = 2.0 ** rng.integers(0, 5, 40)
+    t["data"][3] = np.nan
+    p = capi.expand_trimmed(t)
+    assert p.dtype == SIFT_POINT_DTYPE
+    for f in WRITTEN:
+        assert np.array_equal(p[f], t[f], equal_nan=True), f
+    for f in UNWRITTEN:
+        assert not np.ascontiguousarray(p[f]).view(np.uint8).any(), f
+
+
+@pytest.mark.gpu
+def test_trimmed_pack_and_expand_are_exact(ctx, gray1):
+    prm = capi.default_params(num_octaves=4, init_blur=0.0, peak_thresh=1.0, max_pts=4096)
+    imgs = np.stack([gray1, np.full_like(gray1, 9.0), gray1[::-1].copy()])
+    p = capi.ialign_up(640, 128)
+    d_imgs = capi.DeviceBuffer.from_numpy(ctx, imgs)
+    d_pts = capi.DeviceBuffer(ctx, 3 * prm.max_pts * 588)
+    ctx.memset(d_pts.ptr, 0x5A, d_pts.nbytes)  # the fields extraction does not write hold "whatever the buffer held"
+    d_cnt = capi.DeviceBuffer(ctx, 12)
+    ctx.extract_batch(d_imgs.ptr, 3, 640, 480, p, 480 * p, prm, d_pts.ptr, d_cnt.ptr)
+    ctx.synchronize()
+    cnt = np.minimum(d_cnt.to_numpy(np.uint32, (3,)), prm.max_pts)
+    rec = d_pts.to_numpy(np.uint8, (3 * prm.max_pts, 588)).view(SIFT_POINT_DTYPE).reshape(3, prm.max_pts)
+    flat = np.concatenate([rec[i, : cnt[i]] for i in range(3)])
+    total = int(cnt.sum())
+    assert total > 1000
+    d_out = capi.DeviceBuffer(ctx, (total + 8) * 540)
+    ctx.memset(d_out.ptr, 0xEE, d_out.nbytes)
+    d_off = capi.DeviceBuffer(ctx, 16)
+    ctx.pack_points_trimmed(d_pts.ptr, d_cnt.ptr, 3, prm.max_pts, d_out.ptr, total, d_off.ptr)
+    ctx.synchronize()
+    np.testing.assert_array_equal(d_off.to_numpy(np.uint32, (4,)), [0, cnt[0], cnt[0], total])
+    raw = d_out.to_numpy(np.uint8, (total + 8, 540))
+    assert (raw[total:] == 0xEE).all()  # nothing beyond `capacity`
+    got = raw[:total].copy().view(capi.TRIMMED_POINT_DTYPE).reshape(-1)
+    for f in WRITTEN:  # bit for bit, NaN descriptors included
+        assert np.ascontiguousarray(got[f]).tobytes() == np.ascontiguousarray(flat[f]).tobytes(), f
+    # expansion on the device and on the host: the written fields back in place, the others zero
+    d_back = capi.DeviceBuffer(ctx, (total + 1) * 588)
+    ctx.memset(d_back.ptr, 0x77, d_back.nbytes)
+    ctx.expand_trimmed(d_out.ptr, total, d_back.ptr)
+    ctx.synchronize()
+    back_raw = d_back.to_numpy(np.uint8, (total + 1, 588))
+    assert (back_raw[total] == 0x77).all()
+    back = back_raw[:total].copy().view(SIFT_POINT_DTYPE).reshape(-1)
+    assert back.tobytes() == capi.expand_trimmed(got).tobytes()
+    for f in WRITTEN:
+        assert np.ascontiguousarray(back[f]).tobytes() == np.ascontiguousarray(flat[f]).tobytes(), f
+    for f in UNWRITTEN:
+        assert not np.ascontiguousarray(back[f]).view(np.uint8).any(), f
+    for b in (d_imgs, d_pts, d_cnt, d_out, d_off, d_back):
+        b.free()

@@ -161,6 +161,40 @@ def test_allgatherv_compact_wire_format(ctx, gray1):
             assert res[r][1][src, : len(want)].tobytes() == want.tobytes(), (r, src)
 
 
+def test_allgatherv_trimmed_wire_format(ctx, gray1):
+    """cusift_comm_set_wire_format(comm, 2) at world 3: every rank's records arrive on every rank as 540-byte trimmed
+    records -- the 135 floats extraction writes, bit for bit."""
+    world = 3
+    prm = capi.default_params(num_octaves=3, init_blur=0.0, peak_thresh=1.0, max_pts=2048)
+    imgs = [gray1, gray1[::-1].copy(), np.roll(gray1, (40, 77), axis=(0, 1))]
+    region_cap = prm.max_pts
+
+    def rank_fn(rank, make_comm):
+        c = capi.Context(0)
+        comm = make_comm(c)
+        comm.set_wire_format("trimmed")
+        d_pts = DeviceBuffer(c, prm.max_pts * 588)
+        h = np.zeros(prm.max_pts, dtype=SIFT_POINT_DTYPE)
+        n = c.extract_host(imgs[rank], prm, d_pts.ptr, h)
+        d_cnt = DeviceBuffer.from_numpy(c, np.array([n], np.uint32))
+        out = DeviceBuffer(c, world * region_cap * 540)
+        counts, totals = comm.allgatherv(d_pts.ptr, d_cnt.ptr, 1, prm.max_pts, 1, out.ptr, region_cap)
+        c.synchronize()
+        got = out.to_numpy(np.uint8, (world, region_cap, 540))
+        comm.close()
+        c.close()
+        return h[:n].copy(), got, [int(t) for t in totals]
+
+    res = run_ranks(world, rank_fn)
+    for r in range(world):
+        for src in range(world):
+            want = res[src][0]
+            assert res[r][2][src] == len(want) > 300
+            got = capi.expand_trimmed(res[r][1][src, : len(want)].copy().view(capi.TRIMMED_POINT_DTYPE).reshape(-1))
+            for f in ("coords2D", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"):
+                assert np.ascontiguousarray(got[f]).tobytes() == np.ascontiguousarray(want[f]).tobytes(), (r, src, f)
+
+
 def test_allgatherv_overflow_is_the_same_error_on_every_rank():
     world, max_pts, n_max = 3, 16, 2
     region_cap = 20  # rank 1 will hold 2 x 16 = 32 valid records
