@@ -662,6 +662,31 @@ def main():
                 for k, v in sv.items():
                     setattr(x.params, k, v)
 
+    class leg_guard:
+        """An extra leg never costs the line: an exception inside it is recorded under `leg_errors` and the extractors'
+        parameters are put back to the timed region's."""
+
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, et, ev, tb):
+            if et is None or not issubclass(et, Exception):
+                return False
+            out.setdefault("leg_errors", {})[self.name] = "%s: %s" % (et.__name__, ev)
+            print("bench.py: leg %s failed: %s: %s" % (self.name, et.__name__, ev), file=sys.stderr)
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            for x in exs:
+                x.params.concurrent_batches = 1 if x is ex else E
+                x.params.init_blur = args.init_blur
+                x.params.fused_detect = 0 if args.two_stage else 1
+            return True
+
     if rank == 0 and legs:
         torch.cuda.synchronize()
         if "repeat" in legs and not use_dist:
@@ -851,126 +876,132 @@ def main():
 
         # ---- host-visible leg: SiftData in pinned host memory, copies overlapped with the next step ----
         if "host" in legs:
-            ex.params.concurrent_batches = E
-            out["host_visible_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank, dev,
-                                                       total_local_kp=local_kp)
-            out["keypoints_per_s_host_visible"] = out["host_visible_leg"]["keypoints_per_s"]
-            # the optional 160-byte wire record (exact header fields, 8-bit descriptor with one step per record):
-            # D2H no longer bounds the step; the exact 588-byte path above stays the default
-            out["host_visible_compact_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank,
-                                                               dev, total_local_kp=local_kp, compact=True)
-            out["keypoints_per_s_host_visible_compact"] = out["host_visible_compact_leg"]["keypoints_per_s"]
-            ex.params.concurrent_batches = 1
+            with leg_guard("host"):
+                ex.params.concurrent_batches = E
+                out["host_visible_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank, dev,
+                                                           total_local_kp=local_kp)
+                out["keypoints_per_s_host_visible"] = out["host_visible_leg"]["keypoints_per_s"]
+                # the optional 160-byte wire record (exact header fields, 8-bit descriptor with one step per record):
+                # D2H no longer bounds the step; the exact 588-byte path above stays the default
+                out["host_visible_compact_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank,
+                                                                   dev, total_local_kp=local_kp, compact=True)
+                out["keypoints_per_s_host_visible_compact"] = out["host_visible_compact_leg"]["keypoints_per_s"]
+                ex.params.concurrent_batches = 1
 
         # ---- host-to-host legs: what a caller of the reference's entry point (host image in, host SiftData out) gets ----
         if "host_in" in legs:
-            ex.params.concurrent_batches = E
-            h2h = {}
-            u8_np = np.clip(np.rint(np_imgs), 0, 255).astype(np.uint8)
-            variants = (("u8", torch.from_numpy(u8_np).pin_memory()), ("f32", torch.from_numpy(np_imgs).pin_memory()))
-            for tag, h_src in variants:
-                leg = host_visible_leg(torch, capi, pipe, d_imgs, K if tag == "u8" else max(8, K // 4), B, args.max_pts,
-                                       local_rank, dev, total_local_kp=local_kp, h_src=h_src)
-                # the three things that can bound a step: the upload, the extraction, the read-back -- each as measured
-                # in this run (PCIe rates with the leg's own buffers, each direction ALONE -- in the leg the two directions
-                # run at once and share the host side of the link, so this bound is optimistic; extraction = the timed
-                # region)
-                parts = {"h2d_ms": leg["h2d_bytes_per_step"] / (leg["h2d_alone_GBps"] * 1e9) * 1e3,
-                         "extract_ms": ms_per_step,
-                         "d2h_ms": leg["d2h_bytes_per_step"] / (leg["d2h_alone_GBps"] * 1e9) * 1e3}
-                bound = max(parts.values())
-                leg["bound"] = {k: round(v, 4) for k, v in parts.items()}
-                leg["bound"]["slowest"] = max(parts, key=parts.get)
-                leg["bound"]["frac_of_bound"] = round(bound / leg["ms_per_step"], 4)
-                h2h[tag] = leg
-                del h_src
-            if "u8" in h2h:
-                same = bool(np.array_equal(u8_np.astype(np.float32), np_imgs))
-                h2h["u8"]["images"] = ("the timed images as 8-bit pixels (what a decoded frame holds): " +
-                                       ("the generator rounds to integers, so they ARE the timed images" if same else
-                                        "rounded, so keypoints per step differ slightly from the timed region's"))
-            out["host_to_host"] = h2h
-            out["end_to_end_host_u8_mpix_per_s"] = h2h["u8"]["Mpix_per_s"]
-            out["end_to_end_host_u8_keypoints_per_s"] = h2h["u8"]["keypoints_per_s"]
-            out["end_to_end_host_f32_mpix_per_s"] = h2h["f32"]["Mpix_per_s"]
-            del u8_np, variants
-            ex.params.concurrent_batches = 1
+            with leg_guard("host_in"):
+                ex.params.concurrent_batches = E
+                h2h = {}
+                u8_np = np.clip(np.rint(np_imgs), 0, 255).astype(np.uint8)
+                variants = (("u8", torch.from_numpy(u8_np).pin_memory()), ("f32", torch.from_numpy(np_imgs).pin_memory()))
+                for tag, h_src in variants:
+                    leg = host_visible_leg(torch, capi, pipe, d_imgs, K if tag == "u8" else max(8, K // 4), B, args.max_pts,
+                                           local_rank, dev, total_local_kp=local_kp, h_src=h_src)
+                    # the three things that can bound a step: the upload, the extraction, the read-back -- each as measured
+                    # in this run (PCIe rates with the leg's own buffers, each direction ALONE -- in the leg the two directions
+                    # run at once and share the host side of the link, so this bound is optimistic; extraction = the timed
+                    # region)
+                    parts = {"h2d_ms": leg["h2d_bytes_per_step"] / (leg["h2d_alone_GBps"] * 1e9) * 1e3,
+                             "extract_ms": ms_per_step,
+                             "d2h_ms": leg["d2h_bytes_per_step"] / (leg["d2h_alone_GBps"] * 1e9) * 1e3}
+                    bound = max(parts.values())
+                    leg["bound"] = {k: round(v, 4) for k, v in parts.items()}
+                    leg["bound"]["slowest"] = max(parts, key=parts.get)
+                    leg["bound"]["frac_of_bound"] = round(bound / leg["ms_per_step"], 4)
+                    h2h[tag] = leg
+                    del h_src
+                if "u8" in h2h:
+                    same = bool(np.array_equal(u8_np.astype(np.float32), np_imgs))
+                    h2h["u8"]["images"] = ("the timed images as 8-bit pixels (what a decoded frame holds): " +
+                                           ("the generator rounds to integers, so they ARE the timed images" if same else
+                                            "rounded, so keypoints per step differ slightly from the timed region's"))
+                out["host_to_host"] = h2h
+                out["end_to_end_host_u8_mpix_per_s"] = h2h["u8"]["Mpix_per_s"]
+                out["end_to_end_host_u8_keypoints_per_s"] = h2h["u8"]["keypoints_per_s"]
+                out["end_to_end_host_f32_mpix_per_s"] = h2h["f32"]["Mpix_per_s"]
+                del u8_np, variants
+                ex.params.concurrent_batches = 1
 
         # ---- content legs ----
         if "content" in legs:
-            cl = {}
-            cl["tile_preblurred (the timed workload)"] = content_stats(torch, capi, ex, d_imgs, None, w, h, B, args, K)
-            def pipelined_rate(d, imgs):
-                ex.params.concurrent_batches = E
-                ms = run_pipelined(imgs, max(8, K // 2))
-                ex.params.concurrent_batches = 1
-                d["ms_per_step_pipelined"] = round(ms, 4)
-                d["Mpix_per_s_pipelined"] = round(B * w * h / (ms * 1e-3) / 1e6, 1)
-                d["keypoints_per_s_pipelined"] = round(d["keypoints_per_step"] / (ms * 1e-3), 1)
-                return d["Mpix_per_s_pipelined"]
+            with leg_guard("content"):
+                cl = {}
+                cl["tile_preblurred (the timed workload)"] = content_stats(torch, capi, ex, d_imgs, None, w, h, B, args, K)
+                def pipelined_rate(d, imgs):
+                    ex.params.concurrent_batches = E
+                    ms = run_pipelined(imgs, max(8, K // 2))
+                    ex.params.concurrent_batches = 1
+                    d["ms_per_step_pipelined"] = round(ms, 4)
+                    d["Mpix_per_s_pipelined"] = round(B * w * h / (ms * 1e-3) / 1e6, 1)
+                    d["keypoints_per_s_pipelined"] = round(d["keypoints_per_step"] / (ms * 1e-3), 1)
+                    return d["Mpix_per_s_pipelined"]
 
-            raw = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, 0.0), seeds))
-            name = "tile_raw (SURVEY 8d primary generator as written: no pre-blur; initBlur=%.1f still declared)" % args.init_blur
-            cl[name] = content_stats(torch, capi, ex, raw, run_single_stream, w, h, B, args, max(4, K // 2))
-            out["value_tile_raw_mpix_per_s"] = pipelined_rate(cl[name], raw)
-            del raw
-            blob = ex.images_from_numpy(make_images(lambda s: synth.blobs(s, w, h), seeds))
-            name = "blobs (SURVEY 8d secondary generator)"
-            cl[name] = content_stats(torch, capi, ex, blob, run_single_stream, w, h, B, args, max(4, K // 2))
-            out["value_blobs_mpix_per_s"] = pipelined_rate(cl[name], blob)
-            del blob
-            if stage is not None:
-                cl["tile_preblurred (the timed workload)"].update(
-                    {"ms_per_step_single_stream": out["single_stream_leg"]["ms_per_step"],
-                     "keypoints_per_step": local_kp})
-            out["content_legs"] = cl
+                raw = ex.images_from_numpy(make_images(lambda s: synth.tile(s, w, h, 0.0), seeds))
+                name = "tile_raw (SURVEY 8d primary generator as written: no pre-blur; initBlur=%.1f still declared)" % args.init_blur
+                cl[name] = content_stats(torch, capi, ex, raw, run_single_stream, w, h, B, args, max(4, K // 2))
+                out["value_tile_raw_mpix_per_s"] = pipelined_rate(cl[name], raw)
+                del raw
+                blob = ex.images_from_numpy(make_images(lambda s: synth.blobs(s, w, h), seeds))
+                name = "blobs (SURVEY 8d secondary generator)"
+                cl[name] = content_stats(torch, capi, ex, blob, run_single_stream, w, h, B, args, max(4, K // 2))
+                out["value_blobs_mpix_per_s"] = pipelined_rate(cl[name], blob)
+                del blob
+                if stage is not None:
+                    cl["tile_preblurred (the timed workload)"].update(
+                        {"ms_per_step_single_stream": out["single_stream_leg"]["ms_per_step"],
+                         "keypoints_per_step": local_kp})
+                out["content_legs"] = cl
 
         # ---- initBlur = 0 leg: the timed images with no blur declared (test/detector.cpp:43) ----
         if "initblur0" in legs:
-            saved_blur = ex.params.init_blur
-            ex.params.init_blur = 0.0
-            i_ms, i_st = run_single_stream(ex, d_imgs, max(4, K // 2))
-            i_kp = int(ex.valid_counts().sum().item())
-            raw_cnt = torch.clamp(ex.counts, min=0)
-            ex.params.init_blur = saved_blur
-            ex.params.concurrent_batches = E
-            p_ms = run_pipelined(d_imgs, max(8, K // 2), init_blur=0.0)
-            ex.params.concurrent_batches = 1
-            n_steps = max(4, K // 2)
-            out["initblur0_leg"] = {
-                "workload": "the timed images, initBlur = 0.0 declared: all 8 levels of octave 0 are filtered (no "
-                            "identity pass-through), the detector sees more and finer structure",
-                "ms_per_step_single_stream": round(i_ms, 4), "ms_per_step_pipelined": round(p_ms, 4),
-                "Mpix_per_s_pipelined": round(B * w * h / (p_ms * 1e-3) / 1e6, 1), "keypoints_per_step": i_kp,
-                "keypoints_per_s_pipelined": round(i_kp / (p_ms * 1e-3), 1),
-                "images_saturating_max_pts": int((raw_cnt >= ex.max_pts).sum().item()),
-                "stage_ms_per_step": {k: round(i_st[k][0] / n_steps, 4) for k in ("scale_down", "detect_multi",
-                                                                                  "describe_all")}}
-            out["value_initblur0_mpix_per_s"] = out["initblur0_leg"]["Mpix_per_s_pipelined"]
+            with leg_guard("initblur0"):
+                saved_blur = ex.params.init_blur
+                ex.params.init_blur = 0.0
+                i_ms, i_st = run_single_stream(ex, d_imgs, max(4, K // 2))
+                i_kp = int(ex.valid_counts().sum().item())
+                raw_cnt = torch.clamp(ex.counts, min=0)
+                ex.params.init_blur = saved_blur
+                ex.params.concurrent_batches = E
+                p_ms = run_pipelined(d_imgs, max(8, K // 2), init_blur=0.0)
+                ex.params.concurrent_batches = 1
+                n_steps = max(4, K // 2)
+                out["initblur0_leg"] = {
+                    "workload": "the timed images, initBlur = 0.0 declared: all 8 levels of octave 0 are filtered (no "
+                                "identity pass-through), the detector sees more and finer structure",
+                    "ms_per_step_single_stream": round(i_ms, 4), "ms_per_step_pipelined": round(p_ms, 4),
+                    "Mpix_per_s_pipelined": round(B * w * h / (p_ms * 1e-3) / 1e6, 1), "keypoints_per_step": i_kp,
+                    "keypoints_per_s_pipelined": round(i_kp / (p_ms * 1e-3), 1),
+                    "images_saturating_max_pts": int((raw_cnt >= ex.max_pts).sum().item()),
+                    "stage_ms_per_step": {k: round(i_st[k][0] / n_steps, 4) for k in ("scale_down", "detect_multi",
+                                                                                      "describe_all")}}
+                out["value_initblur0_mpix_per_s"] = out["initblur0_leg"]["Mpix_per_s_pipelined"]
 
         # ---- ragged-width leg ----
         if "ragged" in legs:
-            rw, rh = 1366, 768
-            rex = BatchExtractor(B, rw, rh, **prm_kw)
-            rimgs = rex.images_from_numpy(make_images(lambda s: synth.tile(s, rw, rh, args.init_blur), seeds))
-            r_ms, r_st = run_single_stream(rex, rimgs, max(4, K // 2))
-            rate = B * rw * rh / (r_ms * 1e-3) / 1e6
-            leg = {"workload": "%d x %dx%d (octave widths 1366, 683, 341, 170, 85: none a multiple of 4)" % (B, rw, rh),
-                   "ms_per_step_single_stream": round(r_ms, 4), "Mpix_per_s_single_stream": round(rate, 1),
-                   "stage_ms_per_step": {k: round(r_st[k][0] / max(4, K // 2), 4)
-                                         for k in ("scale_down", "detect_multi", "describe_all")},
-                   "detect_launches_fused": r_st["detect_multi"][1], "laplace_launches": r_st["laplace_multi"][1],
-                   "keypoints_per_step": int(rex.valid_counts().sum().item())}
-            if "single_stream_leg" in out:
-                base = B * w * h / (out["single_stream_leg"]["ms_per_step"] * 1e-3) / 1e6
-                leg["per_pixel_rate_vs_1080p"] = round(rate / base, 3)
-            out["ragged_width_leg"] = leg
-            rex.close()
-            del rimgs
+            with leg_guard("ragged"):
+                rw, rh = 1366, 768
+                rex = BatchExtractor(B, rw, rh, **prm_kw)
+                rimgs = rex.images_from_numpy(make_images(lambda s: synth.tile(s, rw, rh, args.init_blur), seeds))
+                r_ms, r_st = run_single_stream(rex, rimgs, max(4, K // 2))
+                rate = B * rw * rh / (r_ms * 1e-3) / 1e6
+                leg = {"workload": "%d x %dx%d (octave widths 1366, 683, 341, 170, 85: none a multiple of 4)" % (B, rw, rh),
+                       "ms_per_step_single_stream": round(r_ms, 4), "Mpix_per_s_single_stream": round(rate, 1),
+                       "stage_ms_per_step": {k: round(r_st[k][0] / max(4, K // 2), 4)
+                                             for k in ("scale_down", "detect_multi", "describe_all")},
+                       "detect_launches_fused": r_st["detect_multi"][1], "laplace_launches": r_st["laplace_multi"][1],
+                       "keypoints_per_step": int(rex.valid_counts().sum().item())}
+                if "single_stream_leg" in out:
+                    base = B * w * h / (out["single_stream_leg"]["ms_per_step"] * 1e-3) / 1e6
+                    leg["per_pixel_rate_vs_1080p"] = round(rate / base, 3)
+                out["ragged_width_leg"] = leg
+                rex.close()
+                del rimgs
 
         # ---- matcher leg (the first caller after the path): fp32 MFMA bound ----
         if "match" in legs:
-            out["match_leg"] = match_leg(capi, ex.ctx, 16384)
+            with leg_guard("match"):
+                out["match_leg"] = match_leg(capi, ex.ctx, 16384)
 
         # the headline is ONE content; the number to carry is the range over the survey's generators
         rates = {"tile_preblurred (timed region)": out["value"]}
@@ -983,9 +1014,10 @@ def main():
             out["value_by_content_mpix_per_s"] = rates
 
         if "cpu" in legs:
-            out["cpu_baseline"] = cpu_baseline(w, h, dict(prm_kw), args.init_blur, args.cpu_seconds)
-            if world > 1:
-                out["cpu_baseline"]["note"] = "timed on rank 0's host share after the timed region (other ranks idle)"
+            with leg_guard("cpu"):
+                out["cpu_baseline"] = cpu_baseline(w, h, dict(prm_kw), args.init_blur, args.cpu_seconds)
+                if world > 1:
+                    out["cpu_baseline"]["note"] = "timed on rank 0's host share after the timed region (other ranks idle)"
 
     if world > 1:
         dist.barrier()  # the other ranks wait here while rank 0 runs its legs: communicators are torn down together

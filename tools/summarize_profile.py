@@ -56,6 +56,29 @@ def main():
             lines.append("%-62s %6s %12.2f %12.2f %12.2f %7s" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                                float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
                                                                r["Percentage"][:6]))
+        # the HIP-event figures bench.py measured in that same (profiled) process, beside the trace's averages
+        try:
+            line = [l for l in open(os.path.join(src, "trace_single.log")) if l.startswith("{") and '"metric"' in l][-1]
+            b = json.loads(line)
+            st = b["stage_ms_per_step"]
+            by = defaultdict(list)
+            for r in read_csv(single[0]):
+                by[short(r["Name"])].append((int(r["Calls"]), float(r["AverageNs"]) / 1e3))
+            lines.append("bench.py's HIP-event stage table in the same process (per step, `single` leg: one launch per octave, "
+                         "stage timers on): scale_down %.1f us, detect %.1f us, describe_all %.1f us"
+                         % (st["scale_down"] * 1e3, st["detect_multi"] * 1e3, st["describe_all"] * 1e3))
+            da = by.get("describe_all_kernel")
+            if da:
+                lines.append("  describe_all_kernel: trace average %.1f us per launch (HIP events bracket the launch: + dispatch)"
+                             % (sum(c * a for c, a in da) / sum(c for c, a in da)))
+            df = by.get("detect_fused_kernel")
+            if df and len(df) >= 2:
+                big = max(df, key=lambda t: t[1])
+                small = min(df, key=lambda t: t[1])
+                lines.append("  detect_fused_kernel: octave 0 %.1f us + 4 coarser octaves x %.1f us = %.1f us per step in the trace "
+                             "(the stage table adds five dispatches)" % (big[1], small[1], big[1] + 4 * small[1]))
+        except Exception as e:  # noqa: BLE001
+            lines.append("(no bench line found in trace_single.log: %s)" % e)
     # PMC passes
     per_kernel = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [values per dispatch]
     per_dispatch = defaultdict(dict)  # (pass, dispatch) -> info
