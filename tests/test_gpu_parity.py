@@ -437,6 +437,50 @@ def test_descriptors_match_oracle(ctx, oracle, gray1, frac_bits):
     np.testing.assert_array_equal(pts["data"][n:], got["data"][n:])
 
 
+@pytest.mark.parametrize("frac_bits", [0, 8])
+def test_hip_descriptors_vs_float64_anchor(ctx, oracle, gray1, frac_bits):
+    """The HIP descriptors against the INDEPENDENT float64 evaluation of cuSIFT_D.cu:184-297 (tests/test_float64_anchor.py:
+    numpy, written from the reference source, sharing nothing with the oracle or the kernels) -- with the bars the
+    oracle itself is held to there.  Since round 4 the kernel no longer follows the oracle's summation order and takes
+    sqrt / quotient / rsqrt from single instructions: this test says the result is as close to the algorithm's exact
+    value as the oracle's is, not merely close to the oracle."""
+    from test_float64_anchor import descriptors_f64
+
+    w, h = 640, 480
+    src = pitched(gray1)
+    dog = oracle.laplace_multi(src, w, h, 0.0)
+    pts, n = oracle.find_points_multi(dog, w, h, 0.5, 10.0, 1.0, 16384)
+    assert n > 1500
+    oracle.compute_orientations(src, w, h, pts, 0, n, frac_bits)
+    before = pts[:n].copy()
+    fin = np.isfinite(before["orientation"])
+    d_img = DeviceBuffer.from_numpy(ctx, src)
+    d_pts = DeviceBuffer.from_numpy(ctx, pts)
+    d_cnt = DeviceBuffer.from_numpy(ctx, np.array([n], dtype=np.uint32))
+    ctx.extract_descriptors(d_img.ptr, w, h, src.shape[1], d_pts.ptr, len(pts), None, d_cnt.ptr, 1.0, frac_bits)
+    got = d_pts.to_numpy(SIFT_POINT_DTYPE, (len(pts),))["data"][:n].astype(np.float64)
+    for b in (d_img, d_pts, d_cnt):
+        b.free()
+    want, at_pi = descriptors_f64(gray1, before["coords2D"][:, 0].astype(np.float64),
+                                  before["coords2D"][:, 1].astype(np.float64), before["scale"].astype(np.float64),
+                                  before["orientation"].astype(np.float64), frac_bits, want_flags=True)
+    ok = fin & np.isfinite(want).all(axis=1)
+    assert ok.mean() > 0.999
+    l2 = np.linalg.norm(got - want, axis=1)
+    smooth = ok & ~at_pi
+    assert smooth.mean() > 0.5
+    if frac_bits == 0:
+        assert np.median(l2[smooth]) < 3e-5 and l2[smooth].max() < 3e-4, (np.median(l2[smooth]), l2[smooth].max())
+    else:
+        assert np.median(l2[smooth]) < 5e-4 and l2[smooth].max() < 3e-2, (np.median(l2[smooth]), l2[smooth].max())
+    assert l2[ok].max() < 0.2
+    # and the oracle is no closer to the float64 value than the kernel is (same keypoints, same bars)
+    ref = pts.copy()
+    oracle.extract_descriptors(src, w, h, ref, 0, n, 1.0, frac_bits)
+    l2_oracle = np.linalg.norm(ref["data"][:n].astype(np.float64) - want, axis=1)
+    assert np.median(l2[smooth]) < 1.05 * np.median(l2_oracle[smooth]) + 1e-7
+
+
 def test_descriptor_quirk_paths(ctx, oracle):
     """Hand-placed keypoints that force the reference's index-overflow paths:
     rows identical + orientation 0 -> dy == +0 exactly, dx < 0 on falling ramps -> atan2f == +pi ->
