@@ -911,6 +911,41 @@ def main():
                     leg["bound"]["frac_of_bound"] = round(bound / leg["ms_per_step"], 4)
                     h2h[tag] = leg
                     del h_src
+                # the same pipeline through the C ABI alone (cusift_pipe_*: what a C / C++ caller links against -- no
+                # torch stream, event or tensor anywhere in it); the frames are the pinned u8 batch above
+                try:
+                    torch.cuda.synchronize()
+                    depth_c = 4
+                    cpipe = capi.Pipe(local_rank, B, w, h, capi.default_params(**prm_kw), capi.PIPE_U8, depth=depth_c,
+                                      records_capacity=int(max(1.5 * local_kp, 4096)))
+                    frames_c = variants[0][1].numpy()  # a view of the pinned tensor
+                    n_c = max(8, K // 2)
+
+                    def run_c(steps):
+                        got = 0
+                        for _ in range(steps):
+                            if cpipe.in_flight() == depth_c:
+                                got += len(cpipe.collect()[0])
+                            cpipe.submit(frames_c)
+                        while cpipe.in_flight():
+                            got += len(cpipe.collect()[0])
+                        return got
+
+                    run_c(depth_c)
+                    t1 = time.perf_counter()
+                    got_c = run_c(n_c)
+                    dt_c = time.perf_counter() - t1
+                    cpipe.close()
+                    h2h["u8_c_abi"] = {
+                        "ms_per_step": round(dt_c / n_c * 1e3, 4), "Mpix_per_s": round(B * w * h / (dt_c / n_c) / 1e6, 1),
+                        "keypoints_per_s": round(got_c / dt_c, 1), "batches_in_flight": depth_c,
+                        "note": "cusift_pipe_create / _submit / _collect (cusift_amd/csrc/sift_pipe.hip): the same upload -> "
+                                "8-bit to float -> extraction -> pack -> read-back pipeline inside the library, driven by one "
+                                "host thread through the C ABI; pinned 8-bit frames in, SiftData in the pipeline's pinned "
+                                "slots out"}
+                    out["end_to_end_host_u8_c_abi_mpix_per_s"] = h2h["u8_c_abi"]["Mpix_per_s"]
+                except Exception as e:  # noqa: BLE001
+                    h2h["u8_c_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 if "u8" in h2h:
                     same = bool(np.array_equal(u8_np.astype(np.float32), np_imgs))
                     h2h["u8"]["images"] = ("the timed images as 8-bit pixels (what a decoded frame holds): " +

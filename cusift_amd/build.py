@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcusift_amd.so")
 SOURCES = ["sift_context.hip", "sift_stages.hip", "sift_driver.hip", "sift_stencils.hip", "sift_keypoints.hip", "sift_match.hip",
-           "sift_frontend.hip", "sift_homography.hip", "sift_comm.hip", "sift_tiled.hip"]
+           "sift_frontend.hip", "sift_homography.hip", "sift_comm.hip", "sift_tiled.hip", "sift_pipe.hip"]
 HEADERS = [os.path.join(CSRC, "detect_chunk.inc"), os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"), os.path.join(CSRC, "sift_internal.h"), os.path.join(CSRC, "sift_host.h"),
            os.path.join(HERE, "..", "include", "cusift_amd.h")]
 

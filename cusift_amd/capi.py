@@ -129,6 +129,11 @@ SIGNATURES = {
     "cusift_event_record": (_i, [_vp, _vp]),
     "cusift_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "cusift_event_destroy": (_i, [_vp]),
+    "cusift_pipe_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _PP, _i, _i, _sz]),
+    "cusift_pipe_submit": (_i, [_vp, _vp, _i]),
+    "cusift_pipe_collect": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(_sz)]),
+    "cusift_pipe_in_flight": (_i, [_vp]),
+    "cusift_pipe_destroy": (_i, [_vp]),
     "cusift_ctx_set_policy": (_i, [_vp, _i, _i]),
     "cusift_ctx_get_policy": (_i, [_vp, _i, C.POINTER(C.c_int)]),
     "cusift_ctx_arena_bytes": (_sz, [_vp]),
@@ -773,6 +778,58 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+PIPE_U8, PIPE_F32 = 0, 1
+
+
+class Pipe:
+    """cusift_pipe: host frames in, SiftData in pinned host memory out, `depth` batches in flight (C ABI; no torch)."""
+
+    def __init__(self, device, n_images, w, h, params, input_format=PIPE_U8, depth=3, records_capacity=0):
+        self._h = C.c_void_p()
+        self.n_images, self.w, self.h, self.format = n_images, w, h, input_format
+        check(lib().cusift_pipe_create(C.byref(self._h), device, n_images, w, h, C.byref(params), input_format, depth,
+                                       records_capacity))
+
+    def submit(self, frames):
+        """frames: C-contiguous [n, h, w] uint8 / float32 array (or anything with ctypes.data and the same layout,
+        e.g. a pinned torch tensor's numpy view).  It must stay alive and untouched until collected."""
+        a = frames
+        want = np.uint8 if self.format == PIPE_U8 else np.float32
+        assert a.dtype == want and a.ndim == 3 and a.shape[1:] == (self.h, self.w) and a.flags["C_CONTIGUOUS"], a.shape
+        check(lib().cusift_pipe_submit(self._h, a.ctypes.data, int(a.shape[0])))
+
+    def collect(self):
+        """-> (records: SIFT_POINT_DTYPE view of the pinned slot, offsets [n + 1]); valid until `depth` more submits."""
+        rec, off = C.c_void_p(), C.c_void_p()
+        n, total = C.c_int(0), C.c_size_t(0)
+        check(lib().cusift_pipe_collect(self._h, C.byref(rec), C.byref(off), C.byref(n), C.byref(total)))
+        offsets = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint32)), shape=(n.value + 1,))
+        if total.value == 0:
+            return np.zeros(0, dtype=SIFT_POINT_DTYPE), offsets
+        raw = np.ctypeslib.as_array(C.cast(rec, C.POINTER(C.c_uint8)), shape=(total.value * SIFT_POINT_BYTES,))
+        return raw.view(SIFT_POINT_DTYPE), offsets
+
+    def in_flight(self):
+        return int(lib().cusift_pipe_in_flight(self._h))
+
+    def close(self):
+        if self._h:
+            lib().cusift_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

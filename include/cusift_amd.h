@@ -462,6 +462,33 @@ int cusift_exchange_rows(cusift_comm *comm, float *d_band, int pitch, int band_r
 int cusift_exchange_halos(cusift_comm *comm, float *d_band, int pitch, int top_halo, int own_rows, int bottom_halo,
                           int send_rows);
 
+/* ---- host to host: frames in host memory in, SiftData in pinned host memory out ----------------------------------
+ * The reference's entry point takes a HOST image and leaves SiftData on the host, one image at a time, every step
+ * blocking (SiftData::Extract + Synchronize, cuSIFT.cu:61-120,52-59).  At this build's rates a caller is bound by PCIe,
+ * and gets what the link gives only if upload, extraction and read-back of consecutive batches overlap: this object
+ * is that pipeline for a C / C++ caller (no HIP, no Python): `depth` batches in flight, batches rotating over up to
+ * three extraction streams, an upload stream, a pack stream and a copy stream; the 8-bit form converts on the device
+ * (cusift_u8_to_f32; main.cpp:300-318 converts on the host and uploads 4x the bytes).
+ *   create   n_images = the largest batch; frames are dense rows of w pixels, unsigned char (CUSIFT_PIPE_U8) or float
+ *            (CUSIFT_PIPE_F32, values 0..255 as the reference expects); depth 2..8; records_capacity = records one
+ *            batch's SiftData may hold (0: n_images * max_pts -- generous: pinned memory per slot).
+ *   submit   asynchronous: enqueues one batch ([n_images][h][w], pinned memory recommended -- pageable memory makes
+ *            the upload synchronous); fails if `depth` batches are in flight already.  The frames must stay untouched
+ *            until the batch has been collected.
+ *   collect  the OLDEST batch in flight: blocks until its records are on the host; *h_records = its `*total` valid
+ *            records back to back in image order (SiftPoint layout), h_offsets[0 .. n] = their exclusive prefix sums
+ *            per image (image i: records [h_offsets[i], h_offsets[i + 1])).  The pointers stay valid until `depth`
+ *            further batches have been submitted.  More records than the capacity: CUSIFT_ERR_NOMEM. */
+typedef struct cusift_pipe cusift_pipe;
+enum { CUSIFT_PIPE_U8 = 0, CUSIFT_PIPE_F32 = 1 };
+int cusift_pipe_create(cusift_pipe **out, int device, int n_images, int w, int h, const cusift_params *prm,
+                       int input_format, int depth, size_t records_capacity);
+int cusift_pipe_submit(cusift_pipe *pipe, const void *h_frames, int n_images);
+int cusift_pipe_collect(cusift_pipe *pipe, const cusift_point **h_records, const unsigned int **h_offsets, int *n_images,
+                        size_t *total);
+int cusift_pipe_in_flight(cusift_pipe *pipe);
+int cusift_pipe_destroy(cusift_pipe *pipe);
+
 /* ---- one large image strip-tiled over the ranks (BASELINE configs[4]) -------------------------------------------
  * The rank-side driver of the tiling: plan, bands, per-octave ScaleDown -> halo exchange -> band detection and
  * description, coarse-octave collapse onto rank 0, footprint check.  Mirrors the octave loop of cuSIFT.cu:175-202 (the

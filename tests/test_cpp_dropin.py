@@ -1,6 +1,7 @@
 """The C++ drop-in surface (include/cuSIFT.h): a re-write of the reference's own detector test
 (test/detector.cpp:18-90) plus the legacy ExtractSift trio, compiled with plain g++."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -13,17 +14,18 @@ BIN_HOMO = os.path.join(CPP, "homography_dropin")
 BIN_MULTI = os.path.join(CPP, "multigpu_dropin")
 BIN_PIPE = os.path.join(CPP, "pipeline_dropin")
 BIN_TILED = os.path.join(CPP, "tiled_dropin")
+BIN_HOSTPIPE = os.path.join(CPP, "hostpipe_dropin")
 
 
 def build():
     subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
     assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO) and os.path.exists(BIN_MULTI)
-    assert os.path.exists(BIN_PIPE) and os.path.exists(BIN_TILED)
+    assert os.path.exists(BIN_PIPE) and os.path.exists(BIN_TILED) and os.path.exists(BIN_HOSTPIPE)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED):
+    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED, BIN_HOSTPIPE):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -113,6 +115,18 @@ def test_dropin_pipeline_program_runs_on_gpu():
         assert m, out.stdout
         counts.append(int(m.group(4)))
     assert counts[0] == counts[1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [2, 4])
+def test_dropin_hostpipe_program_equals_blocking_extraction(depth):
+    """cusift_pipe_* from plain C++: 8-bit frames in pinned host memory in, SiftData on the host out, `depth` batches in
+    flight -- every image's keypoints equal those of the blocking cusift_extract_host on that frame alone."""
+    build()
+    out = subprocess.run([BIN_HOSTPIPE, os.path.join(ROOT, "tests", "golden", "gray1.pgm"), "7", "5", str(depth)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert re.search(r"hostpipe: 7 batches of 5 images 640x480, depth %d: .* all equal" % depth, out.stdout), out.stdout
 
 
 @pytest.mark.gpu
