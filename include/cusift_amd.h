@@ -8,6 +8,24 @@
  * (SiftPoint / SiftData / cuImage / ExtractSift ...) on top of exactly these functions; Python binds
  * them with ctypes (cusift_amd/capi.py).  See INTEGRATION.md.
  *
+ * Map of this header (107 entry points; the path's own boundary is the first group):
+ *   THE DROP-IN CORE, what include/cuSIFT.h is built on (22): cusift_init / _device_count / _last_error / _version,
+ *     cusift_ctx_create / _create_borrowed / _destroy / _synchronize / _stream / _device / _reserve, cusift_malloc /
+ *     _free / _malloc_host / _free_host / _memcpy_h2d / _memcpy_d2h / _image_h2d / _image_d2h, cusift_default_params,
+ *     cusift_extract / _extract_host / _extract_batch, cusift_scale_down, cusift_rootsift.
+ *   STAGE ENTRY POINTS, one per kernel of the reference, for callers that drive the stages themselves and for the parity
+ *     tests (15): cusift_scale_down_levels / _laplace_multi / _laplace_taps / _find_points_multi / _detect_multi /
+ *     _compute_orientations / _extract_descriptors / _math_eval / _kernel_occupancy; band forms of the strip tiling:
+ *     _scale_down_band / _detect_band / _describe_band / _extract_bands; front-end: _image_u8_h2d / _u8_to_f32 / _gaussian3x3.
+ *   CONTEXT SERVICES (14): _ctx_wait, _ctx_reserve_bands, _ctx_arena_bytes, _ctx_forks, _ctx_set_policy / _get_policy,
+ *     _ctx_timing_enable / _read / _reset, cusift_event_*, cusift_graph_* (replay of one launch sequence).
+ *   HOST-TO-HOST PIPELINE (5): cusift_pipe_*.
+ *   SIFTDATA ON THE WIRE AND AT REST (10): cusift_pack_points (+ _compact, _trimmed), cusift_expand_* , _sort_points_host,
+ *     _memset, _memcpy_d2d, _memcpy2d_d2h.
+ *   MORE THAN ONE GPU (37): cusift_comm_* (communicator over RCCL, bound at run time), cusift_allgatherv_* /
+ *     _compact_gathered, cusift_exchange_halos / _rows, cusift_tiled_* (one large image over the ranks).
+ *   NEXT ROWS OF SURVEY 8f (2): cusift_match, cusift_find_homography.
+ *
  * Conventions
  *  - every function returns CUSIFT_OK (0) or a negative cusift_status; cusift_last_error() gives text.
  *    (The reference prints and exit(-1)s, cutils.h:24-48; the C++ shim keeps that behaviour.)
