@@ -408,6 +408,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     sbin[rep] = bin;
     swgt[rep] = grad * S.gauss[xd[rep]] * S.gauss[yd[rep]];
   }
+  float hist_half;  // this lane's (half, bin) sum
   {
     // Histogram without LDS atomics.  Bins are lanes (tx & 31); the lower half-wave sums samples 0..63 in index order,
     // the upper half-wave samples 64..120, then hist = lower + upper -- the oracle accumulates in exactly this order (the
@@ -436,37 +437,36 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
       acc += (b0 == mybin) ? __builtin_bit_cast(float, w0) : 0.0f;
       acc += (b1 == mybin) ? __builtin_bit_cast(float, w1) : 0.0f;
     }
-    wave_sync();
-    if (tx >= 32) S.hist[tx] = acc;  // hist[32 + b]: scratch until the smoothing pass overwrites it
-    wave_sync();
-    if (tx < 32) S.hist[tx] = acc + S.hist[tx + 32];
+    wave_sync();  // the list has been read: the caller may reuse the storage
+    hist_half = acc;
   }
-  wave_sync();
-  const int x1m = (tx >= 1 ? tx - 1 : tx + 31);
-  const int x1p = (tx <= 30 ? tx + 1 : tx - 31);
-  if (tx < 32) {
-    const int x2m = (tx >= 2 ? tx - 2 : tx + 30);
-    const int x2p = (tx <= 29 ? tx + 2 : tx - 30);
-    S.hist[tx + 32] = 6.0f * S.hist[tx] + 4.0f * (S.hist[x1m] + S.hist[x1p]) + (S.hist[x2m] + S.hist[x2p]);
-  }
-  wave_sync();
-  float pk = 0.0f;
-  if (tx < 32) {
-    const float v = S.hist[32 + tx];
-    pk = (v > S.hist[32 + x1m] && v >= S.hist[32 + x1p]) ? v : 0.0f;
-  }
+  // Round 4: from here on the histogram lives in registers -- no LDS round trip.  (A lone wave issues one vector
+  // instruction per ~8 cycles and an LDS round trip costs a wave ~120: the five dependent round trips this tail used to
+  // make -- combine the halves, smooth, find the peaks, fetch the peak's neighbours -- were worth ~75 instructions.)
+  // hist[b] = lower half's sum + upper half's, in that order (the oracle's), for b = lane % 32 in BOTH halves of the
+  // wave: the swap leaves (lower, lower) in `lo` and (upper, upper) in `hi`.
+  float lo = hist_half, hi = hist_half;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+  const float h0 = lo + hi;
+  // With the 32 bins replicated in both halves, a rotation of the whole wave by one lane IS the circular neighbour
+  // over the 32 bins: lane 0 receives lane 63 = bin 31, lane 32 receives lane 31 = bin 31.
+  const float h_m1 = dpp_perm<0x13C>(h0), h_p1 = dpp_perm<0x134>(h0);  // wave_ror:1: lane i <- i - 1; wave_rol:1: i <- i + 1
+  const float h_m2 = dpp_perm<0x13C>(h_m1), h_p2 = dpp_perm<0x134>(h_p1);
+  const float sm = 6.0f * h0 + 4.0f * (h_m1 + h_p1) + (h_m2 + h_p2);  // cuSIFT_D.cu:357-361, the oracle's order
+  const float sm_m1 = dpp_perm<0x13C>(sm), sm_p1 = dpp_perm<0x134>(sm);
+  const float pk = (sm > sm_m1 && sm >= sm_p1) ? sm : 0.0f;
   // The reference's thread 0 scans the 32 peaks for the first strict maximum (cuSIFT_D.cu:369-379):
   // maxval1 = max(0, max pk), i1 = first index that attains it, -1 if no peak is positive.  Same result from a
   // wave reduction + ballot (pk is never NaN: it comes out of ordered comparisons).
-  const float maxval1 = max_over_32(pk);  // lanes >= 32 hold pk = 0 and reduce among themselves
+  const float maxval1 = max_over_32(pk);  // both halves hold the same 32 values and reduce among themselves
   const unsigned long long hit = __ballot(tx < 32 && pk == maxval1 && maxval1 > 0.0f);
   const int i1 = hit ? (int)__builtin_ctzll(hit) : -1;
   const float mv = uniform(maxval1);  // lane 0's value = the maximum of lanes 0..31
-  const float val1 = S.hist[32 + ((i1 + 1) & 31)];
-  const float val2 = S.hist[32 + ((i1 + 31) & 31)];
+  const int smi = __builtin_bit_cast(int, sm);
+  const float val1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(smi, (i1 + 1) & 31));
+  const float val2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(smi, (i1 + 31) & 31));
   const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * mv - val1 - val2);
   const float ori = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
-  wave_sync();  // every lane has read hist before the caller reuses the buffers
   return ori;
 }
 
