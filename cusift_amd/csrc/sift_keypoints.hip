@@ -1000,13 +1000,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     rec = fetch_head(src);
   }
   while (g < total) {
-    unsigned int nxt = 0;
-    if (lane == 0) nxt = shard + kQueueShards * (atomicAdd(cursor, 1u) + per_shard);
     // a staged keypoint: the three fields of the head that detection wrote and nothing below rewrites
     if (src != pt && (lane == kSharpIndex || lane == kEdgeIndex || lane == kSubIndex))
       reinterpret_cast<float *>(pt)[lane] = rec;
     const float px = head(0), py = head(1), kscale = head(2), sub = head(kSubIndex);
     const int im_cur = im;
+    // The next item's index: one atomic by lane 0, whose round trip (~1-2 us to the L2 and back) is meant to hide behind
+    // the patch loads.  Written as atomicAdd() it did not: the compiler forms the result's arithmetic at once and put
+    // `s_waitcnt vmcnt(0)` directly behind the atomic -- every keypoint began by waiting for it (seen in the ISA, round
+    // 4).  As inline assembly the returning atomic is just an instruction with a vector result; nothing reads `raw`
+    // until the wait below, behind the patch loads.  (Issued AFTER the record's fields have been read: the compiler's own
+    // `vmcnt(0)` for that load -- it does not know this asm is a memory operation -- would wait for the atomic as well.)
+    unsigned int raw = 0;
+    {
+      unsigned long long saved_exec;
+      asm volatile("s_mov_b64 %[sv], exec\n\t"
+                   "s_mov_b64 exec, 1\n\t"
+                   "global_atomic_add %[r], %[off], %[one], %[base] sc0\n\t"
+                   "s_mov_b64 exec, %[sv]"
+                   : [r] "+v"(raw), [sv] "=&s"(saved_exec)
+                   : [off] "v"(0u), [one] "v"(1u), [base] "s"(cursor)
+                   : "memory");
+    }
     int o = ((__float_as_int(sub) >> 23) & 0xff) - exp0;  // subsampling = sub0 * 2^octave
     o = clampi(o, 0, T.n_oct - 1);
     const float *img = T.base[o] + (long)im_cur * T.stride[o];
@@ -1023,7 +1038,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // (Tried on top of this and dropped, tools/exp_describe_stamps.sh: forming the next keypoint's geometry between the
     // stages -- the ~600 cycles it saves here come back, and more, in the descriptor stage; touching the next patch's
     // lines with two LDS-DMA loads so that they are in L2 by the time they are staged -- no gain.)
-    g = __builtin_amdgcn_readfirstlane(nxt);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw) : : "memory");  // (already satisfied after stage_patch)
+    g = __builtin_amdgcn_readfirstlane(shard + kQueueShards * (raw + per_shard));
     cusift_point *pt_next = nullptr;
     if (g < total) {
       pt_next = locate(g, src);
