@@ -1,10 +1,13 @@
 """Builds libcusift_amd.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
 
-    python -m cusift_amd.build [--force] [--lab]
+    python -m cusift_amd.build [--force] [--lab] [--stamps]
 
 --lab builds libcusift_amd_lab.so with -DCUSIFT_LAB: the same kernels, plus the tuning overrides the A/B scripts under
 tools/ read from the environment (CUSIFT_*_ROWS_*, CUSIFT_DETECT_WAVES, ...; select it with CUSIFT_AMD_LIB=<path>).  The
 product library reads none of them.
+
+--stamps builds libcusift_amd_stamps.so with -DCUSIFT_STAMPS: describe_all_kernel with shader-clock stamps at its phase
+boundaries (tools/describe_stamps.py).
 
 The shared object lands next to this file so that it travels to the GPU box with the source tree.
 """
@@ -56,10 +59,17 @@ def is_stale():
 
 
 LAB_LIB = os.path.join(HERE, "libcusift_amd_lab.so")
+STAMPS_LIB = os.path.join(HERE, "libcusift_amd_stamps.so")  # --stamps: -DCUSIFT_STAMPS, for tools/describe_stamps.py
 
 
-def build(force=False, verbose=False, lab=False):
+def build(force=False, verbose=False, lab=False, stamps=False):
     """Compile the HIP extension for gfx950 if missing or older than its sources. Returns the path."""
+    if stamps:
+        cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DCUSIFT_STAMPS", "-o", STAMPS_LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return STAMPS_LIB
     if lab:
         cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DCUSIFT_LAB", "-o", LAB_LIB] + [os.path.join(CSRC, s) for s in SOURCES]
         if verbose:
@@ -84,4 +94,4 @@ def build(force=False, verbose=False, lab=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv, stamps="--stamps" in sys.argv))

@@ -53,6 +53,9 @@ struct PatchGeom {
   int stride;  // floats per patch row
 };
 
+// kWait = false: the loads are left in flight -- the caller has work that does not read the patch and waits for
+// vmcnt(0) itself (describe_all_kernel).
+template <bool kWait = true>
 __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w, int h, int pitch, RowWindow rw,
                                             float *lds, const PatchGeom &g, int pw, int ph, int lane) {
   // Everything about the patch is wave-uniform (it derives from the keypoint's fields).  One instruction per patch
@@ -92,7 +95,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, k * group_bytes, 0, 0);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kWait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
     }
   }
@@ -112,7 +115,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int w
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 4, voff, off, 0, 0);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch is in LDS (this also waits for the wave's older stores)
+  if (kWait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch is in LDS (this also waits for the wave's older stores)
 }
 
 // (1-a)(1-b), a(1-b), (1-a)b, ab of the texture model.
@@ -203,6 +206,24 @@ __device__ __forceinline__ void wave_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Phase stamps (tools/describe_stamps.py; a build with -DCUSIFT_STAMPS, never the product): lane 0 adds the shader-clock
+// time since the previous stamp to counter i of the wave, kept in the `hist` words of the wave's LDS block (unused by the
+// stages since the orientation's tail moved into registers); describe_all_kernel adds them to g_describe_stamps at its end.
+#ifdef CUSIFT_STAMPS
+__device__ unsigned long long g_describe_stamps[16];
+#define STAMP(S, i)                                                                          \
+  do {                                                                                       \
+    const unsigned int t_ = (unsigned int)__builtin_amdgcn_s_memtime();                      \
+    if (threadIdx.x == 0) {                                                                  \
+      unsigned int *h_ = (S).stamps;                                                         \
+      h_[i] += t_ - h_[15];                                                                  \
+      h_[15] = t_;                                                                           \
+    }                                                                                        \
+  } while (0)
+#else
+#define STAMP(S, i) do { } while (0)
+#endif
+
 // Where a keypoint's taps come from: an LDS patch (usual) or global memory (footprint larger than the patch).
 // The choice is wave-uniform and made ONCE per keypoint -- the whole keypoint body is instantiated per sampler
 // type, so there is no branch, no runtime stride multiply and no vmcnt wait around the individual taps (with one
@@ -267,7 +288,10 @@ struct alignas(16) KpShared {
   // first, i.e. at LDS address 0 (the compiler places this 16-byte aligned object before the prefix table): a tap's four
   // pixels are then offset0:0/1 and offset0:40/41 of ONE address register, with no base to add (-2 instructions per tap)
   float patch[kDescPatch * kDescPatch];
-  float hist[64];
+  float hist[64];  // (unused since the orientation's tail moved into registers; kept: the layout below is tuned)
+#ifdef CUSIFT_STAMPS
+  unsigned int stamps[16];  // (the stamps build halves kMaxFlatImages to make room: same 16 waves per CU)
+#endif
   float gauss[11];      // orientation window; gauss[0] also carries the finished orientation to all lanes
   float pad_[1];        // keeps scratch 16-byte aligned (float4 stores)
   // shared by the two stages (they never overlap in time):
@@ -293,6 +317,9 @@ struct alignas(16) OriShared {
   float hist[64];
   float gauss[11];
   float pad_[1];
+#ifdef CUSIFT_STAMPS
+  unsigned int stamps[16];
+#endif
   float scratch[256];  // the (bin, weight) list of the 128 sample slots (kp_orientation)
   __device__ __forceinline__ float *wmat() { return scratch; }
 };
@@ -340,12 +367,37 @@ __device__ __forceinline__ float tree_sum64(float x) {
   return s0 + s1 + s2 + s3;
 }
 
+// What the orientation stage computes from the keypoint's fields alone -- nothing that reads the patch: the Gaussian
+// window's table (into S.gauss) and the lattice shortcut's test and weights.  A function of its own so that
+// describe_all_kernel can run it while the patch's loads are in flight.
+struct OriPrep {
+  bool lattice;
+  float w00, w10, w01, w11;
+  int e_c;  // patch element of the pixel that holds floor(k - 0.5) of the window's centre sample
+};
+// Sum over the wave, every lane returns it, in whatever association is cheapest: four in-row DPP steps, then the two
+// row broadcasts gfx9 has for exactly this (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- 6 vector
+// instructions and a v_readlane against tree_sum64's 17.  For the descriptor's two norms, whose summation order is free.
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += dpp_perm<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_perm<0x141>(v);  // row_half_mirror
+  v += dpp_perm<0x140>(v);  // row_mirror: every lane holds its row's sum
+  // (inline assembly: from the builtin the compiler makes a zeroed register, a DPP move and an addition of each step; the
+  // rows outside row_mask keep their value.  s_nop 1: the two wait states between a VALU write and a DPP read of it.)
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <typename SH, typename TEX>
-__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
+__device__ __forceinline__ OriPrep kp_orientation_prep(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
   if (tx < 11) S.gauss[tx] = sm_expf(i2sigma2 * (tx - 5) * (tx - 5));
-  const float xp = kx - 5.0f;
-  const float yp = ky - 5.0f;
   // Lattice shortcut.  The 484 taps of a keypoint sit at kx + n/2, ky + m/2 (n, m integers, |n|,|m| <= 13).  Let
   // u = ulp(kx) (<= 1/2 for kx < 2^23).  Every intermediate of the reference's arithmetic ((kx - 5) + i) +- 1 - 0.5 is
   // a multiple of u; it is exactly representable -- so no operation rounds -- as long as it does not climb into the
@@ -356,7 +408,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   // same bits.  Keypoints within 8 px below a power of two (or with a coordinate < 16) take the general path.
   bool lattice = false;
   float w00 = 0.f, w10 = 0.f, w01 = 0.f, w11 = 0.f;
-  int e_c = 0;  // patch element of the pixel that holds floor(k - 0.5) of the window's centre sample
+  int e_c = 0;
   if constexpr (TEX::kIsPatch) {
     const float xhi = kx + 8.0f, yhi = ky + 8.0f;
     lattice = kx >= 1.0f && ky >= 1.0f && xhi < 4.0e6f && yhi < 4.0e6f &&
@@ -374,6 +426,17 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
       e_c = ((int)fy - tex.y0) * TEX::kPatchStride + ((int)fx - tex.x0);
     }
   }
+  return OriPrep{lattice, w00, w10, w01, w11, e_c};
+}
+
+template <typename SH, typename TEX>
+__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, const OriPrep &P, float kx, float ky, float scale,
+                                                int tx) {
+  const float xp = kx - 5.0f;
+  const float yp = ky - 5.0f;
+  const bool lattice = P.lattice;
+  const float w00 = P.w00, w10 = P.w10, w01 = P.w01, w11 = P.w11;
+  const int e_c = P.e_c;
   wave_sync();
   int sbin[2] = {0, 0};            // this lane's two samples: histogram bin ...
   float swgt[2] = {0.0f, 0.0f};    // ... and weight (a second sample exists for tx < 57)
@@ -438,6 +501,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     sbin[rep] = bin;
     swgt[rep] = grad * S.gauss[xd[rep]] * S.gauss[yd[rep]];
   }
+  STAMP(S, 4);
   float hist_half;  // this lane's (half, bin) sum
   {
     // Histogram without LDS atomics.  Bins are lanes (tx & 31); the lower half-wave sums samples 0..63 in index order,
@@ -470,6 +534,7 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
     wave_sync();  // the list has been read: the caller may reuse the storage
     hist_half = acc;
   }
+  STAMP(S, 5);
   // Round 4: from here on the histogram lives in registers -- no LDS round trip.  (A lone wave issues one vector
   // instruction per ~8 cycles and an LDS round trip costs a wave ~120: the five dependent round trips this tail used to
   // make -- combine the halves, smooth, find the peaks, fetch the peak's neighbours -- were worth ~75 instructions.)
@@ -497,7 +562,13 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx,
   const float val2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(smi, (i1 + 31) & 31));
   const float peak = i1 + 0.5f * (val1 - val2) / (2.0f * mv - val1 - val2);
   const float ori = 11.25f * (peak < 0.0f ? peak + 32.0f : peak);
+  STAMP(S, 6);
   return ori;
+}
+
+template <typename SH, typename TEX>
+__device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
+  return kp_orientation(S, tex, kp_orientation_prep(S, tex, kx, ky, scale, tx), kx, ky, scale, tx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,31 +623,38 @@ __device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
 // same banks -- and a quarter of this kernel's bank-conflict cycles came from these four reads.)
 __device__ __forceinline__ int desc_elem(int lane) { return 8 * (lane & 15) + (lane >> 4); }
 
-// sqrt and atan2 of the DESCRIPTOR samples: one hardware instruction (1 ulp) instead of the IEEE-exact expansions
-// (~11 instructions each) the orientation stage needs for its bit-identical histogram bins.  atan2: the quotient by
-// v_rcp_f32; min(., 1) also turns the 0 * inf of a zero gradient (whose weight is zero) into a finite angle.  The +pi
-// of (dy = +0, dx < 0) is exact as in sm_atan2f -- the angle-index-8 path depends on it.
+// sqrt and quotient of the DESCRIPTOR samples: one hardware instruction (1 ulp) instead of the IEEE-exact expansions
+// (~11 instructions each) the orientation stage needs for its bit-identical histogram bins.
 __device__ __forceinline__ float desc_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float desc_atan2f(float y, float x) {
-  const float ax = sm_abs(x), ay = sm_abs(y);
+// The descriptor's angle coordinate 4/3.1415f * atan2f(dy, dx) + 4 (cuSIFT_D.cu:231-233).  The share a sample hands to
+// its two angle bins is continuous in this value, so it need not be sm_atan2f's to the ulp: atan t = t + t s Q(s) with Q
+// of degree 4 (Lawson fit as tools/fit_math_polys.py's: 2.4e-6 rad = 3.1e-6 of a bin, which reaches the descriptor as
+// ~4e-6 of its norm against the 1e-4 bar) and no low-order word on pi/2 -- 30 instructions per sample where the form
+// exact to the ulp took 38.  What is kept operation for operation is the ONE place where the value decides something: at
+// 8.0 the reference's index becomes 8 and the share lands in the next cell (cuSIFT_D.cu:233-255) -- a jump, at |atan2f| =
+// 3.1415, t = 9.3e-5 from the negative x axis.  There atan t == t in sm_atan2f and here alike (the cubic term is below
+// half an ulp), and (pi_hi - t) + pi_lo, the product with 4/3.1415f and the + 4 are the reference's operations: the same
+// bits.  ((dy = +0, dx < 0) gives 8.000118, (dy = -0, dx < 0) -0.000118; a zero gradient's 0 * inf comes out finite, its
+// weight is 0.)  (Measured and dropped: the octant fix-ups in units of bins, three instructions fewer, with the value
+// near pi re-formed behind a ballot-skipped branch -- the branch splits the four samples' straight-line code and costs
+// more than it saves.)
+__device__ __forceinline__ float desc_angle_bins(float dy, float dx) {
+  const float ax = sm_abs(dx), ay = sm_abs(dy);
   const bool swap = ay > ax;
   const float mx = swap ? ay : ax;
   const float mn = swap ? ax : ay;
-  const float a = fminf(mn * __builtin_amdgcn_rcpf(mx), 1.0f);
-  const float s = a * a;
-  float q = 0.0029205884784460068f;
-  q = sm_fma(q, s, -0.016367513686418533f);
-  q = sm_fma(q, s, 0.0432111918926239f);
-  q = sm_fma(q, s, -0.07552158087491989f);
-  q = sm_fma(q, s, 0.10665978491306305f);
-  q = sm_fma(q, s, -0.14211048185825348f);
-  q = sm_fma(q, s, 0.19993771612644196f);
-  q = sm_fma(q, s, -0.33333152532577515f);
-  const float t = q * s;
-  float r = sm_fma(t, a, a);
-  if (swap) r = (1.5707963705062866f - r) + -4.371138828673793e-08f;
-  if (sm_bits(x) & 0x80000000u) r = (3.1415927410125732f - r) + -8.742277657347586e-08f;
-  return sm_float(sm_bits(r) | (sm_bits(y) & 0x80000000u));
+  const float t = fminf(mn * __builtin_amdgcn_rcpf(mx), 1.0f);
+  const float s = t * t;
+  float q = -0.0128082866f;
+  q = sm_fma(q, s, 0.055805929f);
+  q = sm_fma(q, s, -0.119818673f);
+  q = sm_fma(q, s, 0.195182785f);
+  q = sm_fma(q, s, -0.33296597f);
+  float r = sm_fma(q * s, t, t);
+  if (swap) r = 1.5707963705062866f - r;
+  if (sm_bits(dx) & 0x80000000u) r = (3.1415927410125732f - r) + -8.742277657347586e-08f;  // pi = hi + lo, as sm_atan2f
+  const float theta = sm_float(sm_bits(r) | (sm_bits(dy) & 0x80000000u));
+  return 4.0f / 3.1415f * theta + 4.0f;
 }
 
 // sum over the 8-column window of cell column `hi` in histogram row `row` (= cellhist() + 64 slot + 16 vi), plus the
@@ -630,7 +708,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     // cuSIFT_D.cu:231-236: angf = 4/pi atan2 + 4 in [0, 8.0001] for every finite gradient (v_cvt_i32_f32 turns a NaN
     // into 0); angi = (int)angf, fraction angf - angi.  The unsigned min is for memory safety only.  code = angi, or 9
     // for angi == 8: slot `code` receives the (1 - fraction) share, slot code + 1 the fraction's.
-    const float angraw = 4.0f / 3.1415f * desc_atan2f(dy, dx) + 4.0f;
+    const float angraw = desc_angle_bins(dy, dx);
     const int angc = (int)angraw;
     const float angf = angraw - (float)angc;
     unsigned int code = min((unsigned int)angc, 8u);
@@ -642,6 +720,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   }
   const bool spill = __ballot((codes & 8u) != 0u) != 0ull;  // wave-uniform: some sample has angle index 8
   wave_sync();
+  STAMP(S, 7);
   // the patch is dead from here on: its storage becomes the histogram rows
 
   // ---- phase 2a: vertical pass ----
@@ -667,6 +746,8 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
       for (int c = 0; c < 4; ++c) {
         const int r = 4 * half + c;
         const bool live = (r >= 2 || vi >= 1) && (r <= 5 || vi <= 2);  // row 4 vi - 2 + r in 0..15
+        // (the visit as an exec-masked `if`: with weight 0 instead -- one basic block, every lane making all eight
+        // read-modify-writes -- the launch is 2 % SLOWER, round 4: the LDS pipe's time is what the skipped lanes save)
         if (live) {
           const unsigned int code = __builtin_bit_cast(unsigned int, sg[c]) & 15u;
           float *p = mine + code * 64;
@@ -685,6 +766,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     mine[0] += fold;
   }
   wave_sync();
+  STAMP(S, 8);
 
   // ---- phase 2b: horizontal pass ----
   float b0, b1;
@@ -708,10 +790,11 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
     }
   }
 
+  STAMP(S, 9);
   // ---- phase 3: normalisation ----
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    const float tsum = tree_sum64(b0 * b0 + b1 * b1);
+    const float tsum = wave_sum64(b0 * b0 + b1 * b1);
     const float r = __builtin_amdgcn_rsqf(tsum);
     b0 = b0 * r;
     b1 = b1 * r;
@@ -722,6 +805,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   }
   out0 = b0;
   out1 = b1;
+  STAMP(S, 10);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -876,19 +960,8 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
 // -- so images with more keypoints do not leave the rest of the grid idle, one patch load serves both stages,
 // and 2 x octaves launches become one.  Same device functions as the two stage kernels => same results.
 // ------------------------------------------------------------------------------------------------
-template <typename TEX>
-__device__ __forceinline__ void describe_keypoint(KpShared &S, const TEX &tex, const DescLaneConsts &C,
-                                                  cusift_point *pt, float px, float py, float kscale, float sub,
-                                                  int lane, int root_sift) {
-  const float ori = kp_orientation(S, tex, px, py, kscale, lane);
-  float b0, b1;
-  kp_descriptor(S, tex, C, px, py, kscale, ori, lane, b0, b1);
-  if (lane == 0) pt->orientation = ori;
-  finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
-}
-// (the same, handing the orientation back: describe_bands_kernel's footprint check wants it.  A function of its own --
-// returning it from describe_keypoint renamed registers all through describe_all_kernel, and that kernel's code is left
-// alone unless a same-box A/B says otherwise)
+// One keypoint, both stages, handing the orientation back (describe_bands_kernel's footprint check wants it);
+// describe_all_kernel makes the same calls itself, with its work-queue steps between them.
 template <typename TEX>
 __device__ __forceinline__ float describe_keypoint_ori(KpShared &S, const TEX &tex, const DescLaneConsts &C,
                                                        cusift_point *pt, float px, float py, float kscale, float sub,
@@ -959,14 +1032,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   unsigned int *cursor = queue + shard * 32;                 // 128-byte stride
   const unsigned int per_shard = gridDim.x / kQueueShards;   // workgroups per shard (host: gridDim.x % shards == 0)
   unsigned int g = blockIdx.x;                               // = shard + kQueueShards * (blockIdx.x / kQueueShards)
-  // item < total; moves `im` forward to the item's image.  Returns the record the keypoint ends up in; `src` is where its
-  // head waits (the same record, or a staged one)
-  auto locate = [&](unsigned int item, const cusift_point *&src) {
+  // item < total: moves `im` forward to the item's image and returns the record the keypoint ends up in (locate_begin);
+  // where its head waits -- the same record, or a staged one -- comes from locate_end.  Two steps because the second
+  // needs memory: the image's segment ends.  locate_begin ISSUES their load (one vector load: lane r < n_seg holds
+  // ends[r]) and locate_end reads it a whole orientation stage later, so nobody waits for it.  (Until round 4 the segment
+  // was found by a loop of DEPENDENT scalar loads -- five round trips for a keypoint of octave 0, the last of five
+  // segments: 17 % of a wave's time in the phase stamps, tools/describe_stamps.py.)
+  unsigned int loc_idx = 0, loc_ends = 0xffffffffu;
+  auto locate_begin = [&](unsigned int item) {
     while (__builtin_amdgcn_readfirstlane(s_prefix[im + 1]) <= item) ++im;  // ends: item < total = s_prefix[n_images]
-    const unsigned int idx = item - __builtin_amdgcn_readfirstlane(s_prefix[im]);
-    cusift_point *dst = points + (long)im * max_pts + idx;
-    src = dst;
+    loc_idx = item - __builtin_amdgcn_readfirstlane(s_prefix[im]);
+    if (G.n_seg > 0 && !self_join) {
+      const unsigned int *ends = seg_end + im * G.n_seg;  // wave-uniform
+      loc_ends = lane < G.n_seg ? ends[lane] : 0xffffffffu;
+    }
+    return points + (long)im * max_pts + loc_idx;
+  };
+  auto locate_end = [&](cusift_point *dst) {
+    const cusift_point *from = dst;
     if (G.n_seg > 0) {
+      const unsigned int idx = loc_idx;
       int r = 0;
       unsigned int first = 0;  // keypoints of this image in the segments before r
       if (self_join) {
@@ -977,13 +1062,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
           first += kept;
         }
       } else {
-        const unsigned int *ends = seg_end + im * G.n_seg;  // wave-uniform: scalar loads
-        while (idx >= ends[r]) first = ends[r++];  // ends: idx < this image's total = ends[n_seg - 1]
+        // ends[] is non-decreasing and idx < ends[n_seg - 1] (this image's total): the segment is the number of ends <= idx
+        r = __builtin_popcountll(__ballot(idx >= loc_ends));
+        first = r > 0 ? (unsigned int)__builtin_amdgcn_readlane((int)loc_ends, r - 1) : 0u;
       }
       const char *base = G.base[r];
-      if (base) src = reinterpret_cast<const cusift_point *>(base + ((size_t)im * max_pts + (idx - first)) * kStagedRecBytes);
+      if (base) from = reinterpret_cast<const cusift_point *>(base + ((size_t)im * max_pts + (idx - first)) * kStagedRecBytes);
     }
-    return dst;
+    return from;
   };
   // lane l < 16 holds float l of the record's head (coords2D, scale, ..., subsampling = float 12): one register
   constexpr int kSubIndex = (int)(offsetof(cusift_point, subsampling) / sizeof(float));
@@ -996,10 +1082,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   constexpr int kSharpIndex = (int)(offsetof(cusift_point, sharpness) / sizeof(float));
   constexpr int kEdgeIndex = (int)(offsetof(cusift_point, edgeness) / sizeof(float));
   if (g < total) {
-    pt = locate(g, src);
+    pt = locate_begin(g);
+    src = locate_end(pt);
     rec = fetch_head(src);
+    // (waited for here so that the loop's head holds no wait of the compiler's: see the wait before the stores below)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec) : : "memory");
   }
+#ifdef CUSIFT_STAMPS
+  if (lane < 16) S.stamps[lane] = lane == 15 ? (unsigned int)__builtin_amdgcn_s_memtime() : 0u;
+  wave_sync();
+#endif
   while (g < total) {
+    STAMP(S, 12);  // loop back edge (+ the kernel's prologue, once)
     // a staged keypoint: the three fields of the head that detection wrote and nothing below rewrites
     if (src != pt && (lane == kSharpIndex || lane == kEdgeIndex || lane == kSubIndex))
       reinterpret_cast<float *>(pt)[lane] = rec;
@@ -1032,33 +1126,88 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     PatchGeom pg;
     int pw, ph;
     const bool use_patch = patch_for_reach(px, py, reach, pg, pw, ph);
-    if (use_patch) stage_patch(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
+    // The patch's loads are issued and NOT waited for: what the orientation stage derives from the keypoint's fields
+    // alone (Gaussian table, lattice test and weights: ~70 instructions) runs while they are in flight.
+    OriPrep prep;
+    if (use_patch) {
+      stage_patch<false>(img, w, h, pitch, rw, S.patch, pg, pw, ph, lane);
+      STAMP(S, 0);
+      if (q > 0.0f)
+        prep = kp_orientation_prep(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, px, py, kscale, lane);
+      else
+        prep = kp_orientation_prep(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, px, py, kscale, lane);
+      STAMP(S, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch is in LDS
+    } else {
+      prep = kp_orientation_prep(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, px, py, kscale, lane);
+    }
     wave_sync();
-    // the patch loads have been waited for, so has the atomic issued before them: fetch the next record now.
+    STAMP(S, 2);
+    // the patch loads have been waited for, so has the atomic issued before them: the next item's index is here.
     // (Tried on top of this and dropped, tools/exp_describe_stamps.sh: forming the next keypoint's geometry between the
     // stages -- the ~600 cycles it saves here come back, and more, in the descriptor stage; touching the next patch's
     // lines with two LDS-DMA loads so that they are in L2 by the time they are staged -- no gain.)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw) : : "memory");  // (already satisfied after stage_patch)
     g = __builtin_amdgcn_readfirstlane(shard + kQueueShards * (raw + per_shard));
     cusift_point *pt_next = nullptr;
-    if (g < total) {
-      pt_next = locate(g, src);
-      rec = fetch_head(src);
-    }
+    if (g < total) pt_next = locate_begin(g);  // issues the load of its image's segment ends
+    STAMP(S, 3);
+    float ori;
     if (use_patch) {
       if (q > 0.0f)
-        describe_keypoint(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
-                          sub, lane, root_sift);
+        ori = kp_orientation(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, prep, px, py, kscale, lane);
       else
-        describe_keypoint(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, C, pt, px, py, kscale,
-                          sub, lane, root_sift);
+        ori = kp_orientation(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, prep, px, py, kscale, lane);
     } else {
-      describe_keypoint(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, pt, px, py, kscale, sub, lane, root_sift);
+      ori = kp_orientation(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, prep, px, py, kscale, lane);
     }
+    // Between the stages: where the next item's head waits, and the load of that head -- its round trip hides behind
+    // the descriptor stage, as the segment ends' did behind the orientation stage.
+    const cusift_point *src_next = nullptr;
+    float rec_next = 0.0f;
+    if (g < total) {
+      src_next = locate_end(pt_next);
+      rec_next = fetch_head(src_next);
+    }
+    STAMP(S, 14);
+    float b0, b1;
+    if (use_patch) {
+      if (q > 0.0f)
+        kp_descriptor(S, PatchSampler<kDescPatch, true>{S.patch, pg.x0, pg.y0, q, inv_q}, C, px, py, kscale, ori, lane, b0, b1);
+      else
+        kp_descriptor(S, PatchSampler<kDescPatch, false>{S.patch, pg.x0, pg.y0, q, inv_q}, C, px, py, kscale, ori, lane, b0, b1);
+    } else {
+      kp_descriptor(S, GlobalSampler{img, w, h, pitch, rw, q, inv_q}, C, px, py, kscale, ori, lane, b0, b1);
+    }
+    // The next head has arrived long ago; waiting for it HERE, before this keypoint's stores are issued, is free -- at
+    // the top of the loop the same wait also waited for those stores' acknowledgements (the compiler's vmcnt(0) for the
+    // head's first use: ~1-2 us of write round trip exposed per keypoint).
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rec_next) : : "memory");
+    if (lane == 0) pt->orientation = ori;
+    finish_descriptor(S, pt, b0, b1, px, py, kscale, sub, lane, root_sift);
     wave_sync();
+    STAMP(S, 11);
+#ifdef CUSIFT_STAMPS
+    if (lane == 0) S.stamps[13] += 1u;
+#endif
     pt = pt_next;
+    src = src_next;
+    rec = rec_next;
   }
+#ifdef CUSIFT_STAMPS
+  wave_sync();
+  if (lane < 15) atomicAdd(&g_describe_stamps[lane], (unsigned long long)S.stamps[lane]);
+#endif
 }
+
+#ifdef CUSIFT_STAMPS
+// the sums of all describe_all_kernel waves since the last call (counters 0..12: shader-clock cycles by phase, 13: keypoints)
+extern "C" int cusift_stamps_read(unsigned long long *out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_describe_stamps), sizeof(g_describe_stamps)) != hipSuccess) return -1;
+  unsigned long long zero[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_describe_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Joins the keypoint segments of a batch (sift_types.h: SegmentTable) before describe_all_kernel walks them: per image
 // the running sum of the segments' counts in list order, clamped at max_pts -- so the coarser segments survive whole,

@@ -56,7 +56,11 @@ struct RowWindow {
 };
 
 // Per-octave base images of a batch, passed by value to describe_all_kernel (driver path).
+#ifdef CUSIFT_STAMPS
+constexpr int kMaxFlatImages = 128;  // (the phase-stamp build's counters take LDS of the prefix table)
+#else
 constexpr int kMaxFlatImages = 256;  // batch size up to which the flattened keypoint kernel is used
+#endif
 constexpr int kDetectWaveLdsFloats = 128 * 21;  // detect_fused_kernel: candidate list per wave (128 entries of 21 words)
 constexpr int kStagedRecBytes = 64;   // a staged keypoint: the first 16 floats of a cusift_point (coords2D .. subsampling)
 // Where the keypoints of a batch wait before describe_all_kernel puts them in place (cusift_extract_batch).  A batch's

@@ -428,7 +428,10 @@ def test_descriptors_match_oracle(ctx, oracle, gray1, frac_bits):
     l2 = np.linalg.norm(want["data"][:n][ok].astype(np.float64) - got["data"][:n][ok].astype(np.float64), axis=1)
     # north_star tolerance: 1e-4 L2 per descriptor -- every descriptor (only the summation order differs)
     assert l2.max() < 1e-4, np.sort(l2)[-5:]
-    assert np.median(l2) < 1e-6
+    # (the typical distance: a few 1e-6 since the angle coordinate became a degree-5 fit good to 2.3e-6 of a bin -- part of
+    # the 1e-4 tolerance spent on purpose, sift_keypoints.hip: desc_angle_bins; it was < 1e-6 with the exact-to-the-ulp form)
+    assert np.median(l2) < 1e-5, np.median(l2)
+    print("descriptor L2 distance to the oracle: median %.3g, max %.3g" % (np.median(l2), l2.max()))
     # unit norm, and the in-place scaling by subsampling (cuSIFT_D.cu:292-296)
     np.testing.assert_allclose(np.linalg.norm(got["data"][:n][ok], axis=1), 1.0, atol=1e-5)
     np.testing.assert_array_equal(want["coords2D"][:n], got["coords2D"][:n])

@@ -75,6 +75,11 @@ FORMS = [
     ("v_log_f32", "v_log_f32 %D, %A", 0),
     ("v_mbcnt_lo_u32_b32", "v_mbcnt_lo_u32_b32 %D, %A, %D", 0),
     ("v_pk_fma_f32 v,v,v op_sel (broadcast lo)", "v_pk_fma_f32 %D, %D, %A, %B op_sel_hi:[1,0,1]", 1),
+    # the orientation histogram's "acc += (b == mybin) ? w : 0" (one dependent chain on the accumulator), as a select and
+    # with the compare writing EXEC; these two rows are cycles per GROUP (= per sample), not per instruction
+    ("GROUP v_cmp + s_nop + v_cndmask + v_add chain", "v_cmp_eq_u32 vcc, %A, %B\\n\\ts_nop 1\\n\\tv_cndmask_b32 %A, 0, %B, vcc\\n\\tv_add_f32 %D, %D, %A", 2),
+    ("GROUP v_cmpx + v_add chain + s_mov exec", "v_cmpx_eq_u32 vcc, %A, %B\\n\\tv_add_f32 %D, %D, %A\\n\\ts_mov_b64 exec, -1", 2),
+    ("GROUP v_cmp + v_add chain (no select)", "v_cmp_eq_u32 vcc, %A, %B\\n\\tv_add_f32 %D, %D, %A", 2),
 ]
 
 HEAD = r'''// valu_rate.hip -- GENERATED by tools/microbench/gen_valu_rate.py (edit that, not this).
@@ -166,7 +171,7 @@ def main():
                    '"s"(s2) : "vcc", "m0");\n' % (kid, name, body, var))
     out.append(TAIL)
     for kid, (name, fmt, _) in enumerate(FORMS):
-        out.append('  run<%d>("%s", %d, cus, only);\n' % (kid, name, 64 if "\\n" in fmt else 32))
+        out.append('  run<%d>("%s", %d, cus, only);\n' % (kid, name, 32 if name.startswith("GROUP") else 64 if "\\n" in fmt else 32))
     out.append("  return 0;\n}\n")
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_rate.hip")
     with open(path, "w") as f:
