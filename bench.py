@@ -881,6 +881,11 @@ def main():
                 out["host_visible_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank, dev,
                                                            total_local_kp=local_kp)
                 out["keypoints_per_s_host_visible"] = out["host_visible_leg"]["keypoints_per_s"]
+                # the same records without the 48 bytes extraction never writes (cusift_pack_points_trimmed: 540 bytes,
+                # every field the reference fills, bit for bit -- expanded on the host by cusift_expand_trimmed_host)
+                out["host_visible_trimmed_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank,
+                                                                   dev, total_local_kp=local_kp, compact="trimmed")
+                out["keypoints_per_s_host_visible_trimmed"] = out["host_visible_trimmed_leg"]["keypoints_per_s"]
                 # the optional 160-byte wire record (exact header fields, 8-bit descriptor with one step per record):
                 # D2H no longer bounds the step; the exact 588-byte path above stays the default
                 out["host_visible_compact_leg"] = host_visible_leg(torch, capi, pipe, d_imgs, K, B, args.max_pts, local_rank,
@@ -1164,8 +1169,11 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
     # staging slots: a step's records leave depth - 2 steps after it was enqueued.  The exact records are bound by the
     # copy itself (99 MB per step over PCIe); the compact ones are not, and need the host to stay further ahead than the
     # 4-stream extraction pipeline is deep
-    depth = 8 if compact else 4
-    rec_bytes = capi.COMPACT_POINT_BYTES if compact else capi.SIFT_POINT_BYTES
+    fmt = "compact" if compact is True else ("trimmed" if compact == "trimmed" else "exact")
+    depth = 8 if fmt == "compact" else 4
+    rec_bytes = capi.WIRE_FORMATS[fmt][1]
+    pack = {"exact": cctx.pack_points, "trimmed": cctx.pack_points_trimmed, "compact": cctx.pack_points_compact}[fmt]
+    rec_dtype = {"exact": capi.SIFT_POINT_DTYPE, "trimmed": capi.TRIMMED_POINT_DTYPE, "compact": capi.COMPACT_POINT_DTYPE}[fmt]
     packed = [torch.empty((cap, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(depth)]
     offs = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
     h_offs = [torch.zeros(B + 1, dtype=torch.int32).pin_memory() for _ in range(depth)]
@@ -1209,8 +1217,7 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
             pack_stream.wait_event(ev)
             if ev_copied[j] is not None:
                 pack_stream.wait_event(ev_copied[j])
-            (cctx.pack_points_compact if compact else cctx.pack_points)(
-                pts.data_ptr(), cnt.data_ptr(), B, max_pts, packed[j].data_ptr(), cap, offs[j].data_ptr())
+            pack(pts.data_ptr(), cnt.data_ptr(), B, max_pts, packed[j].data_ptr(), cap, offs[j].data_ptr())
             done = torch.cuda.Event()
             done.record(pack_stream)  # the slot's records have been packed: the slot may be overwritten
             h_offs[j].copy_(offs[j], non_blocking=True)
@@ -1234,7 +1241,7 @@ def _host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, de
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # spot check: the last step's host records are real (first record of image 0 has a finite, in-range location)
-    rec = h_rec[(K - 1) % depth][:1].numpy().view(capi.COMPACT_POINT_DTYPE if compact else capi.SIFT_POINT_DTYPE)
+    rec = h_rec[(K - 1) % depth][:1].numpy().view(rec_dtype)
     assert np.isfinite(rec["coords2D"]).all() and rec["subsampling"][0] >= 1.0
     res = {"ms_per_step": round(dt / K * 1e3, 4), "keypoints_per_s": round(got["records"] / dt, 1),
            "d2h_GBps": round(got["bytes"] / dt / 1e9, 2), "d2h_bytes_per_step": int(got["bytes"] / K),
