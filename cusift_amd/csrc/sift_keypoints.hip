@@ -343,30 +343,6 @@ __device__ __forceinline__ float max_over_32(float v) {
   return fmaxf(v, __shfl_xor(v, 16));
 }
 
-// The reference's 64-element reduction tree (cuSIFT_D.cu:262-280: s[l] += s[l+32], += s[l+16], += s[l+8],
-// += s[l+4], then s[0]+s[1]+s[2]+s[3] left to right) without LDS round trips: the two cross-row steps are gfx950
-// lane-swap instructions, the two in-row steps DPP shifts, the last four terms are read by lane.  Same pairs added in
-// the same order, so the same bits; every lane returns the total.
-__device__ __forceinline__ float tree_sum64(float x) {
-  // The swap instructions exchange halves / rows BETWEEN two registers and modify both.  Inline assembly: this
-  // compiler's __builtin_amdgcn_permlane{32,16}_swap returns the first register for both results.  The s_nops cover
-  // the VALU -> permlane-swap -> VALU wait states, which the hazard recogniser does not see inside an asm block.
-  float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));  // a = (lo, lo), b = (hi, hi)
-  const float y = a + b;  // x[l] + x[l+32]
-  float c = y, d = y;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));  // c = (r0,r0,r2,r2), d = (r1,r1,r3,r3)
-  const float z = c + d;  // y[l] + y[l+16]
-  const float w = z + dpp_perm<0x108>(z);  // row_shl:8: lane l receives lane l+8
-  const float u = w + dpp_perm<0x104>(w);  // row_shl:4
-  const int ui = __builtin_bit_cast(int, u);
-  const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 0));
-  const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 1));
-  const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 2));
-  const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, 3));
-  return s0 + s1 + s2 + s3;
-}
-
 // What the orientation stage computes from the keypoint's fields alone -- nothing that reads the patch: the Gaussian
 // window's table (into S.gauss) and the lattice shortcut's test and weights.  A function of its own so that
 // describe_all_kernel can run it while the patch's loads are in flight.
@@ -375,9 +351,11 @@ struct OriPrep {
   float w00, w10, w01, w11;
   int e_c;  // patch element of the pixel that holds floor(k - 0.5) of the window's centre sample
 };
+
 // Sum over the wave, every lane returns it, in whatever association is cheapest: four in-row DPP steps, then the two
 // row broadcasts gfx9 has for exactly this (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- 6 vector
-// instructions and a v_readlane against tree_sum64's 17.  For the descriptor's two norms, whose summation order is free.
+// instructions and a v_readlane (the reference's own tree, cuSIFT_D.cu:262-280, on lane swaps and DPP shifts: 17).  For the
+// descriptor's two norms, whose summation order is free.
 __device__ __forceinline__ float wave_sum64(float v) {
   v += dpp_perm<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]
