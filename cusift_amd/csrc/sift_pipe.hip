@@ -13,11 +13,11 @@
 // Host code only: the kernels are the product's (u8_to_f32, the batch driver, pack_points).  One object owns
 //   * `depth` SLOTS -- per slot the upload staging, the float batch, the records + counters, the packed records, and
 //     their pinned host twins (records, offsets);
-//   * up to three extraction contexts, each with a stream of its own (consecutive batches rotate over them, as
-//     bench.py's timed region does: the launch tails of one batch are filled by the next);
-//   * an upload stream, a pack context and a copy stream.
-// A batch moves through: H2D (upload stream) -> [8-bit -> float] + extraction (its context's stream) -> pack + offsets
-// D2H (pack stream) -> records D2H (copy stream; exactly sized, so it is enqueued once the batch's counts have
+//   * two extraction contexts, each with a stream of its own (consecutive batches alternate over them: the launch tails
+//     of one batch are filled by the next);
+//   * an upload stream and a copy stream -- four streams in all, one per hardware queue (cusift_pipe_create).
+// A batch moves through: H2D (upload stream) -> [8-bit -> float] + extraction + pack + offsets D2H (its context's
+// stream) -> records D2H (copy stream; exactly sized, so it is enqueued once the batch's counts have
 // arrived on the host -- by the submit / collect calls that follow, never by a blocked thread).
 #include <hip/hip_runtime.h>
 
@@ -56,7 +56,7 @@ struct Slot {
   unsigned int *d_offsets = nullptr;  // [n + 1]
   cusift_point *h_records = nullptr;  // pinned, [capacity]
   unsigned int *h_offsets = nullptr;  // pinned, [n + 1]
-  hipEvent_t ev_up = nullptr, ev_extracted = nullptr, ev_counts = nullptr, ev_copied = nullptr;
+  hipEvent_t ev_up = nullptr, ev_counts = nullptr, ev_copied = nullptr;
   int n = 0;            // images of the batch in flight
   bool busy = false;    // submitted, not yet collected
   bool copying = false;  // its records' D2H has been enqueued
@@ -70,7 +70,6 @@ struct cusift_pipe {
   size_t capacity = 0;
   cusift_params prm;
   std::vector<cusift_ctx *> ex;  // extraction contexts (own streams)
-  cusift_ctx *pack = nullptr;    // pack kernel + the offsets' D2H
   hipStream_t up = nullptr, copy = nullptr;
   std::vector<Slot> slots;
   unsigned long submitted = 0, collected = 0;
@@ -91,11 +90,10 @@ void free_pipe(cusift_pipe *p) {
     if (s.d_offsets) (void)hipFree(s.d_offsets);
     if (s.h_records) (void)hipHostFree(s.h_records);
     if (s.h_offsets) (void)hipHostFree(s.h_offsets);
-    for (hipEvent_t e : {s.ev_up, s.ev_extracted, s.ev_counts, s.ev_copied})
+    for (hipEvent_t e : {s.ev_up, s.ev_counts, s.ev_copied})
       if (e) (void)hipEventDestroy(e);
   }
   for (cusift_ctx *c : p->ex) (void)cusift_ctx_destroy(c);
-  if (p->pack) (void)cusift_ctx_destroy(p->pack);
   if (p->up) (void)hipStreamDestroy(p->up);
   if (p->copy) (void)hipStreamDestroy(p->copy);
   delete p;
@@ -152,9 +150,14 @@ extern "C" int cusift_pipe_create(cusift_pipe **out, int device, int n_images, i
   p->depth = depth;
   p->prm = *prm;
   p->capacity = records_capacity ? records_capacity : (size_t)n_images * prm->max_pts;
-  // one batch per stream in flight on up to three extraction streams: with the upload, pack and copy streams that is
-  // as many busy streams as the command processor's pipes carry without queues waiting for each other
-  const int n_ex = std::min(depth, 3);
+  // FOUR streams in all -- two extraction streams (consecutive batches alternate; a batch's records are packed on its own
+  // extraction stream), the upload stream and the copy stream: HIP maps streams onto four hardware queues, and a fifth
+  // or sixth busy stream shares a queue with one of these -- an upload then waits behind another batch's kernels.
+  // Measured, 64 x 1080p 8-bit frames, a fresh process each (tools/probe_pipe_depth.py): three extraction streams + a pack
+  // stream 2.64 ms per batch at depth 4 (3.02 at depth 3), two + a pack stream 2.55, two with the pack on the extraction
+  // stream 2.51 (2.49 at depth 3) -- 0.93 of the upload's own time; the link-bound pipeline has no use for a third batch
+  // in extraction (1.1 ms of GPU time per 2.3 ms of upload).
+  const int n_ex = std::min(depth, 2);
   p->prm.concurrent_batches = n_ex;
   int rc = CUSIFT_OK;
   auto hip = [&](hipError_t e, const char *what) {
@@ -169,7 +172,6 @@ extern "C" int cusift_pipe_create(cusift_pipe **out, int device, int n_images, i
       rc = cusift_ctx_reserve(c, n_images, w, h, &p->prm);
     }
   }
-  if (rc == CUSIFT_OK) rc = cusift_ctx_create(&p->pack, device, nullptr);
   if (rc == CUSIFT_OK) hip(hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking), "hipStreamCreate");
   if (rc == CUSIFT_OK) hip(hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking), "hipStreamCreate");
   p->slots.resize(depth);
@@ -186,7 +188,7 @@ extern "C" int cusift_pipe_create(cusift_pipe **out, int device, int n_images, i
     hip(hipHostMalloc((void **)&s.h_records, std::max<size_t>(1, p->capacity) * sizeof(cusift_point), hipHostMallocDefault),
         "hipHostMalloc");
     hip(hipHostMalloc((void **)&s.h_offsets, sizeof(unsigned int) * (n_images + 1), hipHostMallocDefault), "hipHostMalloc");
-    for (hipEvent_t *e : {&s.ev_up, &s.ev_extracted, &s.ev_counts, &s.ev_copied})
+    for (hipEvent_t *e : {&s.ev_up, &s.ev_counts, &s.ev_copied})
       hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
   }
   if (rc == CUSIFT_OK) hip(hipStreamSynchronize(p->up), "hipStreamSynchronize");
@@ -239,10 +241,9 @@ extern "C" int cusift_pipe_submit(cusift_pipe *p, const void *h_frames, int n_im
     p->failed = true;
     return rc;
   }
-  HIP_TRY(hipEventRecord(s.ev_extracted, st));
-  hipStream_t ps = (hipStream_t)cusift_ctx_stream(p->pack);
-  HIP_TRY(hipStreamWaitEvent(ps, s.ev_extracted, 0));
-  rc = cusift_pack_points(p->pack, s.d_points, s.d_counters, n_images, p->prm.max_pts, s.d_packed, p->capacity, s.d_offsets);
+  // the records are packed, and the offsets read back, on the batch's own extraction stream (behind the extraction)
+  hipStream_t ps = st;
+  rc = cusift_pack_points(ctx, s.d_points, s.d_counters, n_images, p->prm.max_pts, s.d_packed, p->capacity, s.d_offsets);
   if (rc != CUSIFT_OK) {
     p->failed = true;
     return rc;

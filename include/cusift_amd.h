@@ -484,8 +484,8 @@ int cusift_exchange_halos(cusift_comm *comm, float *d_band, int pitch, int top_h
  * The reference's entry point takes a HOST image and leaves SiftData on the host, one image at a time, every step
  * blocking (SiftData::Extract + Synchronize, cuSIFT.cu:61-120,52-59).  At this build's rates a caller is bound by PCIe,
  * and gets what the link gives only if upload, extraction and read-back of consecutive batches overlap: this object
- * is that pipeline for a C / C++ caller (no HIP, no Python): `depth` batches in flight, batches rotating over up to
- * three extraction streams, an upload stream, a pack stream and a copy stream; the 8-bit form converts on the device
+ * is that pipeline for a C / C++ caller (no HIP, no Python): `depth` batches in flight, batches alternating over two
+ * extraction streams, an upload stream and a copy stream (four streams: one per hardware queue); the 8-bit form converts on the device
  * (cusift_u8_to_f32; main.cpp:300-318 converts on the host and uploads 4x the bytes).
  *   create   n_images = the largest batch; frames are dense rows of w pixels, unsigned char (CUSIFT_PIPE_U8) or float
  *            (CUSIFT_PIPE_F32, values 0..255 as the reference expects); depth 2..8; records_capacity = records one
