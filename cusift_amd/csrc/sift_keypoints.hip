@@ -342,6 +342,20 @@ __device__ __forceinline__ float max_over_32(float v) {
   v = fmaxf(v, dpp_perm<0x140>(v));  // row_mirror
   return fmaxf(v, __shfl_xor(v, 16));
 }
+// The maximum of lanes 0..31 as a wave-uniform value, without the LDS round trip of the cross-row shuffle above: the
+// four in-row steps, then row 0's lane 15 into row 1 (DPP row_bcast:15) and lane 31 read back.  max() is exact and
+// order-free.
+__device__ __forceinline__ float max_of_lanes_0_31(float v) {
+  v = fmaxf(v, dpp_perm<0xB1>(v));
+  v = fmaxf(v, dpp_perm<0x4E>(v));
+  v = fmaxf(v, dpp_perm<0x141>(v));
+  v = fmaxf(v, dpp_perm<0x140>(v));
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+}
 
 // What the orientation stage computes from the keypoint's fields alone -- nothing that reads the patch: the Gaussian
 // window's table (into S.gauss) and the lattice shortcut's test and weights.  A function of its own so that
@@ -531,10 +545,9 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, const Ori
   // The reference's thread 0 scans the 32 peaks for the first strict maximum (cuSIFT_D.cu:369-379):
   // maxval1 = max(0, max pk), i1 = first index that attains it, -1 if no peak is positive.  Same result from a
   // wave reduction + ballot (pk is never NaN: it comes out of ordered comparisons).
-  const float maxval1 = max_over_32(pk);  // both halves hold the same 32 values and reduce among themselves
-  const unsigned long long hit = __ballot(tx < 32 && pk == maxval1 && maxval1 > 0.0f);
+  const float mv = max_of_lanes_0_31(pk);  // wave-uniform (both halves hold the same 32 values)
+  const unsigned long long hit = __ballot(tx < 32 && pk == mv && mv > 0.0f);
   const int i1 = hit ? (int)__builtin_ctzll(hit) : -1;
-  const float mv = uniform(maxval1);  // lane 0's value = the maximum of lanes 0..31
   const int smi = __builtin_bit_cast(int, sm);
   const float val1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(smi, (i1 + 1) & 31));
   const float val2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(smi, (i1 + 31) & 31));
