@@ -453,7 +453,8 @@ class Context:
                                          d_counter, subsampling, tex_frac_bits, root_sift, d_flags))
 
     def math_eval(self, op, d_a, d_b, d_out, d_out2, n):
-        """cusift_math_eval: op 0 expf, 1 exp2f, 2 atan2f(a, b), 3 sincosf -> (out, out2); device pointers."""
+        """cusift_math_eval: op 0 expf, 1 exp2f, 2 atan2f(a, b), 3 sincosf -> (out, out2), 4 the descriptor's angle
+        coordinate of (dy = a, dx = b); device pointers."""
         check(lib().cusift_math_eval(self.handle, op, d_a, d_b, d_out, d_out2, n))
 
     def rootsift(self, d_points, num_pts):

@@ -625,7 +625,9 @@ __device__ __forceinline__ float desc_sqrtf(float x) { return __builtin_amdgcn_s
 // 8.0 the reference's index becomes 8 and the share lands in the next cell (cuSIFT_D.cu:233-255) -- a jump, at |atan2f| =
 // 3.1415, t = 9.3e-5 from the negative x axis.  There atan t == t in sm_atan2f and here alike (the cubic term is below
 // half an ulp), and (pi_hi - t) + pi_lo, the product with 4/3.1415f and the + 4 are the reference's operations: the same
-// bits.  ((dy = +0, dx < 0) gives 8.000118, (dy = -0, dx < 0) -0.000118; a zero gradient's 0 * inf comes out finite, its
+// bits -- but for the last ulp of t itself, which is v_rcp_f32's quotient here as it was before the fit (a pair of
+// gradients whose exact quotient lies within 7e-12 of the threshold can land on the other side: ~1e-12 of an image's
+// samples; tests/test_gpu_parity.py::test_descriptor_angle_coordinate counts them in a sample dense at the jump).  ((dy = +0, dx < 0) gives 8.000118, (dy = -0, dx < 0) -0.000118; a zero gradient's 0 * inf comes out finite, its
 // weight is 0.)  (Measured and dropped: the octant fix-ups in units of bins, three instructions fewer, with the value
 // near pi re-formed behind a ballot-skipped branch -- the branch splits the four samples' straight-line code and costs
 // more than it saves.)
@@ -1484,7 +1486,8 @@ __global__ void __launch_bounds__(64) pack_points_compact_kernel(const cusift_po
 // ------------------------------------------------------------------------------------------------
 // The written-out transcendental functions of sift_math.h evaluated on the device, array form (cusift_math_eval):
 // lets a test compare the device's results with the host's bit for bit.  op 0 expf(a), 1 exp2f(a), 2 atan2f(a, b),
-// 3 sincosf(a) -> (out, out2).
+// 3 sincosf(a) -> (out, out2); op 4: the DESCRIPTOR's angle coordinate desc_angle_bins(a = dy, b = dx), which is not
+// sm_atan2f to the ulp (a test prices its distance and checks the one decision it carries).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) math_eval_kernel(int op, const float *__restrict__ a,
                                                        const float *__restrict__ b, float *__restrict__ out,
@@ -1493,6 +1496,7 @@ __global__ void __launch_bounds__(256) math_eval_kernel(int op, const float *__r
     if (op == 0) out[i] = sm_expf(a[i]);
     else if (op == 1) out[i] = sm_exp2f(a[i]);
     else if (op == 2) out[i] = sm_atan2f(a[i], b[i]);
+    else if (op == 4) out[i] = desc_angle_bins(a[i], b[i]);
     else {
       float s, c;
       sm_sincosf(a[i], &s, &c);

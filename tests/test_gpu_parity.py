@@ -89,6 +89,54 @@ def test_math_device_equals_host(ctx, oracle):
             buf.free()
 
 
+def test_descriptor_angle_coordinate(ctx, oracle):
+    """The descriptor stage's angle coordinate (sift_keypoints.hip: desc_angle_bins, cusift_math_eval op 4) is NOT the
+    oracle's 4/3.1415f * atan2f + 4 to the ulp -- its effect on a descriptor is continuous, so it is a degree-4 fit -- except
+    where it decides: at 8.0 the reference's index becomes 8 and the share lands in the next cell (cuSIFT_D.cu:233-255).
+    So: within 6e-6 of the oracle's value everywhere, and the SAME side of 8.0 (and of every other integer that close to
+    the negative x axis) for every input -- with the operands that sit on the jump sampled densely."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    dy = (rng.normal(0, 1, n) * np.exp(rng.uniform(-6, 6, n))).astype(np.float32)
+    dx = (rng.normal(0, 1, n) * np.exp(rng.uniform(-6, 6, n))).astype(np.float32)
+    # next to the negative x axis, both signs of dy: |dy| / |dx| from 0 to 3e-4 (the jump sits at 9.27e-5) ...
+    ax = np.exp(rng.uniform(-5, 5, n)).astype(np.float32)
+    t = rng.uniform(0.0, 3.0e-4, n)
+    near_dy = (t * ax * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    # ... and the jump itself, densely
+    t2 = rng.uniform(9.2e-5, 9.35e-5, n)
+    jump_dy = (t2 * ax).astype(np.float32)
+    axis = np.array([0.0, -0.0, 1e-30, -1e-30], dtype=np.float32)
+    a = np.concatenate([dy, near_dy, jump_dy, np.repeat(axis, 4), np.float32([1.0, -1.0, 1.0, -1.0])])
+    b = np.concatenate([dx, -ax, -ax, np.tile(np.float32([-1.0, -3.5, -100.0, -1e-3]), 4), np.float32([1.0, 1.0, -1.0, -1.0])])
+    d_a, d_b = DeviceBuffer.from_numpy(ctx, a), DeviceBuffer.from_numpy(ctx, b)
+    d_o = DeviceBuffer(ctx, a.nbytes)
+    ctx.math_eval(4, d_a.ptr, d_b.ptr, d_o.ptr, None, a.size)
+    ctx.synchronize()
+    got = d_o.to_numpy(np.float32, a.shape)
+    th = oracle.math_eval("atan2", a, b)  # sm_atan2f, the oracle's and the orientation stage's
+    want = (np.float32(4.0) / np.float32(3.1415)) * th + np.float32(4.0)  # float32 throughout, as cuSIFT_D.cu:233 / the oracle
+    assert want.dtype == np.float32
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert err.max() < 6e-6, (err.max(), a[err.argmax()], b[err.argmax()])
+    near = slice(n, a.size - 4)  # everything next to the negative x axis (elsewhere an integer crossed is a continuous event)
+    # (int) truncates, as the kernels' v_cvt_i32_f32.  The quotient |dy| / |dx| is v_rcp_f32's (1 ulp, as it was before the
+    # fit): a pair whose exact quotient lies within an ulp (7e-12) of the threshold may land on the other side -- ~5e-6 of
+    # a sample as dense as this one (2^20 operands within 1.5e-6 of the jump), ~1e-12 of an image's gradients
+    flips = int((got[near].astype(np.int32) != want[near].astype(np.int32)).sum())
+    assert flips <= 20, flips
+    np.testing.assert_array_equal(got[n:2 * n].astype(np.int32)[np.abs(t - 9.27e-5) > 1e-6],
+                                  want[n:2 * n].astype(np.int32)[np.abs(t - 9.27e-5) > 1e-6])
+    eight = want >= 8.0
+    assert 0.2 < eight[2 * n:3 * n].mean() < 0.8  # the dense sample straddles the jump
+    assert (got[near].view(np.uint32) == want[near].view(np.uint32)).mean() > 0.999  # the reference's own operations there
+    print("descriptor angle coordinate: largest distance to the oracle's %.2e of a bin; index 8 for %d of %d operands at the "
+          "jump, %d of all %d near the axis on the other side of it than the oracle" %
+          (err.max(), int(eight[2 * n:3 * n].sum()), n, flips, 2 * n))
+    for buf in (d_a, d_b, d_o):
+        buf.free()
+
+
 # ------------------------------------------------------------------------------------------------
 # ScaleDown
 # ------------------------------------------------------------------------------------------------
