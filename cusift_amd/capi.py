@@ -162,6 +162,7 @@ SIGNATURES = {
     "cusift_laplace_taps": (_i, [_f, _vp]),
     "cusift_find_points_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _vp, _i, _vp, _i]),
     "cusift_detect_multi": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _f, _vp, _i, _vp, _i]),
+    "cusift_detect_multi_down": (_i, [_vp, _vp, _i, _i, _i, _sz, _f, _f, _f, _f, _vp, _i, _vp, _i, _vp, _i, _sz, _f]),
     "cusift_compute_orientations": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _i, _i]),
     "cusift_extract_descriptors": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _vp, _vp, _f, _i, _i]),
     "cusift_rootsift": (_i, [_vp, _vp, _i]),
@@ -264,7 +265,7 @@ def ialign_up(a, b):
 
 # cusift_ctx_set_policy keys (include/cusift_amd.h)
 POLICY_SIDE_STREAM, POLICY_OCTAVE_LISTS, POLICY_GENERIC_KERNELS, POLICY_LAUNCH_PER_OCTAVE, POLICY_MATCH_SPLITS, \
-    POLICY_TILED_PER_OCTAVE = range(6)
+    POLICY_TILED_PER_OCTAVE, POLICY_PYRAMID_IN_DETECT = range(7)
 
 
 class Context:
@@ -423,6 +424,15 @@ class Context:
         img_stride = h * pitch if img_stride is None else img_stride
         check(lib().cusift_detect_multi(self.handle, d_img, w, h, pitch, img_stride, init_blur, peak_thresh,
                                         edge_thresh, subsampling, d_points, max_pts, d_counters, n_images))
+
+    def detect_multi_down(self, d_img, w, h, pitch, init_blur, peak_thresh, edge_thresh, subsampling, d_heads, max_pts,
+                          d_counters, d_next, next_pitch, n_images=1, img_stride=None, next_stride=None, variance=0.5):
+        """cusift_detect_multi_down: the fused detection (keypoint HEADS, 64 bytes each) + the next octave's image."""
+        img_stride = h * pitch if img_stride is None else img_stride
+        next_stride = (h // 2) * next_pitch if next_stride is None else next_stride
+        check(lib().cusift_detect_multi_down(self.handle, d_img, w, h, pitch, img_stride, init_blur, peak_thresh,
+                                             edge_thresh, subsampling, d_heads, max_pts, d_counters, n_images, d_next,
+                                             next_pitch, next_stride, variance))
 
     def compute_orientations(self, d_img, w, h, pitch, d_points, max_pts, d_first, d_counters, tex_frac_bits=8,
                              n_images=1, img_stride=None):

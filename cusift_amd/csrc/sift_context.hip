@@ -46,6 +46,7 @@ Knobs read_knobs() {
   k.match_splits = num("CUSIFT_MATCH_SPLITS", 0);
   k.stage_all = num("CUSIFT_STAGE_ALL", -1);
   k.no_multi = text("CUSIFT_NO_MULTI") != nullptr;
+  k.pyramid_in_detect = num("CUSIFT_PYRAMID_IN_DETECT", -1);
 #endif
   return k;
 }
@@ -299,7 +300,24 @@ bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_imag
   if (!prm || !prm->fused_detect || n_images < 1 || n_images > kMaxFlatImages) return false;
   if (ctx->knobs.stage_all > 0) return true;  // tests: whenever the lists fit
   if (ctx->timing) return false;  // the stage timers bracket the reference's launch-per-octave sequence
+  if (wants_pyramid_in_detect(ctx, prm, n_images, w, h) > 0) return true;  // finest first needs a list per octave
   return prm->concurrent_batches < 2 || (size_t)n_images * (size_t)w * (size_t)h <= kListsMaxPixelsPipelined;
+}
+
+// The pyramid as a by-product of the detection (CUSIFT_POLICY_PYRAMID_IN_DETECT; detect_fused_kernel<.., kDown>): octave
+// o's detection writes octave o + 1's image from its own row window, so the ScaleDown launches -- 0.2 ms of HBM-bound
+// re-reading per 64 x 1080p, a fifth of a lone caller's step -- disappear for ~5 % more vector instructions in the
+// detection, and the octaves are searched finest first (lists per octave).  What it costs is the one-launch detection
+// of the coarser octaves: a chain of dependent launches has a tail per octave.  So by default: calls of at least
+// kPyramidInDetectMinPixels, every octave.  0: never; 1: octave 0 only; 2: every octave.
+constexpr size_t kPyramidInDetectMinPixels = 6u << 20;
+int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h) {
+  const int mode = ctx->knobs.pyramid_in_detect;
+  if (mode == 0 || ctx->knobs.force_generic || ctx->knobs.stage_all == 0) return 0;
+  if (!prm || !prm->fused_detect || prm->num_octaves < 2 || n_images < 1 || n_images > kMaxFlatImages) return 0;
+  if (ctx->timing) return 0;  // the stage timers bracket the reference's launch-per-octave sequence
+  if (mode > 0) return std::min(mode, 2);
+  return (size_t)n_images * (size_t)w * (size_t)h >= kPyramidInDetectMinPixels ? 2 : 0;
 }
 
 // OPT-IN since round 4 (cusift_ctx_set_policy(ctx, CUSIFT_POLICY_SIDE_STREAM, 1 | 2), or CUSIFT_OCTAVE_OVERLAP=1 | 2 in the
@@ -548,6 +566,10 @@ extern "C" int cusift_ctx_set_policy(cusift_ctx *ctx, int key, int value) {
       k.match_splits = value;
       return CUSIFT_OK;
     case CUSIFT_POLICY_TILED_PER_OCTAVE: k.tiled_per_octave = value != 0; return CUSIFT_OK;
+    case CUSIFT_POLICY_PYRAMID_IN_DETECT:
+      if (value < -1 || value > 2) return fail(CUSIFT_ERR_INVALID, "CUSIFT_POLICY_PYRAMID_IN_DETECT: -1, 0, 1 or 2");
+      k.pyramid_in_detect = value;
+      return CUSIFT_OK;
   }
   return fail(CUSIFT_ERR_INVALID, "unknown policy key %d", key);
 }
@@ -562,6 +584,7 @@ extern "C" int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value) {
     case CUSIFT_POLICY_LAUNCH_PER_OCTAVE: *value = k.no_multi; return CUSIFT_OK;
     case CUSIFT_POLICY_MATCH_SPLITS: *value = k.match_splits; return CUSIFT_OK;
     case CUSIFT_POLICY_TILED_PER_OCTAVE: *value = k.tiled_per_octave; return CUSIFT_OK;
+    case CUSIFT_POLICY_PYRAMID_IN_DETECT: *value = k.pyramid_in_detect; return CUSIFT_OK;
   }
   return fail(CUSIFT_ERR_INVALID, "unknown policy key %d", key);
 }
@@ -643,7 +666,7 @@ extern "C" int cusift_kernel_occupancy(const char *kernel, int *blocks_per_cu, i
   int n = 0, t = 256;
   hipError_t e = hipErrorInvalidValue;
   if (k == "detect_fused")  // single-wave workgroups, a 10.5 KB candidate list each
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false, (int)sizeof(cusift_point)>, t = 64,
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, detect_fused_kernel<false, (int)sizeof(cusift_point), false>, t = 64,
                                                      kDetectWaveLdsFloats * sizeof(float));
   else if (k == "laplace_multi") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, laplace_multi_fast_kernel<0>, t, 0);
   else if (k == "find_points") e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, find_points_fast_kernel, t, 0);

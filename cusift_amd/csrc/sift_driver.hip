@@ -90,13 +90,23 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     G.base[1] = reinterpret_cast<const char *>(list_of(0));
     G.count[1] = seg_counts;
   }
+  // The pyramid as a by-product of the detection (CUSIFT_POLICY_PYRAMID_IN_DETECT): octaves [0, chain_end) are searched
+  // finest first by detections that also write the next octave's image -- images 1 .. chain_end come from there, not
+  // from ScaleDown launches.  Needs a list per octave (the detections no longer run in list order) and octave 0 on the
+  // context's own stream (octave 1 waits for it anyway).
+  int chain_end = 0;
+  if (stage_all && !forked) {
+    const int mode = wants_pyramid_in_detect(ctx, prm, n_images, w, h);
+    while (chain_end < pl.n_oct - 1 && (mode == 2 || (mode == 1 && chain_end == 0)) && searched(chain_end)) ++chain_end;
+  }
   // A small call's dispatches are most of its time, so its housekeeping rides along: the ScaleDown chain in one launch
   // (which also clears the lists' counters), all octaves in one detection launch (which also clears describe_all's work
   // cursors), and describe_all_kernel joins the lists itself -- pyramid, detection, description: three dispatches.
-  const bool small_pyramid = pl.n_oct >= 2 && wants_small_pyramid(ctx, n_images, w, h);
+  const bool small_pyramid = pl.n_oct >= 2 && chain_end == 0 && wants_small_pyramid(ctx, n_images, w, h);
+  const int first_rest = std::max(forked ? 1 : 0, chain_end);  // the octaves from here on: the ScaleDown chain, then searched
   int n_one_launch = 0;  // octaves the one detection launch would take
   if (stage_all && !ctx->knobs.no_multi)
-    for (int o = forked ? 1 : 0; o < pl.n_oct && n_one_launch < kMaxMultiOctaves; ++o) n_one_launch += searched(o) ? 1 : 0;
+    for (int o = first_rest; o < pl.n_oct && n_one_launch < kMaxMultiOctaves; ++o) n_one_launch += searched(o) ? 1 : 0;
   const bool one_launch = n_one_launch >= 2;
   const bool self_join = stage_all && one_launch;              // no join_counts_kernel: describe_all_kernel joins
   const bool pyramid_clears = small_pyramid && stage_all && !forked;  // (a forked octave 0 may count before the pyramid runs)
@@ -127,6 +137,17 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   auto on_main = [&]() -> int {
     // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest -- a small call's first levels in one launch
     int built = 0;
+    for (int o = 0; o < chain_end; ++o) {  // finest first: octave o's detection writes octave o + 1
+      DownOut dn;
+      dn.dst = const_cast<float *>(base[o + 1]);
+      dn.pitch = pl.p[o + 1];
+      dn.stride = (long)stride[o + 1];
+      scale_down_taps(dn.T, 0.5f);  // cuSIFT.cu:185
+      TRY(detect_impl(ctx, base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], prm->peak_thresh,
+                      prm->edge_thresh, pl.sub[o], list_of(o), prm->max_pts, seg_counts + (size_t)o * n_images, n_images,
+                      RowWindow{0, pl.h[o]}, 0, pl.h[o], prm->concurrent_batches, true, false, &dn));
+      built = o + 1;
+    }
     if (small_pyramid) {
       built = std::min(pl.n_oct - 1, kMaxPyramidLevels);
       TRY(pyramid_small_impl(ctx, base, pl.w, pl.h, pl.p, stride, built, n_images, 0.5f,
@@ -140,7 +161,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     if (one_launch) {
       MultiOctave mo[kMaxMultiOctaves];
       int n_mo = 0;
-      for (int o = forked ? 1 : 0; o < pl.n_oct && n_mo < kMaxMultiOctaves; ++o)
+      for (int o = first_rest; o < pl.n_oct && n_mo < kMaxMultiOctaves; ++o)
         if (searched(o)) {
           mo[n_mo++] = MultiOctave{base[o], pl.w[o], pl.h[o], pl.p[o], stride[o], (float)pl.blur[o], pl.sub[o], list_of(o),
                                    seg_counts + (size_t)o * n_images};
@@ -150,7 +171,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
                             forked ? 1 : prm->concurrent_batches, ctx->d_queue));
     }
     // ... and search it coarsest first (the recursion unwinds: cuSIFT.cu:190-196)
-    for (int o = pl.n_oct - 1; o >= (forked ? 1 : 0); --o) {
+    for (int o = pl.n_oct - 1; o >= first_rest; --o) {
       if (!searched(o) || in_one_launch[o]) continue;
       // ExtractSiftOctave, cuSIFT.cu:204-270
       unsigned int *fst = first + (size_t)o * n_images;  // cuSIFT.cu:243 (fstPts), kept on the device

@@ -32,9 +32,9 @@ template <int kStoreAux>
 __global__ void laplace_multi_fast_kernel(const float *, float *, int, int, int, long, long, int, LaplaceTapsPk);
 __global__ void find_points_fast_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
                                         FindParams);
-template <bool kIdent0, int kRecBytes>
+template <bool kIdent0, int kRecBytes, bool kDown>
 __global__ void detect_fused_kernel(const float *, int, int, int, long, cusift_point *, int, unsigned int *, int,
-                                    LaplaceTapsPk, FindParams, RowWindow, int, int);
+                                    LaplaceTapsPk, FindParams, RowWindow, int, int, DownOut);
 template <int kRecBytes>
 __global__ void detect_multi_kernel(DetectTable, int, unsigned int *);
 __global__ void pyramid_small_kernel(PyramidLevels, ScaleDownTaps, unsigned int *, int);
@@ -117,6 +117,7 @@ struct Knobs {
   bool no_multi = false;                             // CUSIFT_POLICY_LAUNCH_PER_OCTAVE: the coarser octaves one launch each, even with lists
   int match_splits = 0;                              // CUSIFT_POLICY_MATCH_SPLITS
   bool tiled_per_octave = false;                     // CUSIFT_POLICY_TILED_PER_OCTAVE (read by cusift_tiled_create)
+  int pyramid_in_detect = -1;                        // CUSIFT_POLICY_PYRAMID_IN_DETECT: -1 by size, 0 never, 1 octave 0, 2 every octave
   // ---- tuning (CUSIFT_LAB builds only) ----
   int rows_per_wave = 0;                             // CUSIFT_ROWS_PER_WAVE: every stencil stage
   int rows_lo[kKnobStages] = {0}, rows_hi[kKnobStages] = {0};  // CUSIFT_<STAGE>_ROWS_LO / _HI
@@ -246,6 +247,7 @@ int check_launch(const char *what);
 bool wants_side_stream(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h);
 size_t stage_all_limit(const cusift_ctx *ctx);
 bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h);
+int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h);
 int ensure_side_stream(cusift_ctx *ctx);
 int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool borrow);
 size_t bands_arena_bytes(int n_bands, int max_pts);
@@ -254,7 +256,7 @@ bool wants_small_pyramid(const cusift_ctx *ctx, int n_images, int w, int h);
 int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const int *w, const int *h, const int *pitch, const size_t *stride, int n_levels, int n_images, float variance, unsigned int *d_zero, int n_zero);
 bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t img_stride);
 int detect_rows(const cusift_ctx *ctx, int rows_total, int strips, int n_images, int concurrent);
-int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur, float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end, int concurrent = 1, bool heads = false, bool side = false);
+int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur, float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end, int concurrent = 1, bool heads = false, bool side = false, const DownOut *down = nullptr);
 int detect_multi_impl(cusift_ctx *ctx, const MultiOctave *octaves, int n_octaves, float peak_thresh, float edge_thresh, int max_pts, int n_images, int concurrent, unsigned int *d_queue);
 int keypoint_grid_x(int max_pts, int n_images);
 int orientations_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, cusift_point *d_points, int max_pts, const unsigned int *d_first, const unsigned int *d_counters, int tex_frac_bits, int n_images, RowWindow rw);

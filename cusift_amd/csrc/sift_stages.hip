@@ -294,9 +294,10 @@ int detect_rows(const cusift_ctx *ctx, int rows_total, int strips, int n_images,
 int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
                        float peak_thresh, float edge_thresh, float subsampling, cusift_point *d_points, int max_pts,
                        unsigned int *d_counters, int n_images, RowWindow rw, int cy_begin, int cy_end,
-                       int concurrent, bool heads, bool side) {
+                       int concurrent, bool heads, bool side, const DownOut *down) {
   // heads: `d_points` is a staging list of the context (kStagedRecBytes per keypoint); side: the launch goes to the
-  // context's side stream (cusift_extract_batch)
+  // context's side stream (cusift_extract_batch); down: the kernel also writes the next octave's image (heads only,
+  // whole images only: see down_emit_ok)
   TRY(enter(ctx));
   if (!d_img || !d_points || !d_counters) return fail(CUSIFT_ERR_INVALID, "DetectMulti: missing data");
   if (n_images < 1 || w < 1 || h < 1 || pitch < w || max_pts < 1)
@@ -325,7 +326,13 @@ int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, si
   // several streams -- the throughput mode -- the other batches' kernels fill the tail and taller chunks win: two
   // streams 0.05 -> 1.451, 0.08 -> 1.414 ms per step; four streams 0.05 -> 1.414, 0.08 -> 1.370, 0.1 -> 1.379,
   // 0.13 -> 1.382.  The caller says which case it is (cusift_params.concurrent_batches).
-  const int rows = detect_rows(ctx, rows_total, strips, n_images, concurrent);
+  int rows = detect_rows(ctx, rows_total, strips, n_images, concurrent);
+  if (down) {
+    if (!heads || rw.row0 != 0 || rw.hg != h || cy_begin != 0 || cy_end != h || !down->dst || h / 2 < 1 || w / 2 < 1 ||
+        (down->pitch % 2) != 0 || (down->stride % 2) != 0 || (((uintptr_t)down->dst) % 8) != 0 || down->pitch < w / 2)
+      return fail(CUSIFT_ERR_INVALID, "DetectMulti: the next octave can only be emitted from a whole image into a staged list, 8-byte aligned rows");
+    rows = std::max(rows, 2);  // the chunk [0, rows) clipped to [1, h-1) must not be empty: it owns output row 0
+  }
   // Single-wave workgroups: a workgroup's wave slots and LDS are released only when its slowest wave ends, and the
   // threshold pre-test makes the waves' run times uneven -- measured 64x1080p, r = 16: 4 waves per workgroup 0.693 ms,
   // 2: 0.645 ms, 1: 0.630 ms (tools/probe_rows.py with CUSIFT_DETECT_WAVES).
@@ -340,10 +347,14 @@ int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, si
   StageTimer t(ctx, CUSIFT_STAGE_DETECT);
   constexpr int kWhole = (int)sizeof(cusift_point);
   const bool ident = ident0 && !ctx->knobs.no_ident;
-  auto kernel = heads ? (ident ? detect_fused_kernel<true, kStagedRecBytes> : detect_fused_kernel<false, kStagedRecBytes>)
-                      : (ident ? detect_fused_kernel<true, kWhole> : detect_fused_kernel<false, kWhole>);
+  auto kernel = down ? (ident ? detect_fused_kernel<true, kStagedRecBytes, true> : detect_fused_kernel<false, kStagedRecBytes, true>)
+              : heads ? (ident ? detect_fused_kernel<true, kStagedRecBytes, false> : detect_fused_kernel<false, kStagedRecBytes, false>)
+                      : (ident ? detect_fused_kernel<true, kWhole, false> : detect_fused_kernel<false, kWhole, false>);
+  DownOut dn;
+  memset(&dn, 0, sizeof(dn));
+  if (down) dn = *down;
   hipLaunchKernelGGL(kernel, grid, dim3(64 * wpb), cube_bytes, side ? ctx->side : ctx->stream, d_img, w, h, pitch,
-                     (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end);
+                     (long)img_stride, d_points, max_pts, d_counters, rows, TP, P, rw, cy_begin, cy_end, dn);
   return check_launch("detect_multi");
 }
 
@@ -405,6 +416,24 @@ extern "C" int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, i
                                    cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images) {
   return detect_impl(ctx, d_img, w, h, pitch, img_stride, init_blur, peak_thresh, edge_thresh, subsampling, d_points,
                      max_pts, d_counters, n_images, RowWindow{0, h}, 0, h);
+}
+
+extern "C" int cusift_detect_multi_down(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                                        float init_blur, float peak_thresh, float edge_thresh, float subsampling,
+                                        void *d_heads, int max_pts, unsigned int *d_counters, int n_images,
+                                        float *d_next, int next_pitch, size_t next_stride, float variance) {
+  if (!d_next) return fail(CUSIFT_ERR_INVALID, "DetectMulti (down): d_next is NULL");
+  if (!(variance > 0.0f)) return fail(CUSIFT_ERR_INVALID, "ScaleDown: variance must be > 0");
+  if (n_images > 1 && next_stride < (size_t)(h / 2) * next_pitch)
+    return fail(CUSIFT_ERR_INVALID, "DetectMulti (down): next_stride too small");
+  DownOut dn;
+  dn.dst = d_next;
+  dn.pitch = next_pitch;
+  dn.stride = (long)next_stride;
+  scale_down_taps(dn.T, variance);
+  return detect_impl(ctx, d_img, w, h, pitch, img_stride, init_blur, peak_thresh, edge_thresh, subsampling,
+                     reinterpret_cast<cusift_point *>(d_heads), max_pts, d_counters, n_images, RowWindow{0, h}, 0, h, 1, true,
+                     false, &dn);
 }
 
 extern "C" int cusift_detect_band(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, int row0, int h_global,

@@ -294,6 +294,34 @@ template __global__ void laplace_multi_fast_kernel<18>(const float *, float *, i
 // ------------------------------------------------------------------------------------------------
 constexpr int kDownStrip = 62 * 2;  // output columns per wave
 
+// Horizontal 5-tap of ScaleDown (cuSIFT_D.cu:111-113) for a lane that holds source columns c..c+3 (c % 4 == 0) of one row:
+// output columns c/2 (centre c) and c/2+1 (centre c+2); columns c-2, c-1 and c+4 come from the neighbouring lanes by DPP.
+// Shared by scale_down_fast_kernel and by the fused detection when it emits the next octave (detect_chunk.inc): the
+// same operations in the same order on the same values, so the same bits whichever kernel produces a pixel.
+__device__ __forceinline__ f2 down_hrow(const f4 v, float k0, float k1, float k2) {
+  const float m2 = from_prev_lane(v.z), m1 = from_prev_lane(v.w), p4 = from_next_lane(v.x);
+  float a = k0 * (m2 + v.z);
+  a = fmaf(k1, m1 + v.y, a);
+  a = fmaf(k2, v.x, a);
+  float b = k0 * (v.x + p4);
+  b = fmaf(k1, v.y + v.w, b);
+  b = fmaf(k2, v.z, b);
+  return f2{a, b};
+}
+// Vertical pass (cuSIFT_D.cu:123-125): k2*B[2r] + k0*(B[2r+3]+B[2r+2]) + k1*(B[2r-1]+B[2r+1]) -- the reference's
+// asymmetric support (yRead = yStart + tx - 1, cuSIFT_D.cu:75).
+__device__ __forceinline__ f2 down_vcol(f2 bm1, f2 b0, f2 bp1, f2 bp2, f2 bp3, float k0, float k1, float k2) {
+  f2 v;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float t = k2 * b0[j];
+    t = fmaf(k0, bp3[j] + bp2[j], t);
+    t = fmaf(k1, bm1[j] + bp1[j], t);
+    v[j] = t;
+  }
+  return v;
+}
+
 __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict__ dst, int dst_pitch, long dst_stride,
                                                              const float *__restrict__ src, int w, int h,
                                                              int src_pitch, long src_stride, int rows_per_wave,
@@ -328,16 +356,7 @@ __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict_
     return edge(__builtin_bit_cast(f4, raw));
   };
   // horizontal 5-tap of one source row for output columns o0 (centre 4l) and o0+1 (centre 4l+2)
-  auto hrow = [&](const f4 v) -> f2 {
-    const float m2 = from_prev_lane(v.z), m1 = from_prev_lane(v.w), p4 = from_next_lane(v.x);
-    float a = k0 * (m2 + v.z);
-    a = fmaf(k1, m1 + v.y, a);
-    a = fmaf(k2, v.x, a);
-    float b = k0 * (v.x + p4);
-    b = fmaf(k1, v.y + v.w, b);
-    b = fmaf(k2, v.z, b);
-    return f2{a, b};
-  };
+  auto hrow = [&](const f4 v) -> f2 { return down_hrow(v, k0, k1, k2); };
 
   f2 bm1 = hrow(load_row(2 * r0 - 1)), b0 = hrow(load_row(2 * r0)), bp1 = hrow(load_row(2 * r0 + 1));
   f4 n2 = load_row(2 * r0 + 2), n3 = load_row(2 * r0 + 3);
@@ -346,14 +365,7 @@ __global__ void __launch_bounds__(256) scale_down_fast_kernel(float *__restrict_
     n2 = load_row(2 * r + 4);  // next iteration's rows, requested now
     n3 = load_row(2 * r + 5);
     const f2 bp2 = hrow(s2), bp3 = hrow(s3);
-    f2 v;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float t = k2 * b0[j];
-      t = fmaf(k0, bp3[j] + bp2[j], t);
-      t = fmaf(k1, bm1[j] + bp1[j], t);
-      v[j] = t;
-    }
+    const f2 v = down_vcol(bm1, b0, bp1, bp2, bp3, k0, k1, k2);
     const __amdgpu_buffer_rsrc_t ro =
         __builtin_amdgcn_make_buffer_rsrc((void *)(dst + (long)(r - dst_row0) * dst_pitch), 0, ow * 4, kBufFlags);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), ro, voff_out, 0, 0);
@@ -860,12 +872,18 @@ struct CandList {
   }
 };
 
-template <bool kIdent0, int kRecBytes>
+// kDown: the kernel also EMITS THE NEXT OCTAVE'S IMAGE (ScaleDown, cuSIFT.cu:185 / cuSIFT_D.cu:37-182) as a by-product:
+// the source rows 2r-1 .. 2r+3 and columns 2c-2 .. 2c+2 an output pixel reads are inside the 9-row window (and its
+// neighbouring lanes) that the blur streams through anyway, so the pyramid costs no second read of the image and no
+// launch of its own.  The wave whose chunk holds source row 2r (as an unclipped chunk row) owns output row r; a lane
+// owns the two output columns under its four source columns.  Whole images only (rw = {0, h}); same operations as
+// scale_down_fast_kernel (down_hrow / down_vcol), so the same bits.
+template <bool kIdent0, int kRecBytes, bool kDown>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) detect_fused_kernel(const float *__restrict__ img, int w, int h, int pitch,
                                                           long img_stride, cusift_point *__restrict__ points,
                                                           int max_pts, unsigned int *__restrict__ counters,
                                                           int rows_per_wave, LaplaceTapsPk T, FindParams P,
-                                                          RowWindow rw, int cy_begin, int cy_end) {
+                                                          RowWindow rw, int cy_begin, int cy_end, DownOut down) {
   extern __shared__ float s_cands[];  // [waves per workgroup][kDetectWaveLdsFloats]: the wave's candidate list
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: uniform, say so
@@ -881,6 +899,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) d
   char *const list = reinterpret_cast<char *>(points) + (size_t)bz * max_pts * kRecBytes;
   unsigned int *counter = counters + bz;
   CandList cands{s_cands + wv * kDetectWaveLdsFloats, 0};
+  // (kDown) this wave owns the output rows r with own_lo <= 2r < own_hi: its chunk before the clipping to [1, h-1)
+  const int own_lo = gy0, own_hi = gy0 + rows_per_wave;
+  float *const down_img = kDown ? down.dst + (long)bz * down.stride : nullptr;
+  const int down_pitch = down.pitch;
+  const ScaleDownTaps DT = down.T;
 
 #include "detect_chunk.inc"
 }
@@ -1036,6 +1059,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) de
   CandList cands{s_cands, 0};
   const LaplaceTapsPk &T = O.T;
   const FindParams &P = O.P;
+  // (this launch searches octaves whose images exist already: nothing is emitted)
+  constexpr bool kDown = false;
+  constexpr int own_lo = 0, own_hi = 0, down_pitch = 0;
+  float *const down_img = nullptr;
+  const ScaleDownTaps DT{};
   if (O.ident) {  // wave-uniform; both bodies live in this kernel, a wave runs one
     constexpr bool kIdent0 = true;
 #include "detect_chunk.inc"
@@ -1047,14 +1075,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) de
 
 template __global__ void detect_multi_kernel<kStagedRecBytes>(DetectTable, int, unsigned int *);
 
-#define CUSIFT_DETECT_INSTANCE(IDENT, REC)                                                                         \
-  template __global__ void detect_fused_kernel<IDENT, REC>(const float *, int, int, int, long, cusift_point *, int,  \
-                                                           unsigned int *, int, LaplaceTapsPk, FindParams, RowWindow, \
-                                                           int, int);
-CUSIFT_DETECT_INSTANCE(false, (int)sizeof(cusift_point))
-CUSIFT_DETECT_INSTANCE(true, (int)sizeof(cusift_point))
-CUSIFT_DETECT_INSTANCE(false, kStagedRecBytes)
-CUSIFT_DETECT_INSTANCE(true, kStagedRecBytes)
+#define CUSIFT_DETECT_INSTANCE(IDENT, REC, DOWN)                                                                     \
+  template __global__ void detect_fused_kernel<IDENT, REC, DOWN>(const float *, int, int, int, long, cusift_point *,  \
+                                                                 int, unsigned int *, int, LaplaceTapsPk, FindParams, \
+                                                                 RowWindow, int, int, DownOut);
+CUSIFT_DETECT_INSTANCE(false, (int)sizeof(cusift_point), false)
+CUSIFT_DETECT_INSTANCE(true, (int)sizeof(cusift_point), false)
+CUSIFT_DETECT_INSTANCE(false, kStagedRecBytes, false)
+CUSIFT_DETECT_INSTANCE(true, kStagedRecBytes, false)
+// (the next octave can only be emitted when the octaves are searched finest first, i.e. into lists of their own)
+CUSIFT_DETECT_INSTANCE(false, kStagedRecBytes, true)
+CUSIFT_DETECT_INSTANCE(true, kStagedRecBytes, true)
 #undef CUSIFT_DETECT_INSTANCE
 
 }  // namespace cusift

@@ -46,6 +46,14 @@ struct ScaleDownTaps {
   float k[3];  // k0, k1, k2 of cuSIFT.cu:330-341 (k[2] centre)
 };
 
+// Where detect_fused_kernel<.., kDown = true> writes the next octave's image while it searches this one (sift_stencils.hip)
+struct DownOut {
+  float *dst;       // image 0 of the next octave (w/2 x h/2); unused by the kDown = false instantiations
+  int pitch;        // floats (even: float2 stores)
+  long stride;      // floats between images (even)
+  ScaleDownTaps T;  // cuSIFT.cu:330-341
+};
+
 // A device image may be a horizontal band of a larger ("global") image: its local row 0 is global row
 // `row0` and the global image has `hg` rows.  Whole images use {0, h}.  Row addressing everywhere is
 // "clamp to the global image, then translate" so that a band with enough halo rows behaves exactly like

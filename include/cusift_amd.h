@@ -158,7 +158,13 @@ enum {
   CUSIFT_POLICY_GENERIC_KERNELS = 2,   /* 1: the generic (any pitch / alignment) kernels even where the fast ones apply */
   CUSIFT_POLICY_LAUNCH_PER_OCTAVE = 3, /* 1: with lists, still one detection launch per coarser octave */
   CUSIFT_POLICY_MATCH_SPLITS = 4,      /* cusift_match: column splits of the second set (0: by size) */
-  CUSIFT_POLICY_TILED_PER_OCTAVE = 5   /* cusift_tiled_*: one detection + description launch per tiled octave */
+  CUSIFT_POLICY_TILED_PER_OCTAVE = 5,  /* cusift_tiled_*: one detection + description launch per tiled octave */
+  /* The pyramid as a by-product of the detection: the fused detection of octave o writes octave o + 1's image from the
+   * row window it streams through anyway (ScaleDown's arithmetic, cuSIFT_D.cu:37-182, bit for bit), so the octaves are
+   * searched finest first -- into lists of their own, which therefore must fit (CUSIFT_POLICY_OCTAVE_LISTS) -- and no
+   * ScaleDown launch re-reads the images.  -1 by size (default), 0 never (the ScaleDown chain first, as the reference:
+   * cuSIFT.cu:175-192), 1 octave 0 only (then the chain and the coarser octaves as with 0), 2 every octave. */
+  CUSIFT_POLICY_PYRAMID_IN_DETECT = 6
 };
 int cusift_ctx_set_policy(cusift_ctx *ctx, int key, int value);
 int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value);
@@ -248,6 +254,17 @@ int cusift_find_points_multi(cusift_ctx *ctx, const float *d_dog, int w, int h, 
 int cusift_detect_multi(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
                         float init_blur, float peak_thresh, float edge_thresh, float subsampling,
                         cusift_point *d_points, int max_pts, unsigned int *d_counters, int n_images);
+/* cusift_detect_multi that ALSO writes the next octave's image -- ScaleDown (cuSIFT.cu:185,313-353 + ScaleDown_D
+ * cuSIFT_D.cu:37-182: 5 x 5 low-pass of variance `variance` and decimation, the asymmetric vertical taps included), bit
+ * for bit what cusift_scale_down writes -- from the row window the blur streams through anyway: no second read of the
+ * image, no launch of its own.  The keypoints go to a list of 64-byte HEADS (the first 16 floats of a SiftPoint:
+ * coords2D .. subsampling), `max_pts` per image: finest-first detection cannot append to SiftData in list order, the
+ * octave driver joins such lists (cusift_extract_batch with CUSIFT_POLICY_PYRAMID_IN_DETECT).  d_next: (w/2) x (h/2),
+ * next_pitch floats per row (even), next_stride floats between images (even), 8-byte aligned. */
+int cusift_detect_multi_down(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,
+                             float init_blur, float peak_thresh, float edge_thresh, float subsampling, void *d_heads,
+                             int max_pts, unsigned int *d_counters, int n_images, float *d_next, int next_pitch,
+                             size_t next_stride, float variance);
 /* SiftData::ComputeOrientations, cuSIFT.cu:355-365 + ComputeOrientations_D cuSIFT_D.cu:319-396.
  * Processes points [d_first[i], min(d_counters[i], max_pts)) of every image; d_first may be NULL (= 0). */
 int cusift_compute_orientations(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride,

@@ -366,6 +366,70 @@ def test_detect_multi_same_set_as_oracle(ctx, oracle, gray1, w, h, blur, thresh)
     np.testing.assert_array_equal(a["scale"], b["scale"])
 
 
+@pytest.mark.parametrize("w,h,blur,thresh,n", [(640, 480, 0.0, 0.5, 1), (1920, 1080, 1.0, 3.0, 1), (101, 77, 0.0, 0.2, 2),
+                                               (130, 64, 0.5, 0.2, 1), (7, 9, 0.0, 0.01, 1), (256, 17, 0.0, 0.2, 3),
+                                               (4, 4, 0.0, 0.01, 1), (248, 6, 0.0, 0.2, 1), (252, 31, 0.0, 0.2, 1),
+                                               (500, 3, 0.0, 0.2, 2), (960, 540, 0.71, 2.0, 1), (120, 67, 0.0, 0.2, 1),
+                                               (241, 12, 0.0, 0.2, 1), (243, 9, 0.0, 0.2, 1), (481, 5, 0.0, 0.1, 1),
+                                               (1366, 768, 0.0, 1.0, 1), (5, 3, 0.0, 0.01, 1), (239, 200, 1.0, 0.3, 2),
+                                               (722, 131, 0.0, 0.3, 1)])
+def test_detect_multi_down_emits_scale_down_bit_exact(ctx, oracle, gray1, w, h, blur, thresh, n):
+    """The fused detection that also writes the next octave's image (cusift_detect_multi_down: ScaleDown as a by-product
+    of the detection's row window, cuSIFT_D.cu:37-182): the image is the oracle's ScaleDown bit for bit -- odd sizes,
+    ragged widths, widths around a strip border (240 columns), heights of one chunk and of many, batches, nothing written
+    outside (w/2) x (h/2) -- and the keypoint heads are the plain fused detection's records."""
+    if (w, h) == (640, 480):
+        imgs = [gray1]
+    elif (w, h) == (1920, 1080):
+        imgs = [synth.tile(1003, preblur=1.0)]
+    else:
+        imgs = [rand_image(h, w, w * 17 + h + i) for i in range(n)]
+    stack = np.stack([pitched(i) for i in imgs])
+    p = stack.shape[2]
+    ow, oh = w // 2, h // 2
+    op = capi.ialign_up(max(ow, 1), 128)
+    max_pts = 16384
+    d_img = DeviceBuffer.from_numpy(ctx, stack)
+    d_next = DeviceBuffer(ctx, n * oh * op * 4)
+    ctx.memset(d_next.ptr, 0x5A, n * oh * op * 4)
+    d_heads = DeviceBuffer(ctx, n * max_pts * 64)
+    d_heads.zero()
+    d_cnt = DeviceBuffer(ctx, 4 * n)
+    d_cnt.zero()
+    ctx.detect_multi_down(d_img.ptr, w, h, p, blur, thresh, 10.0, 2.0, d_heads.ptr, max_pts, d_cnt.ptr, d_next.ptr, op,
+                          n_images=n)
+    got_next = d_next.to_numpy(np.float32, (n, oh, op))
+    cnt = d_cnt.to_numpy(np.uint32, (n,))
+    heads = d_heads.to_numpy(np.float32, (n, max_pts, 16))
+    # the plain detection of the same images, whole records
+    d_pts = DeviceBuffer(ctx, n * max_pts * 588)
+    d_pts.zero()
+    d_cnt2 = DeviceBuffer(ctx, 4 * n)
+    d_cnt2.zero()
+    ctx.detect_multi(d_img.ptr, w, h, p, blur, thresh, 10.0, 2.0, d_pts.ptr, max_pts, d_cnt2.ptr, n_images=n)
+    cnt2 = d_cnt2.to_numpy(np.uint32, (n,))
+    pts = d_pts.to_numpy(SIFT_POINT_DTYPE, (n, max_pts))
+    np.testing.assert_array_equal(cnt, cnt2)
+    pad = np.frombuffer(b"\x5a" * 4, dtype=np.float32)[0]
+    for i in range(n):
+        want = oracle.scale_down(stack[i], w, h)
+        np.testing.assert_array_equal(got_next[i, :, :ow], want[:oh, :ow])
+        assert np.all(got_next[i, :, ow:].view(np.uint32) == pad.view(np.uint32))  # pad columns untouched
+        k = int(cnt[i])
+        hd = heads[i, :k]
+        rec = pts[i, :k]
+        a = np.stack([hd[:, 0], hd[:, 1], hd[:, 2], hd[:, 3], hd[:, 4], hd[:, 12]], axis=1)
+        b = np.stack([rec["coords2D"][:, 0], rec["coords2D"][:, 1], rec["scale"], rec["sharpness"], rec["edgeness"],
+                      rec["subsampling"]], axis=1)
+        a = a[np.lexsort(a.T[::-1])]
+        b = b[np.lexsort(b.T[::-1])]
+        np.testing.assert_array_equal(a, b)
+    if (w, h) in ((640, 480), (1920, 1080)):
+        assert cnt.sum() > 500
+    for buf in (d_img, d_next, d_heads, d_cnt, d_pts, d_cnt2):
+        buf.free()
+
+
 def test_generic_kernels_on_unaligned_pitch(ctx, oracle):
     """A caller-owned cuImage may have any pitch (cuImage.cu:16).  Rows that are not 16-byte aligned take the generic
     kernels (per-column clamps, scalar loads): ScaleDown, LaplaceMulti, FindPointsMulti bit-exact there too."""

@@ -50,7 +50,7 @@ def same_records(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f], equal_nan=True) for f in FIELDS)
 
 
-def context_with(overlap, stage_all=None, no_multi=False):
+def context_with(overlap, stage_all=None, no_multi=False, pyramid=0):
     """A context with the launch policy forced (cusift_ctx_set_policy)."""
     c = capi.Context(0)
     c.set_policy(capi.POLICY_SIDE_STREAM, overlap)
@@ -58,13 +58,18 @@ def context_with(overlap, stage_all=None, no_multi=False):
         c.set_policy(capi.POLICY_OCTAVE_LISTS, stage_all)
     if no_multi:
         c.set_policy(capi.POLICY_LAUNCH_PER_OCTAVE, 1)
+    c.set_policy(capi.POLICY_PYRAMID_IN_DETECT, pyramid)
     return c
 
 
 # how the keypoints of a call reach SiftData (cusift_extract_batch): octave 0 on the side stream with a list of its own
 # and the coarser octaves in place; every octave to a list of its own and the coarser octaves searched by one launch
 # (or by a launch each); both
-MODES = {"fork": (3, 0), "lists": (0, 1), "lists, a launch per octave": (0, 1, True), "fork+lists": (3, 1)}
+# ...; the pyramid as a by-product of the detections, searched finest first (every octave / octave 0 only, then the
+# ScaleDown chain and one launch for the coarser octaves / then a launch per octave)
+MODES = {"fork": (3, 0), "lists": (0, 1), "lists, a launch per octave": (0, 1, True), "fork+lists": (3, 1),
+         "pyramid in the detections": (0, 1, False, 2), "pyramid in octave 0's detection": (0, 1, False, 1),
+         "pyramid in octave 0's detection, a launch per octave": (0, 1, True, 1)}
 
 
 @pytest.fixture(params=sorted(MODES))
