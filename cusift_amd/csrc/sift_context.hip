@@ -129,6 +129,7 @@ int ensure_arena(cusift_ctx *ctx, size_t bytes) {
   if (bytes <= ctx->arena_bytes) return CUSIFT_OK;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->scratch_gen++;
+  ctx->seg_clean_ptr = nullptr;
   if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
   ctx->arena = nullptr;
   ctx->arena_bytes = 0;

@@ -113,10 +113,17 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   // cuSIFT.cu:69: point counter = 0 (with every octave staged the join writes it instead)
   if (!stage_all) HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));
   const size_t n_seg_counts = (size_t)n_images * (stage_all ? pl.n_oct : 1);
-  if (G.n_seg && !pyramid_clears) {
+  // join_counts_kernel reads every list's counter exactly once and leaves it zero (join_clears): when the previous
+  // extraction of this context did that for these very counters, nothing has to be cleared now -- in a loop of equal
+  // batches no memset is dispatched at all.  Not relied upon inside a recording (a replay cannot know what ran before it).
+  const bool join_clears = stage_all && !self_join && !forked;
+  const size_t seg_bytes = std::min(align_up_sz(sizeof(unsigned int) * n_seg_counts, 64),
+                                    sizeof(unsigned int) * n_images * kMaxOctaves);
+  const bool seg_clean = !ctx->recording && ctx->seg_clean_ptr == (const void *)seg_counts && ctx->seg_clean_bytes >= seg_bytes;
+  ctx->seg_clean_ptr = nullptr;  // whatever follows writes the arena; set again once the clearing join is enqueued
+  if (G.n_seg && !pyramid_clears && !seg_clean) {
     // (a multiple of 64 bytes: the runtime fills an odd size with two dispatches; the region is kMaxOctaves x n_images)
-    HIP_TRY(hipMemsetAsync(seg_counts, 0, std::min(align_up_sz(sizeof(unsigned int) * n_seg_counts, 64),
-                                                   sizeof(unsigned int) * n_images * kMaxOctaves), ctx->stream));
+    HIP_TRY(hipMemsetAsync(seg_counts, 0, seg_bytes, ctx->stream));
   }
 
   if (forked) {
@@ -235,8 +242,12 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
       // (the detection launch cleared the cursors; describe_all_kernel joins the lists itself)
     } else if (G.n_seg) {
       hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counters, G, seg_end, n_images,
-                         prm->max_pts, queue);
+                         prm->max_pts, queue, join_clears ? 1 : 0);
       TRY(check_launch("join_counts"));
+      if (join_clears) {
+        ctx->seg_clean_ptr = seg_counts;
+        ctx->seg_clean_bytes = seg_bytes;
+      }
     } else {
       HIP_TRY(hipMemsetAsync(queue, 0, kQueueShards * 128, ctx->stream));
     }
@@ -327,6 +338,7 @@ extern "C" int cusift_graph_launch(cusift_graph *g) {
     return fail(CUSIFT_ERR_INVALID,
                 "the context's scratch (arena / DoG planes) was re-allocated after this graph was recorded; record it again");
   HIP_TRY(hipSetDevice(g->ctx->device));
+  g->ctx->seg_clean_ptr = nullptr;  // the recording may leave its lists' counters in any state
   HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
   return CUSIFT_OK;
 }

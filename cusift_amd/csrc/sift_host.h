@@ -46,7 +46,7 @@ __global__ void descriptors_kernel(const float *, int, int, int, long, cusift_po
                                    const unsigned int *, float, float, float, RowWindow, int, unsigned int *);
 __global__ void describe_all_kernel(OctaveTable, cusift_point *, int, unsigned int *, int, float, float, int,
                                     unsigned int *, SegmentTable, const unsigned int *);
-__global__ void join_counts_kernel(unsigned int *, SegmentTable, unsigned int *, int, int, unsigned int *);
+__global__ void join_counts_kernel(unsigned int *, SegmentTable, unsigned int *, int, int, unsigned int *, int);
 __global__ void describe_bands_kernel(OctaveTable, BandWindows, cusift_point *, int, SegmentTable, const unsigned int *,
                                       float, float, int, unsigned int *);
 __global__ void rootsift_kernel(cusift_point *, int);
@@ -161,6 +161,10 @@ struct cusift_ctx {
   bool side_failed = false;  // no stream was found that runs beside the context's stream: never fork
   bool recording = false;  // inside cusift_graph_create's capture
   unsigned long forks = 0;  // extractions that took the side stream
+  // the lists' counters in the arena that the last extraction's join_counts_kernel left zero (stream order): the next
+  // extraction that uses exactly them skips its memset.  Anything else that writes the arena resets this.
+  const void *seg_clean_ptr = nullptr;
+  size_t seg_clean_bytes = 0;
   unsigned long scratch_gen = 0;  // bumped whenever arena / DoG / matcher scratch is re-allocated (recorded graphs check it)
   // timing
   bool timing = false;

@@ -1221,12 +1221,15 @@ extern "C" int cusift_stamps_read(unsigned long long *out16) {
 // the caller's own counter (keypoints appended in place).  Also clears the work cursors of describe_all_kernel.
 __global__ void __launch_bounds__(256) join_counts_kernel(unsigned int *__restrict__ counters, SegmentTable G,
                                                           unsigned int *__restrict__ seg_end, int n_images, int max_pts,
-                                                          unsigned int *__restrict__ queue) {
+                                                          unsigned int *__restrict__ queue, int clear_counts) {
   for (int i = threadIdx.x; i < kQueueShards * 32; i += 256) queue[i] = 0u;
   for (int i = threadIdx.x; i < n_images; i += 256) {
     unsigned int raw = 0, kept = 0;
     for (int r = 0; r < G.n_seg; ++r) {
       const unsigned int c = G.count[r][i];
+      // clear_counts: the lists' counters are the context's own (never the caller's) and this is their one reader --
+      // leaving them zero saves the NEXT extraction its memset dispatch (cusift_extract_batch keeps track)
+      if (clear_counts) const_cast<unsigned int *>(G.count[r])[i] = 0u;
       raw += c;
       const unsigned int room = (unsigned int)max_pts - kept;
       kept += c < room ? c : room;

@@ -546,6 +546,7 @@ extern "C" int cusift_extract_bands(cusift_ctx *ctx, const cusift_band *bands, i
   const size_t list_bytes = (size_t)max_pts * kStagedRecBytes;
   const size_t lists_off = 512;
   TRY(ensure_arena(ctx, bands_arena_bytes(n_bands, max_pts)));
+  ctx->seg_clean_ptr = nullptr;  // (this driver lays the arena out its own way)
   unsigned int *seg_counts = (unsigned int *)ctx->arena;
   unsigned int *seg_end = seg_counts + 32;
   HIP_TRY(hipMemsetAsync(seg_counts, 0, 128, ctx->stream));
@@ -578,7 +579,7 @@ extern "C" int cusift_extract_bands(cusift_ctx *ctx, const cusift_band *bands, i
     G.count[r] = seg_counts + k;
   }
   TRY(detect_multi_impl(ctx, mo, n_bands, peak_thresh, edge_thresh, max_pts, 1, 1, nullptr));
-  hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counter, G, seg_end, 1, max_pts, ctx->d_queue);
+  hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counter, G, seg_end, 1, max_pts, ctx->d_queue, 0);
   TRY(check_launch("join_counts"));
   float q, inv_q;
   frac_consts(tex_frac_bits, q, inv_q);

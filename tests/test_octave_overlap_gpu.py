@@ -232,6 +232,50 @@ def test_back_to_back_calls_do_not_race_on_the_staging_list(ctx, one_stream):
             b.free()
 
 
+def test_list_counters_left_clean_survive_any_interleaving(ctx, one_stream):
+    """join_counts_kernel leaves the lists' counters zero and the next extraction of the context skips its memset
+    (cusift_extract_batch: seg_clean).  That bookkeeping must hold whatever is called in between: other geometries (the
+    counters move inside the arena), a recorded graph's replays, a policy change, an arena that grows."""
+    prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=2.0, max_pts=4096)
+    small = images(2, 320, 240)
+    other = [np.roll(i, 37, 0) for i in images(3, 320, 240)]
+    large = images(1, 800, 600)
+    want = {k: run_batch(one_stream, v, prm) for k, v in (("small", small), ("other", other), ("large", large))}
+
+    def check(name, imgs):
+        cnt, pts = run_batch(ctx, imgs, prm)
+        np.testing.assert_array_equal(cnt, want[name][0], err_msg=name)
+        for i in range(len(imgs)):
+            assert same_records(canonical_order(pts[i, : cnt[i]]), canonical_order(want[name][1][i, : cnt[i]])), name
+
+    check("small", small)
+    check("small", small)  # the second call finds clean counters
+    check("other", other)  # three images: the counters sit elsewhere
+    check("small", small)
+    src = np.stack([pitched(i) for i in small])
+    d_imgs = DeviceBuffer.from_numpy(ctx, src)
+    d_pts = DeviceBuffer(ctx, 2 * prm.max_pts * 588)
+    d_cnt = DeviceBuffer(ctx, 8)
+    g = ctx.record_graph(d_imgs.ptr, 2, 320, 240, src.shape[2], 240 * src.shape[2], prm, d_pts.ptr, d_cnt.ptr)
+    for _ in range(2):
+        g.launch()
+        ctx.synchronize()
+        np.testing.assert_array_equal(d_cnt.to_numpy(np.uint32, (2,)), want["small"][0])
+        check("small", small)  # an eager call between the replays
+    g.close()
+    for b in (d_imgs, d_pts, d_cnt):
+        b.free()
+    check("large", large)  # the arena grows: everything moves
+    check("small", small)
+    old = ctx.get_policy(capi.POLICY_PYRAMID_IN_DETECT)
+    ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, 0 if old else 2)
+    if ctx.get_policy(capi.POLICY_OCTAVE_LISTS) == 1:
+        check("small", small)
+        check("small", small)
+    ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, old)
+    check("small", small)
+
+
 def test_default_policy(one_stream):
     """A context never forks unless asked to (round 4: the side stream is opt-in, nothing is decided by timing).  Asked
     (policy 1 = trust the caller, 2 = after the concurrency probe -- which may refuse on a box whose queues are taken):

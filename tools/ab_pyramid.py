@@ -5,6 +5,7 @@ detection): ms per 64 x 1080p batch for policy 0 (ScaleDown chain first), 1 (oct
 concurrent_batches = 4: the benchmark's timed region).
 
     python tools/ab_pyramid.py [reps=5] [content=tile|blobs|raw] [n=64]
+    AB_POLICIES=2 AB_STREAMS=1 rocprofv3 --kernel-trace --stats ... -- python3 tools/ab_pyramid.py 1   # one variant's kernels
 """
 import os
 import sys
@@ -33,9 +34,9 @@ def main():
     rows = [np.zeros((h, p), dtype=np.float32) for _ in imgs]
     for r, i in zip(rows, imgs):
         r[:, :w] = i
-    policies = (0, 1, 2)
+    policies = tuple(int(x) for x in os.environ.get("AB_POLICIES", "0,1,2").split(","))  # (a kernel trace wants one)
     results = {}
-    for n_streams in (1, 4):
+    for n_streams in tuple(int(x) for x in os.environ.get("AB_STREAMS", "1,4").split(",")):
         prm = capi.default_params(num_octaves=5, init_blur=1.0, peak_thresh=3.0, max_pts=32768,
                                   concurrent_batches=n_streams if n_streams > 1 else 1)
         # one set of contexts per policy, all alive at once so that the trials interleave on the same device state

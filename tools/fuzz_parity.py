@@ -57,6 +57,12 @@ def main():
             n_img = int(rng.choice([1, 1, 2, 5]))
             imgs = [make_image(rng, w, h) for _ in range(n_img)]
             prm = capi.default_params(fused_detect=fused, **kw)
+            # the launch sequence is drawn too (results never depend on it): a list per octave or not, the pyramid as a
+            # by-product of the detections (every octave / octave 0 only) or the ScaleDown chain first
+            lists = int(rng.choice([-1, 1]))
+            pyramid = int(rng.choice([-1, 0, 1, 2])) if lists == 1 else -1
+            ctx.set_policy(capi.POLICY_OCTAVE_LISTS, lists)
+            ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, pyramid)
             stack = np.stack([pitched(i) for i in imgs])
             p = stack.shape[2]
             d_imgs = capi.DeviceBuffer.from_numpy(ctx, stack)
@@ -104,9 +110,10 @@ def main():
                         msg.append("img %d: %d descriptors >= 1e-4 (max %.2e)" % (i, int((l2 >= 1e-4).sum()), l2.max()))
             status = "ok " if not msg else "BAD"
             bad += bool(msg)
-            print("%s case %3d: %dx%d x%d oct=%d blur=%.1f thr=%.1f edge=%.0f low=%.0f sub=%.0f max=%d fused=%d counts=%s %s"
+            print("%s case %3d: %dx%d x%d oct=%d blur=%.1f thr=%.1f edge=%.0f low=%.0f sub=%.0f max=%d fused=%d lists=%d pyr=%d counts=%s %s"
                   % (status, case, w, h, n_img, kw["num_octaves"], kw["init_blur"], kw["peak_thresh"], kw["edge_thresh"],
-                     kw["lowest_scale"], kw["subsampling"], kw["max_pts"], fused, list(map(int, counts)), "; ".join(msg)),
+                     kw["lowest_scale"], kw["subsampling"], kw["max_pts"], fused, lists, pyramid, list(map(int, counts)),
+                     "; ".join(msg)),
                   flush=True)
             for bfr in (d_imgs, d_pts, d_cnt):
                 bfr.free()
