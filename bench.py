@@ -345,6 +345,10 @@ def main():
     ap.add_argument("--profile-run", action="store_true",
                     help="under rocprofv3 (tools/profile_gpu.sh): skip the sub-legs that launch a kernel outside the "
                          "5-octave cycle, so that per-launch PMC averages are over whole steps")
+    ap.add_argument("--pyramid-in-detect", type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help="CUSIFT_POLICY_PYRAMID_IN_DETECT of every extraction context: -1 the library's default (calls of "
+                         ">= 6 Mpixel: every detection writes the next octave's image, no ScaleDown launches), 0 the "
+                         "ScaleDown chain first (the reference's order, cuSIFT.cu:175-192), 1 octave 0 only, 2 every octave")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the launch only: ranks rendezvous over gloo on the CPU, shard the batch, barrier, "
                          "reduce a time and rank 0 prints a line -- no GPU, no extraction (tests the --gpus N spawn)")
@@ -411,6 +415,9 @@ def main():
                               fused_detect=0 if args.two_stage else 1, **prm_kw)
     exs = pipe.extractors
     ex = exs[0]
+    if args.pyramid_in_detect != -1:
+        for x in exs:
+            x.ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, args.pyramid_in_detect)
 
     # ---- synthetic inputs, resident in HBM before anything is timed ----
     from concurrent.futures import ThreadPoolExecutor
@@ -594,6 +601,10 @@ def main():
                 "pipeline": "two-stage (DoG in HBM)" if args.two_stage else "fused detection (DoG on chip)",
                 "timed_region_timers": False,
                 "timed_region_forks": int(forks_timed),
+                "pyramid_in_detect": ex.ctx.get_policy(capi.POLICY_PYRAMID_IN_DETECT),
+                "pyramid_in_detect_note": "-1 = the library's default: a call of >= 6 Mpixel searches its octaves finest "
+                                          "first and every detection launch also writes the next octave's image "
+                                          "(ScaleDown's arithmetic, bit for bit) -- no ScaleDown launch, no memset",
             },
             "keypoints_per_s_in_hbm": round(total_kp / (elapsed / K), 1),
             "keypoints_per_step": total_kp,
@@ -695,6 +706,19 @@ def main():
             out["ms_per_step_spread"] = {"min": round(allr[0], 4), "median": round(allr[len(allr) // 2], 4),
                                          "max": round(allr[-1], 4), "regions": len(allr),
                                          "note": "the timed region (`ms_per_step`) and 4 repeats of it, K steps each"}
+            # same box, same images, the reference's order (ScaleDown chain first, coarsest octave searched first):
+            # what the pyramid-in-detection sequence is worth here
+            if args.pyramid_in_detect == -1:
+                with leg_guard("pyramid_policy_ab"):
+                    ab = {}
+                    for pol, name in ((0, "scale_down_chain_first"), (-1, "pyramid_in_detect (default)")):
+                        for x in exs:
+                            x.ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, pol)
+                        r = sorted(run_pipelined(d_imgs, K) for _ in range(3))
+                        ab[name] = {"ms_per_step_median_of_3": round(r[1], 4), "Mpix_per_s": round(total_pix / r[1] / 1e3, 1)}
+                    out["pyramid_policy_ab"] = ab
+                for x in exs:
+                    x.ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, -1)
         ex.params.concurrent_batches = 1  # the single-stream legs below run one batch at a time on one stream
         if stage_overlapped is not None and E > 1:
             out["timed_region_kernel_spans_ms_per_step"] = dict(
@@ -708,28 +732,36 @@ def main():
             out["stage_ms_per_step"] = stage_table(stage, K)
             # a lone caller: one batch at a time on one stream, no stage timers -- the driver then runs octave 0's
             # detection on the context's second stream beside the ScaleDown chain and the coarser octaves
-            forks0 = ex.ctx.forks()
             lone_steps = 0 if args.profile_run else K  # (not under the profiler: its per-kernel averages are per launch)
-            if lone_steps:  # the side stream is opt-in (nothing in the timed region or any other leg uses it)
+
+            def lone(steps):
+                for _ in range(2 if steps else 0):
+                    ex.extract(d_imgs)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    ex.extract(d_imgs)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / max(1, steps) * 1e3
+
+            lone_ms = lone(lone_steps)  # the default policy: nothing forks
+            forks0 = ex.ctx.forks()
+            if lone_steps:  # the side stream is opt-in (nothing in the timed region or any other leg uses it); with it
+                # octave 0 cannot hand octave 1 to the coarser detections, so the ScaleDown chain runs beside it
                 ex.ctx.set_policy(capi.POLICY_SIDE_STREAM, 2)  # after the probe: four other streams are in use here
-            for _ in range(2 if lone_steps else 0):
-                ex.extract(d_imgs)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(lone_steps):
-                ex.extract(d_imgs)
-            torch.cuda.synchronize()
-            lone_ms = (time.perf_counter() - t1) / max(1, lone_steps) * 1e3
+            lone_forked_ms = lone(lone_steps)
             ex.ctx.set_policy(capi.POLICY_SIDE_STREAM, 0)
             out["single_stream_leg"] = {
                 "ms_per_step": round(single_ms, 4),
                 "lone_caller_ms_per_step": round(lone_ms, 4) if lone_steps else None,
+                "lone_caller_side_stream_ms_per_step": round(lone_forked_ms, 4) if lone_steps else None,
                 "lone_caller_forked_steps": max(0, ex.ctx.forks() - forks0 - 2),
                 "note": "the timed region alternates steps over %d streams; stage_ms_per_step, the VALU rooflines and "
                         "pyramid_mpix_per_s are measured on the same steps run on one stream (HIP events per launch), "
                         "where kernel spans do not overlap.  lone_caller_ms_per_step: the same calls without the stage "
-                        "timers and with concurrent_batches = 1 -- what a caller that keeps ONE batch in flight gets "
-                        "(octave 0's detection then runs on the context's second stream)" % E}
+                        "timers and with concurrent_batches = 1 -- what a caller that keeps ONE batch in flight gets by "
+                        "default; lone_caller_side_stream_ms_per_step: with CUSIFT_POLICY_SIDE_STREAM = 2 (octave 0's "
+                        "detection on the context's second stream beside the ScaleDown chain and the coarser octaves)" % E}
             sd_ms = stage["scale_down"][0]
             det_ms, det_n = stage["detect_multi"]
             if det_n > 0:
@@ -1052,6 +1084,21 @@ def main():
         if len(rates) > 1:
             out["value_range_mpix_per_s"] = [min(rates.values()), max(rates.values())]
             out["value_by_content_mpix_per_s"] = rates
+
+        # `roofline` is the blur + DoG exhibit the north star gates (a kernel the timed region does not launch); the timed
+        # step's own dominant kernel and ITS bound ride inside it, so that whoever copies `roofline` has both
+        if "roofline" in out and out.get("roofline_kernels"):
+            dom = max(out["roofline_kernels"], key=lambda r: r["ms_per_step"])
+            ib = dom.get("issue_bound", {})
+            out["roofline"]["timed_region"] = {
+                "kernel": dom["kernel"], "bound": "valu", "achieved": dom["achieved"], "peak": dom["peak"],
+                "unit": dom["unit"], "frac": dom["frac"], "ms_per_step_single_stream": dom["ms_per_step"],
+                "launches_per_step": dom["launches_per_step"], "frac_of_issue_bound": ib.get("frac_of_issue_bound"),
+                "share_of_single_stream_step": round(dom["ms_per_step"] / out["single_stream_leg"]["ms_per_step"], 3)
+                if out.get("single_stream_leg") else None,
+                "note": "the kernel that owns the timed step (fused blur + DoG + extrema + refinement + the next octave's "
+                        "image): vector-issue bound at two waves per SIMD, moves 4 B per pixel of HBM traffic -- its HBM "
+                        "roofline fraction is meaningless by design (DoG planes never leave the chip)"}
 
         if "cpu" in legs:
             with leg_guard("cpu"):

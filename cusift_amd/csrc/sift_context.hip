@@ -300,8 +300,8 @@ bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_imag
   if (ctx->knobs.stage_all == 0 || ctx->knobs.force_generic) return false;
   if (!prm || !prm->fused_detect || n_images < 1 || n_images > kMaxFlatImages) return false;
   if (ctx->knobs.stage_all > 0) return true;  // tests: whenever the lists fit
-  if (ctx->timing) return false;  // the stage timers bracket the reference's launch-per-octave sequence
   if (wants_pyramid_in_detect(ctx, prm, n_images, w, h) > 0) return true;  // finest first needs a list per octave
+  if (ctx->timing) return false;  // the stage timers bracket the reference's launch-per-octave sequence
   return prm->concurrent_batches < 2 || (size_t)n_images * (size_t)w * (size_t)h <= kListsMaxPixelsPipelined;
 }
 
@@ -316,7 +316,8 @@ int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int
   const int mode = ctx->knobs.pyramid_in_detect;
   if (mode == 0 || ctx->knobs.force_generic || ctx->knobs.stage_all == 0) return 0;
   if (!prm || !prm->fused_detect || prm->num_octaves < 2 || n_images < 1 || n_images > kMaxFlatImages) return 0;
-  if (ctx->timing) return 0;  // the stage timers bracket the reference's launch-per-octave sequence
+  // (the stage timers do not change this: every launch of the finest-first sequence is a detection launch and is
+  // bracketed as one -- the ScaleDown stage then simply reports no launches)
   if (mode > 0) return std::min(mode, 2);
   return (size_t)n_images * (size_t)w * (size_t)h >= kPyramidInDetectMinPixels ? 2 : 0;
 }
