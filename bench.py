@@ -333,8 +333,13 @@ def main():
                     help="N > 1: exchange 160-byte compact records (exact header fields, 8-bit descriptor) instead of the "
                          "exact 588-byte SiftPoint records -- NOT the default: the metric is the all-gatherv of SiftData")
     ap.add_argument("--gather-trimmed", action="store_true",
-                    help="N > 1: exchange 540-byte trimmed records (the 135 floats extraction writes: EXACT, 8 %% fewer "
-                         "bytes per link than the 588-byte SiftPoint) -- not the default either")
+                    help="N > 1: exchange 540-byte trimmed records and LEAVE them trimmed (no expansion on arrival)")
+    ap.add_argument("--gather-exact", action="store_true",
+                    help="N > 1: exchange the 588-byte SiftPoint records as they are.  The default since round 5: the "
+                         "records TRAVEL trimmed (540 bytes: the 135 floats extraction writes, exact; the other 12 are "
+                         "never written by extraction and uninitialised in the reference, cuSIFT.cu:24,29) and are "
+                         "EXPANDED ON ARRIVAL (cusift_expand_gathered), so every rank ends the step holding the 588-byte "
+                         "SiftData of all images for 8 %% fewer bytes per xGMI link")
     ap.add_argument("--no-self-p2p", action="store_true",
                     help="with --force-gather at one rank: do not route the local shard through ncclSend/ncclRecv to self "
                          "(what remains is what every rank does for ITS OWN shard at any N: clamp, pack into its region, "
@@ -455,7 +460,8 @@ def main():
             comm = make_comm(side_ctx, self_p2p=(world == 1 and not args.no_self_p2p))
             gatherer = SiftGatherer(comm, B, args.max_pts, region_cap=region_cap, device=dev, n_out=LAG + 2,
                                     depth=LAG + 1, wire_format="compact" if args.gather_compact else (
-                                        "trimmed" if args.gather_trimmed else "exact"))
+                                        "exact" if args.gather_exact else "trimmed"),
+                                    expand=not (args.gather_compact or args.gather_exact or args.gather_trimmed))
         except Exception as e:  # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
@@ -525,6 +531,22 @@ def main():
     # config.timed_region_forks / _timers say so.  The kernel-span table of the overlapped streams comes from a REPEAT of
     # the region with the timers on (`timed_region_kernel_spans_ms_per_step`, with that repeat's own ms per step).
     torch.cuda.synchronize()
+    # Pre-flight, before the W warm-up steps: every extractor runs the batch a few times and all of them must report the
+    # same keypoint counts (four contexts, four arenas, one answer) -- a set-up check, not part of the contract's W + K
+    # steps and never timed.  It is also what takes the device out of its idle clocks: after ANY idle gap (50 ms is
+    # enough) the first ~20 ms of load run 5-12 % slow (tools/probe_rampup.py: 1.09, 1.02, then 0.97 ms per step in
+    # steady state; staggering the streams' starts changes nothing, a region that follows another without a gap starts
+    # at the steady rate).  W = 5 steps is 5 ms.  config.preflight_steps says how many ran; the repeat leg reports the
+    # same region started from idle (`ms_per_step_from_idle`) beside it.
+    PREFLIGHT = 6 * E * n_slots
+    for _ in range(PREFLIGHT):
+        pipe.submit(d_imgs)
+    pipe.synchronize()
+    ref_counts = exs[0].slots[0][1].clone()
+    for x in exs:
+        for _, cnt_t in x.slots:
+            if not torch.equal(cnt_t, ref_counts):
+                raise SystemExit("bench.py: pre-flight: extractors disagree on the keypoint counts of the same batch")
     for _ in range(args.warmup):
         step()
     fence()
@@ -554,9 +576,29 @@ def main():
                 k: (stage_overlapped[k][0] + t[k][0], stage_overlapped[k][1] + t[k][1]) for k in t}
             x.ctx.timing_enable(False)
 
-    # max over ranks
+    # N > 1: the same K steps WITHOUT the exchange, right behind the timed region -- what gather_model needs as the
+    # extraction's own time, so that "measured - predicted" means something (max over ranks, like the timed region)
+    extraction_only_ms = None
+    if use_dist:
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.submit(d_imgs)
+        pipe.synchronize()
+        eo = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(eo, op=dist.ReduceOp.MAX)
+        extraction_only_ms = float(eo.item()) / args.steps * 1e3
+    # max over ranks (and every rank's own time, for the line)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank_elapsed = [elapsed]
     if world > 1:
+        every = [torch.zeros_like(el) for _ in range(world)]
+        dist.all_gather(every, el)
+        per_rank_elapsed = [float(t.item()) for t in every]
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     counts = ex.valid_counts()
@@ -601,6 +643,10 @@ def main():
                 "pipeline": "two-stage (DoG in HBM)" if args.two_stage else "fused detection (DoG on chip)",
                 "timed_region_timers": False,
                 "timed_region_forks": int(forks_timed),
+                "preflight_steps": PREFLIGHT,
+                "preflight_note": "untimed set-up check before the W warm-up steps: every extractor runs the batch, all "
+                                  "must report identical keypoint counts; it also takes the device out of its idle clocks "
+                                  "(ms_per_step_spread.ms_per_step_from_idle = the same region started 50 ms after idle)",
                 "pyramid_in_detect": ex.ctx.get_policy(capi.POLICY_PYRAMID_IN_DETECT),
                 "pyramid_in_detect_note": "-1 = the library's default: a call of >= 6 Mpixel searches its octaves finest "
                                           "first and every detection launch also writes the next octave's image "
@@ -610,13 +656,29 @@ def main():
             "keypoints_per_step": total_kp,
         }
         rec_b = gatherer.record_bytes if gatherer is not None else 588
-        out["gather_model"] = gather_model(local_kp, rec_b, ms_per_step, LAG if use_dist else E)
+        out["gather_model"] = gather_model(local_kp, rec_b, extraction_only_ms if use_dist else ms_per_step,
+                                           LAG if use_dist else E)
+        if use_dist:
+            out["gather_model"]["extraction_ms_per_step_source"] = (
+                "the same K steps run without the exchange right behind the timed region (max over ranks)")
         out["gather_model"]["step_of_this_run_includes_an_exchange"] = bool(use_dist)
         if use_dist:
             out["config"]["gather_impl"] = gather_impl
             out["config"]["rccl_library"] = capi.Comm.library()
             out["config"]["gather_region_records"] = region_cap
             out["config"]["gather_record_bytes"] = rec_b
+            out["config"]["gather_wire_format"] = (
+                "%s%s" % (gatherer.wire_format, ", expanded on arrival to 588-byte SiftPoint records" if gatherer.expand
+                          else "")) if gatherer is not None else "exact (torch.distributed fallback)"
+            # what the LIBRARY reports (ncclCommCount / ncclGetVersion), not this script's own bookkeeping: "RCCL saw N
+            # ranks" can be read off the line
+            info = comm.info() if comm is not None else {}
+            out["config"]["rccl_ranks"] = info.get("lib_ranks")
+            out["config"]["rccl_version"] = info.get("lib_version")
+            out["config"]["ms_per_step_by_rank"] = [round(float(t) / K * 1e3, 4) for t in per_rank_elapsed]
+            ex_ms = out["gather_model"]["ranks"].get(str(world), {}).get("eff_1.0", {}).get("ms_per_step_overlapped")
+            if ex_ms:
+                out["gather_model"]["measured_minus_predicted_ms_at_link_peak"] = round(ms_per_step - ex_ms, 4)
             if gather_waits is not None:
                 out["config"]["gather_host_waits"] = gather_waits[0]
                 out["config"]["gather_host_wait_ms"] = round(gather_waits[1], 3)
@@ -706,6 +768,8 @@ def main():
             out["ms_per_step_spread"] = {"min": round(allr[0], 4), "median": round(allr[len(allr) // 2], 4),
                                          "max": round(allr[-1], 4), "regions": len(allr),
                                          "note": "the timed region (`ms_per_step`) and 4 repeats of it, K steps each"}
+            time.sleep(0.05)  # what a region costs that starts from an idle device (no pre-flight, no warm-up)
+            out["ms_per_step_spread"]["ms_per_step_from_idle"] = round(run_pipelined(d_imgs, K, warm=0), 4)
             # same box, same images, the reference's order (ScaleDown chain first, coarsest octave searched first):
             # what the pyramid-in-detection sequence is worth here
             if args.pyramid_in_detect == -1:

@@ -95,6 +95,8 @@ SIGNATURES = {
     "cusift_comm_create": (_i, [C.POINTER(_vp), _vp, _vp, _i, _i]),
     "cusift_comm_destroy": (_i, [_vp]),
     "cusift_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "cusift_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "cusift_expand_gathered": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "cusift_comm_library": (C.c_char_p, []),
     "cusift_comm_set_self_p2p": (_i, [_vp, _i]),
     "cusift_comm_use_library": (_i, [C.c_char_p]),
@@ -579,6 +581,20 @@ class Comm:
     def library():
         p = lib().cusift_comm_library()
         return p.decode() if p else ""
+
+    def info(self):
+        """cusift_comm_info: what the bound LIBRARY says about this communicator -- {"lib_ranks": ncclCommCount,
+        "lib_rank": ncclCommUserRank, "lib_version": ncclGetVersion}; -1 where the library lacks the call."""
+        n, r, v = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        check(lib().cusift_comm_info(self._h, C.byref(n), C.byref(r), C.byref(v)))
+        return {"lib_ranks": n.value, "lib_rank": r.value, "lib_version": v.value}
+
+    def expand_gathered(self, d_gathered_trimmed, region_cap, totals, d_points):
+        """cusift_expand_gathered: regions of 540-byte trimmed records -> regions of 588-byte SiftPoint records, one
+        launch on the communicator's stream behind the exchange (asynchronous)."""
+        t = np.ascontiguousarray(np.asarray(totals, dtype=np.uint64))
+        assert len(t) == self.world
+        check(lib().cusift_expand_gathered(self._h, d_gathered_trimmed, region_cap, t.ctypes.data, d_points))
 
     def reserve(self, n_images_max, tickets=4, stage_records=0):
         check(lib().cusift_comm_reserve(self._h, n_images_max, tickets, stage_records))

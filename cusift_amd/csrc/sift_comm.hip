@@ -63,6 +63,10 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  // optional (cusift_comm_info): what the LIBRARY says about a communicator -- absent from a minimal stand-in
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
   bool complete() const {
     return handle && GetUniqueId && CommInitRank && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd &&
            GetErrorString;
@@ -129,6 +133,9 @@ int load_rccl(Rccl **out) {
       BIND(GroupEnd, "ncclGroupEnd")
       BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
+      r->CommCount = (decltype(r->CommCount))dlsym(r->handle, "ncclCommCount");
+      r->CommUserRank = (decltype(r->CommUserRank))dlsym(r->handle, "ncclCommUserRank");
+      r->GetVersion = (decltype(r->GetVersion))dlsym(r->handle, "ncclGetVersion");
     }
     it = g_libs.emplace(key, std::move(r)).first;
   }
@@ -399,6 +406,18 @@ extern "C" int cusift_comm_rank(cusift_comm *c, int *rank, int *world) {
 
 extern "C" cusift_ctx *cusift_comm_ctx(cusift_comm *c) { return c ? c->ctx : nullptr; }
 
+extern "C" int cusift_comm_info(cusift_comm *c, int *lib_ranks, int *lib_rank, int *lib_version) {
+  if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
+  int n = -1, r = -1, v = -1;
+  if (c->lib->CommCount && c->lib->CommCount(c->nccl, &n) != ncclSuccess) n = -1;
+  if (c->lib->CommUserRank && c->lib->CommUserRank(c->nccl, &r) != ncclSuccess) r = -1;
+  if (c->lib->GetVersion && c->lib->GetVersion(&v) != ncclSuccess) v = -1;
+  if (lib_ranks) *lib_ranks = n;
+  if (lib_rank) *lib_rank = r;
+  if (lib_version) *lib_version = v;
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_comm_set_self_p2p(cusift_comm *c, int on) {
   if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
   if (c->pending) return cusift_fail(CUSIFT_ERR_INVALID, "comm: exchanges in flight");
@@ -560,6 +579,55 @@ extern "C" int cusift_allgatherv(cusift_comm *c, cusift_ctx *producer, const cus
   TRY(cusift_allgatherv_begin(c, producer, d_points, d_counters, n_images, max_pts, n_images_max, d_gathered,
                               region_cap));
   return cusift_allgatherv_finish(c, h_counts, h_totals);
+}
+
+// trimmed regions -> SiftPoint regions, all ranks in one launch: block (x, r) walks region r's records x, x + gridDim.x, ...
+struct RegionTotals {
+  unsigned int n[64];
+};
+__global__ void __launch_bounds__(64) expand_regions_kernel(const cusift_trimmed_point *__restrict__ trimmed,
+                                                           size_t region_cap, RegionTotals totals, int first_rank,
+                                                           cusift_point *__restrict__ points) {
+  const int lane = threadIdx.x;
+  const int rk = blockIdx.y;
+  const size_t n = totals.n[rk];
+  constexpr int kData = (int)(offsetof(cusift_point, data) / 4), kSub = (int)(offsetof(cusift_point, subsampling) / 4);
+  constexpr int kDwords = sizeof(cusift_point) / 4;
+  const size_t base = (size_t)(first_rank + rk) * region_cap;
+  for (size_t g = blockIdx.x; g < n; g += gridDim.x) {
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(trimmed + base + g);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(points + base + g);
+    dst[kData + lane] = src[7 + lane];
+    dst[kData + 64 + lane] = src[7 + 64 + lane];
+    if (lane < kData) dst[lane] = lane < 6 ? src[lane] : (lane == kSub ? src[6] : 0u);
+    if (lane < kDwords - kData - 128) dst[kData + 128 + lane] = 0u;  // coords3D
+  }
+}
+
+extern "C" int cusift_expand_gathered(cusift_comm *c, const cusift_trimmed_point *d_gathered, size_t region_cap,
+                                      const size_t *h_totals, cusift_point *d_points) {
+  if (!c) return cusift_fail(CUSIFT_ERR_INVALID, "comm is NULL");
+  if (!d_gathered || !h_totals || !d_points) return cusift_fail(CUSIFT_ERR_INVALID, "expand (gathered): NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  for (int first = 0; first < c->world; first += 64) {
+    RegionTotals t;
+    memset(&t, 0, sizeof(t));
+    const int nr = std::min(64, c->world - first);
+    size_t most = 0;
+    for (int r = 0; r < nr; ++r) {
+      if (h_totals[first + r] > region_cap)
+        return cusift_fail(CUSIFT_ERR_INVALID, "expand (gathered): rank %d holds %zu records, regions hold %zu", first + r,
+                           h_totals[first + r], region_cap);
+      t.n[r] = (unsigned int)h_totals[first + r];
+      most = std::max(most, h_totals[first + r]);
+    }
+    if (most == 0) continue;
+    dim3 grid((unsigned int)std::min<size_t>(most, 2048), nr);
+    hipLaunchKernelGGL(expand_regions_kernel, grid, dim3(64), 0, c->stream, d_gathered, region_cap, t, first, d_points);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cusift_fail(CUSIFT_ERR_HIP, "expand (gathered) launch failed: %s", hipGetErrorString(e));
+  }
+  return CUSIFT_OK;
 }
 
 extern "C" int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_gathered, size_t region_cap, int world,

@@ -54,13 +54,18 @@ class SiftGatherer:
     `compact=True`: the records travel and arrive as 160-byte cusift_compact_point (capi.COMPACT_POINT_DTYPE; exact
     header fields, 8-bit descriptor) -- `gathered` is then [world, region_cap, 160].  `wire_format="trimmed"`: as 540-byte
     cusift_trimmed_point (the 135 floats extraction writes: exact; capi.TRIMMED_POINT_DTYPE, capi.expand_trimmed).
+    `wire_format="trimmed", expand=True` (what bench.py uses for N > 1): the records TRAVEL as trimmed records and are
+    expanded on arrival (cusift_expand_gathered, one launch behind the exchange), so finish() returns [world, region_cap,
+    588] SiftPoint regions exactly as the exact format does -- every rank ends the step holding SiftData of all images --
+    for 8 % fewer bytes per xGMI link (the 12 floats dropped are never written by extraction and uninitialised in the
+    reference, cuSIFT.cu:24,29; they arrive as zeros).
     The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: begin()
     returns an event recorded behind it -- `producer_stream.wait_event(ev)` (or `producer_ctx.wait(comm.ctx)`) orders
     the producer's next write after the pack without a host wait.  The tensors themselves are kept alive by this object
     until that event has fired."""
 
     def __init__(self, comm, n_images_max, max_pts, region_cap=None, device=None, n_out=2, depth=1, fixed_size=False,
-                 compact=False, wire_format=None):
+                 compact=False, wire_format=None, expand=False):
         self.comm, self.n_max, self.max_pts = comm, int(n_images_max), int(max_pts)
         self.region_cap = int(region_cap) if region_cap else self.n_max * self.max_pts
         self.device = torch.device("cuda", comm.ctx.device) if device is None else torch.device(device)
@@ -70,6 +75,12 @@ class SiftGatherer:
         fmt_code, self.record_bytes = capi.WIRE_FORMATS[self.wire_format]
         self.out = [torch.empty((comm.world, self.region_cap, self.record_bytes), dtype=torch.uint8, device=self.device)
                     for _ in range(n_out)]
+        self.expand = bool(expand)
+        if self.expand and self.wire_format != "trimmed":
+            raise ValueError("expand=True goes with wire_format='trimmed'")
+        # expanded regions (SiftPoint records), one per output buffer
+        self.out_exact = [torch.empty((comm.world, self.region_cap, SIFT_POINT_BYTES), dtype=torch.uint8, device=self.device)
+                          for _ in range(n_out)] if self.expand else None
         comm.set_wire_format(fmt_code)
         comm.reserve(self.n_max, self.depth, self.region_cap)
         if fixed_size:
@@ -92,12 +103,15 @@ class SiftGatherer:
         packed = torch.cuda.Event()
         packed.record(self._stream)
         self._held = [(e, t) for e, t in self._held if not e.query()] + [(packed, (points, counts))]
-        self._inflight.append(buf)
+        self._inflight.append((buf, self.out_exact[(self.k - 1) % len(self.out)] if self.expand else None))
         return packed  # after this event the caller may overwrite points / counts (stream.wait_event(packed))
 
     def finish(self):
-        buf = self._inflight.pop(0)
+        buf, exact = self._inflight.pop(0)
         counts, totals = self.comm.allgatherv_finish()
+        if exact is not None:  # expand on arrival: behind the exchange on the communicator's stream
+            self.comm.expand_gathered(buf.data_ptr(), self.region_cap, totals, exact.data_ptr())
+            return counts, exact, totals
         return counts, buf, totals
 
     def gather(self, points, counts, producer=None):

@@ -431,6 +431,10 @@ int cusift_comm_create(cusift_comm **out, cusift_ctx *ctx, const char id[CUSIFT_
 int cusift_comm_destroy(cusift_comm *comm);
 int cusift_comm_rank(cusift_comm *comm, int *rank, int *world);
 cusift_ctx *cusift_comm_ctx(cusift_comm *comm); /* the context (device + stream) the communicator is bound to */
+/* What the bound LIBRARY reports for this communicator: ncclCommCount, ncclCommUserRank, ncclGetVersion (major * 10000 +
+ * minor * 100 + patch) -- each -1 if the library does not export the call.  A benchmark line that carries lib_ranks
+ * proves "RCCL saw N ranks" without trusting the caller's own bookkeeping (cusift_comm_rank). */
+int cusift_comm_info(cusift_comm *comm, int *lib_ranks, int *lib_rank, int *lib_version);
 /* Path of the library bound last ("" before the first communicator call). */
 const char *cusift_comm_library(void);
 /* Tests / world == 1: route the local shard (and rows addressed to this rank) through ncclSend/ncclRecv to self too,
@@ -485,6 +489,14 @@ int cusift_allgatherv(cusift_comm *comm, cusift_ctx *producer, const cusift_poin
                       void *d_gathered, size_t region_cap, unsigned int *h_counts, size_t *h_totals);
 int cusift_compact_gathered(cusift_ctx *ctx, const cusift_point *d_gathered, size_t region_cap, int world,
                             const size_t *h_totals, cusift_point *d_out, size_t capacity);
+/* Expand on arrival: regions gathered in the trimmed wire format (cusift_comm_set_wire_format(comm, 2): 540 B per record
+ * over xGMI) -> the same regions as SiftPoint records (588 B, what the reference's SiftData holds; the 12 floats
+ * extraction never writes -- uninitialised in the reference, cuSIFT.cu:24,29 -- are zero), region r at
+ * d_points + r * region_cap, h_totals[r] records each (as cusift_allgatherv_finish returned them).  One launch for all
+ * ranks on the communicator's stream, behind the exchange; asynchronous.  Every rank then ends the step holding the
+ * SiftData of all ranks' images exactly as with the 588-byte wire format, for 8 % fewer bytes per link. */
+int cusift_expand_gathered(cusift_comm *comm, const cusift_trimmed_point *d_gathered, size_t region_cap,
+                           const size_t *h_totals, cusift_point *d_points);
 
 /* Rows of a pitched float image between ranks, as one ncclGroup: op i sends send_rows[i] rows starting at local row
  * send_row[i] of d_band to peers[i] and receives recv_rows[i] rows from it into local row recv_row[i] (`pitch` floats

@@ -283,6 +283,18 @@ ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcoun
   return ncclGroupEnd();
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+  if (!comm || !count) return ncclInvalidArgument;
+  *count = comm->w->n;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
+  if (!comm || !rank) return ncclInvalidArgument;
+  *rank = comm->rank;
+  return ncclSuccess;
+}
+
 const char *ncclGetErrorString(ncclResult_t r) {
   switch (r) {
     case ncclSuccess: return "success";

@@ -26,6 +26,33 @@ def test_gpus_2_spawns_its_own_ranks_and_prints_one_line():
     assert d["n_gpus"] == 2 and d["dry_launch"] is True and d["images_total"] == 128 and d["steps"] == 3
 
 
+def test_gpus_8_dry_launch():
+    """The shape the driver's scaling run has (`python bench.py --gpus 8`): eight ranks rendezvous over gloo on the CPU,
+    shard 512 images 64 per rank (BASELINE configs[3]), barrier, reduce a time, one line."""
+    out = run_bench("--gpus", "8", "--dry-launch", "--steps", "2", "--warmup", "1")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_launch"] is True and d["images_total"] == 512 and d["steps"] == 2
+
+
+def test_under_torchrun_the_ranks_are_not_spawned_again():
+    """The driver's other form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` -- WORLD_SIZE is
+    set, so bench.py must NOT start ranks of its own; rank 0 alone prints the line."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                         timeout=300, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    assert json.loads(lines[0])["n_gpus"] == 2
+
+
 def test_a_failing_rank_fails_the_command():
     # --gpus 2 but the children are told a batch the dry run rejects: make a rank exit non-zero through a bad flag
     out = run_bench("--gpus", "2", "--dry-launch", "--no-such-flag")

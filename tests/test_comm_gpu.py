@@ -97,6 +97,22 @@ def test_allgatherv_world1_equals_pack_points(extracted, self_p2p):
     ref = want.cpu().numpy().view(capi.SIFT_POINT_DTYPE).reshape(-1)
     for f in ("coords2D", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"):
         assert np.ascontiguousarray(got[f]).tobytes() == np.ascontiguousarray(ref[f]).tobytes(), f
+    # ... and expanded on arrival (what bench.py's N > 1 step does): SiftPoint regions again, the 12 floats extraction
+    # never writes zeroed, everything else bit for bit
+    g5 = SiftGatherer(comm, 5, ex.max_pts, region_cap=total + 3, wire_format="trimmed", expand=True)
+    counts, gathered, totals = g5.gather(pts, cnt, producer=ex.ctx)
+    side.synchronize()
+    assert gathered.shape == (1, total + 3, 588) and int(totals[0]) == total
+    got = gathered[0, :total].cpu().numpy().view(capi.SIFT_POINT_DTYPE).reshape(-1)
+    for f in ("coords2D", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"):
+        assert np.ascontiguousarray(got[f]).tobytes() == np.ascontiguousarray(ref[f]).tobytes(), f
+    for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos", "match_error", "empty", "coords3D"):
+        assert not np.ascontiguousarray(got[f]).view(np.uint8).any(), f
+    with pytest.raises(ValueError):
+        SiftGatherer(comm, 5, ex.max_pts, wire_format="exact", expand=True)
+    # what the LIBRARY says about the communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion)
+    info = comm.info()
+    assert info["lib_ranks"] in (1, -1) and info["lib_rank"] in (0, -1)
     comm.set_wire_format("exact")
     with pytest.raises(capi.CusiftError):
         comm.set_wire_format(5)

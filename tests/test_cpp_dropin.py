@@ -15,6 +15,7 @@ BIN_MULTI = os.path.join(CPP, "multigpu_dropin")
 BIN_PIPE = os.path.join(CPP, "pipeline_dropin")
 BIN_TILED = os.path.join(CPP, "tiled_dropin")
 BIN_HOSTPIPE = os.path.join(CPP, "hostpipe_dropin")
+BIN_SCALING = os.path.join(CPP, "scaling_bench")
 
 
 def build():
@@ -25,7 +26,7 @@ def build():
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED, BIN_HOSTPIPE):
+    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED, BIN_HOSTPIPE, BIN_SCALING):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -95,6 +96,27 @@ def test_dropin_multigpu_program_passes_on_one_gpu(tmp_path):
     print(out.stdout[-2000:], out.stderr[-2000:])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "PASSED" in out.stdout and "rccl" in out.stdout.lower()
+
+
+@pytest.mark.gpu
+def test_scaling_bench_rank_program_prints_the_benchmark_line(tmp_path):
+    """tests/cpp/scaling_bench: the multi-GPU benchmark step as a C++ rank program over the C ABI (no torch): W warm-up
+    steps, K timed steps between two barriers, all-gatherv every step (trimmed records expanded on arrival), ONE JSON
+    line from rank 0 with what the LIBRARY says about the communicator.  World 1 here (self send / recv through RCCL)."""
+    import json
+
+    build()
+    out = subprocess.run([BIN_SCALING, "0", "1", str(tmp_path / "comm.id"), os.path.join(ROOT, "tests", "golden", "gray1.pgm"),
+                          "4", "2", "5", "640", "480", "2"], capture_output=True, text=True, timeout=300)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["rccl_version"] > 20000 and "rccl" in d["config"]["rccl_library"]
+    assert d["config"]["gather_record_bytes"] == 540 and len(d["config"]["ms_per_step_by_rank"]) == 1
+    assert d["records_gathered_per_step"] == d["keypoints_per_step_rank0"] > 100
 
 
 @pytest.mark.gpu

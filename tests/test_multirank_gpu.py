@@ -179,11 +179,17 @@ def test_allgatherv_trimmed_wire_format(ctx, gray1):
         d_cnt = DeviceBuffer.from_numpy(c, np.array([n], np.uint32))
         out = DeviceBuffer(c, world * region_cap * 540)
         counts, totals = comm.allgatherv(d_pts.ptr, d_cnt.ptr, 1, prm.max_pts, 1, out.ptr, region_cap)
+        # expand on arrival (cusift_expand_gathered): SiftPoint regions, one launch behind the exchange
+        exact = DeviceBuffer(c, world * region_cap * 588)
+        c.memset(exact.ptr, 0x5A, world * region_cap * 588)
+        comm.expand_gathered(out.ptr, region_cap, totals, exact.ptr)
         c.synchronize()
         got = out.to_numpy(np.uint8, (world, region_cap, 540))
+        full = exact.to_numpy(np.uint8, (world, region_cap, 588)).copy()
+        info = comm.info()
         comm.close()
         c.close()
-        return h[:n].copy(), got, [int(t) for t in totals]
+        return h[:n].copy(), got, [int(t) for t in totals], full, info
 
     res = run_ranks(world, rank_fn)
     for r in range(world):
@@ -191,8 +197,15 @@ def test_allgatherv_trimmed_wire_format(ctx, gray1):
             want = res[src][0]
             assert res[r][2][src] == len(want) > 300
             got = capi.expand_trimmed(res[r][1][src, : len(want)].copy().view(capi.TRIMMED_POINT_DTYPE).reshape(-1))
+            full = res[r][3][src, : len(want)].copy().view(SIFT_POINT_DTYPE).reshape(-1)
             for f in ("coords2D", "scale", "sharpness", "edgeness", "orientation", "subsampling", "data"):
                 assert np.ascontiguousarray(got[f]).tobytes() == np.ascontiguousarray(want[f]).tobytes(), (r, src, f)
+                assert np.ascontiguousarray(full[f]).tobytes() == np.ascontiguousarray(want[f]).tobytes(), (r, src, f)
+            for f in ("score", "ambiguity", "match", "match_xpos", "match_ypos", "match_error", "empty", "coords3D"):
+                assert not np.ascontiguousarray(full[f]).view(np.uint8).any(), (r, src, f)
+            # nothing beyond a region's records is written
+            assert np.all(res[r][3][src, len(want):] == 0x5A)
+        assert res[r][4]["lib_ranks"] in (world, -1)
 
 
 def test_allgatherv_overflow_is_the_same_error_on_every_rank():
