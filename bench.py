@@ -538,8 +538,8 @@ def main():
     # steady state; staggering the streams' starts changes nothing, a region that follows another without a gap starts
     # at the steady rate).  W = 5 steps is 5 ms.  config.preflight_steps says how many ran; the repeat leg reports the
     # same region started from idle (`ms_per_step_from_idle`) beside it.
-    PREFLIGHT = 6 * E * n_slots
-    for _ in range(PREFLIGHT):
+    PREFLIGHT = 7 * E * n_slots
+    for _ in range(E * n_slots):
         pipe.submit(d_imgs)
     pipe.synchronize()
     ref_counts = exs[0].slots[0][1].clone()
@@ -547,6 +547,11 @@ def main():
         for _, cnt_t in x.slots:
             if not torch.equal(cnt_t, ref_counts):
                 raise SystemExit("bench.py: pre-flight: extractors disagree on the keypoint counts of the same batch")
+    # (the comparison above is torch's first work in the process -- tens of milliseconds of lazy initialisation during
+    # which the device idles -- so the load that takes it out of its idle clocks comes AFTER it, with nothing but
+    # enqueueing between here and the timed region's fence)
+    for _ in range(PREFLIGHT - E * n_slots):
+        pipe.submit(d_imgs)
     for _ in range(args.warmup):
         step()
     fence()
@@ -763,10 +768,12 @@ def main():
     if rank == 0 and legs:
         torch.cuda.synchronize()
         if "repeat" in legs and not use_dist:
-            reps = sorted(run_pipelined(d_imgs, K, warm=0) for _ in range(4))
+            reps_in_order = [run_pipelined(d_imgs, K, warm=0) for _ in range(4)]
+            reps = sorted(reps_in_order)
             allr = sorted(reps + [elapsed / K * 1e3])
             out["ms_per_step_spread"] = {"min": round(allr[0], 4), "median": round(allr[len(allr) // 2], 4),
                                          "max": round(allr[-1], 4), "regions": len(allr),
+                                         "in_order": [round(elapsed / K * 1e3, 4)] + [round(r, 4) for r in reps_in_order],
                                          "note": "the timed region (`ms_per_step`) and 4 repeats of it, K steps each"}
             time.sleep(0.05)  # what a region costs that starts from an idle device (no pre-flight, no warm-up)
             out["ms_per_step_spread"]["ms_per_step_from_idle"] = round(run_pipelined(d_imgs, K, warm=0), 4)

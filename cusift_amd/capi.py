@@ -830,7 +830,7 @@ class Pipe:
         check(lib().cusift_pipe_submit(self._h, a.ctypes.data, int(a.shape[0])))
 
     def collect(self):
-        """-> (records: SIFT_POINT_DTYPE view of the pinned slot, offsets [n + 1]); valid until `depth` more submits."""
+        """-> (records: SIFT_POINT_DTYPE view of the pinned slot, offsets [n + 1]); valid until the next collect()."""
         rec, off = C.c_void_p(), C.c_void_p()
         n, total = C.c_int(0), C.c_size_t(0)
         check(lib().cusift_pipe_collect(self._h, C.byref(rec), C.byref(off), C.byref(n), C.byref(total)))

@@ -54,7 +54,7 @@ struct Slot {
   unsigned int *d_counters = nullptr;  // [n]
   cusift_point *d_packed = nullptr;  // [capacity]
   unsigned int *d_offsets = nullptr;  // [n + 1]
-  cusift_point *h_records = nullptr;  // pinned, [capacity]
+  cusift_point *h_records = nullptr;  // pinned, [capacity]: the host buffer this batch lands in (one of depth + 1, below)
   unsigned int *h_offsets = nullptr;  // pinned, [n + 1]
   hipEvent_t ev_up = nullptr, ev_counts = nullptr, ev_copied = nullptr;
   int n = 0;            // images of the batch in flight
@@ -72,6 +72,12 @@ struct cusift_pipe {
   std::vector<cusift_ctx *> ex;  // extraction contexts (own streams)
   hipStream_t up = nullptr, copy = nullptr;
   std::vector<Slot> slots;
+  // The pinned host buffers are one MORE than the slots and are dealt out round robin at submit: with at most `depth`
+  // batches in flight, the buffer of the batch collected last is never the next to be written -- a collected view stays
+  // valid through any number of submits, until the next collect (round 4 documented "until depth further submits", which
+  // the slot-indexed buffers did not hold: at full depth the very next submit re-used the collected slot).
+  std::vector<cusift_point *> h_records;   // [depth + 1] pinned, [capacity] each
+  std::vector<unsigned int *> h_offsets;   // [depth + 1] pinned, [n + 1] each
   unsigned long submitted = 0, collected = 0;
   bool failed = false;
 };
@@ -88,11 +94,13 @@ void free_pipe(cusift_pipe *p) {
     if (s.d_counters) (void)hipFree(s.d_counters);
     if (s.d_packed) (void)hipFree(s.d_packed);
     if (s.d_offsets) (void)hipFree(s.d_offsets);
-    if (s.h_records) (void)hipHostFree(s.h_records);
-    if (s.h_offsets) (void)hipHostFree(s.h_offsets);
     for (hipEvent_t e : {s.ev_up, s.ev_counts, s.ev_copied})
       if (e) (void)hipEventDestroy(e);
   }
+  for (cusift_point *h : p->h_records)
+    if (h) (void)hipHostFree(h);
+  for (unsigned int *h : p->h_offsets)
+    if (h) (void)hipHostFree(h);
   for (cusift_ctx *c : p->ex) (void)cusift_ctx_destroy(c);
   if (p->up) (void)hipStreamDestroy(p->up);
   if (p->copy) (void)hipStreamDestroy(p->copy);
@@ -185,11 +193,15 @@ extern "C" int cusift_pipe_create(cusift_pipe **out, int device, int n_images, i
     hip(hipMalloc((void **)&s.d_counters, sizeof(unsigned int) * n_images), "hipMalloc");
     hip(hipMalloc((void **)&s.d_packed, std::max<size_t>(1, p->capacity) * sizeof(cusift_point)), "hipMalloc");
     hip(hipMalloc((void **)&s.d_offsets, sizeof(unsigned int) * (n_images + 1)), "hipMalloc");
-    hip(hipHostMalloc((void **)&s.h_records, std::max<size_t>(1, p->capacity) * sizeof(cusift_point), hipHostMallocDefault),
-        "hipHostMalloc");
-    hip(hipHostMalloc((void **)&s.h_offsets, sizeof(unsigned int) * (n_images + 1), hipHostMallocDefault), "hipHostMalloc");
     for (hipEvent_t *e : {&s.ev_up, &s.ev_counts, &s.ev_copied})
       hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+  }
+  p->h_records.assign(depth + 1, nullptr);
+  p->h_offsets.assign(depth + 1, nullptr);
+  for (int j = 0; j <= depth && rc == CUSIFT_OK; ++j) {
+    hip(hipHostMalloc((void **)&p->h_records[j], std::max<size_t>(1, p->capacity) * sizeof(cusift_point), hipHostMallocDefault),
+        "hipHostMalloc");
+    hip(hipHostMalloc((void **)&p->h_offsets[j], sizeof(unsigned int) * (n_images + 1), hipHostMallocDefault), "hipHostMalloc");
   }
   if (rc == CUSIFT_OK) hip(hipStreamSynchronize(p->up), "hipStreamSynchronize");
   if (rc != CUSIFT_OK) {
@@ -219,17 +231,27 @@ extern "C" int cusift_pipe_submit(cusift_pipe *p, const void *h_frames, int n_im
   Slot &s = p->slots[p->submitted % p->depth];
   cusift_ctx *ctx = p->ex[p->submitted % p->ex.size()];
   hipStream_t st = (hipStream_t)cusift_ctx_stream(ctx);
+  // From the first enqueue on, ANY failure leaves work for this slot in flight that nothing accounts for (`submitted` has
+  // not moved): the pipeline is then marked failed -- every later call refuses -- instead of re-using the slot.
+#define PIPE_HIP(expr)                                                                                                   \
+  do {                                                                                                                   \
+    hipError_t e_ = (expr);                                                                                              \
+    if (e_ != hipSuccess) {                                                                                              \
+      p->failed = true;                                                                                                  \
+      return cusift_fail(CUSIFT_ERR_HIP, "pipe: %s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                                                    \
+  } while (0)
   // (the slot's previous batch was collected: its upload, extraction, pack and copy have all completed)
   const size_t row = (size_t)p->w * (p->format == CUSIFT_PIPE_U8 ? 1 : sizeof(float));
   if (p->format == CUSIFT_PIPE_U8 || p->pitch == p->w) {
     void *dst = p->format == CUSIFT_PIPE_U8 ? (void *)s.d_u8 : (void *)s.d_img;
-    HIP_TRY(hipMemcpyAsync(dst, h_frames, row * p->h * n_images, hipMemcpyHostToDevice, p->up));
+    PIPE_HIP(hipMemcpyAsync(dst, h_frames, row * p->h * n_images, hipMemcpyHostToDevice, p->up));
   } else {  // dense host rows -> pitched device rows (cuImage::HostToDevice, cuImage.cu:83-92)
-    HIP_TRY(hipMemcpy2DAsync(s.d_img, (size_t)p->pitch * sizeof(float), h_frames, row, row, (size_t)p->h * n_images,
-                             hipMemcpyHostToDevice, p->up));
+    PIPE_HIP(hipMemcpy2DAsync(s.d_img, (size_t)p->pitch * sizeof(float), h_frames, row, row, (size_t)p->h * n_images,
+                              hipMemcpyHostToDevice, p->up));
   }
-  HIP_TRY(hipEventRecord(s.ev_up, p->up));
-  HIP_TRY(hipStreamWaitEvent(st, s.ev_up, 0));
+  PIPE_HIP(hipEventRecord(s.ev_up, p->up));
+  PIPE_HIP(hipStreamWaitEvent(st, s.ev_up, 0));
   int rc = CUSIFT_OK;
   if (p->format == CUSIFT_PIPE_U8)
     rc = cusift_u8_to_f32(ctx, s.d_img, p->pitch, (size_t)p->h * p->pitch, s.d_u8, p->w, p->h, p->w, (size_t)p->h * p->w,
@@ -248,8 +270,12 @@ extern "C" int cusift_pipe_submit(cusift_pipe *p, const void *h_frames, int n_im
     p->failed = true;
     return rc;
   }
-  HIP_TRY(hipMemcpyAsync(s.h_offsets, s.d_offsets, sizeof(unsigned int) * (n_images + 1), hipMemcpyDeviceToHost, ps));
-  HIP_TRY(hipEventRecord(s.ev_counts, ps));
+  // this batch's host buffers: the next of depth + 1 (never the one handed out by the last collect)
+  s.h_records = p->h_records[p->submitted % (p->depth + 1)];
+  s.h_offsets = p->h_offsets[p->submitted % (p->depth + 1)];
+  PIPE_HIP(hipMemcpyAsync(s.h_offsets, s.d_offsets, sizeof(unsigned int) * (n_images + 1), hipMemcpyDeviceToHost, ps));
+  PIPE_HIP(hipEventRecord(s.ev_counts, ps));
+#undef PIPE_HIP
   s.n = n_images;
   s.busy = true;
   s.copying = false;
@@ -272,7 +298,13 @@ extern "C" int cusift_pipe_collect(cusift_pipe *p, const cusift_point **h_record
     return rc;
   }
   Slot &s = p->slots[p->collected % p->depth];
-  HIP_TRY(hipEventSynchronize(s.ev_copied));
+  {
+    const hipError_t e = hipEventSynchronize(s.ev_copied);
+    if (e != hipSuccess) {
+      p->failed = true;
+      return cusift_fail(CUSIFT_ERR_HIP, "pipe: hipEventSynchronize failed: %s", hipGetErrorString(e));
+    }
+  }
   if (h_records) *h_records = s.h_records;
   if (h_offsets) *h_offsets = s.h_offsets;
   if (n_images) *n_images = s.n;

@@ -522,12 +522,19 @@ int cusift_exchange_halos(cusift_comm *comm, float *d_band, int pitch, int top_h
  *            (CUSIFT_PIPE_F32, values 0..255 as the reference expects); depth 2..8; records_capacity = records one
  *            batch's SiftData may hold (0: n_images * max_pts -- generous: pinned memory per slot).
  *   submit   asynchronous: enqueues one batch ([n_images][h][w], pinned memory recommended -- pageable memory makes
- *            the upload synchronous); fails if `depth` batches are in flight already.  The frames must stay untouched
- *            until the batch has been collected.
+ *            the upload synchronous); fails if `depth` batches are in flight already.  h_frames is READ by the upload,
+ *            which runs some time after submit returns: the frames must stay untouched until THIS batch has been
+ *            collected (there is no earlier signal; a caller that recycles frame buffers needs depth + 1 of them).
  *   collect  the OLDEST batch in flight: blocks until its records are on the host; *h_records = its `*total` valid
  *            records back to back in image order (SiftPoint layout), h_offsets[0 .. n] = their exclusive prefix sums
- *            per image (image i: records [h_offsets[i], h_offsets[i + 1])).  The pointers stay valid until `depth`
- *            further batches have been submitted.  More records than the capacity: CUSIFT_ERR_NOMEM. */
+ *            per image (image i: records [h_offsets[i], h_offsets[i + 1])).  The pointers stay valid until the NEXT
+ *            cusift_pipe_collect, through any number of submits in between (the pipeline owns depth + 1 pinned result
+ *            buffers: the one handed out last is never the next to be written).
+ *   errors   a batch with more records than records_capacity: CUSIFT_ERR_NOMEM from the submit / collect that finds
+ *            out -- the reference saturates at maxPts per image instead (cuSIFT.cu:110), which max_pts still does; the
+ *            batch capacity is this pipeline's own limit.  After ANY error from submit or collect other than
+ *            CUSIFT_ERR_INVALID (bad arguments, nothing enqueued) the pipeline is FAILED: work of unknown state is in
+ *            flight, every later submit / collect refuses, the batches in flight are lost; destroy it. */
 typedef struct cusift_pipe cusift_pipe;
 enum { CUSIFT_PIPE_U8 = 0, CUSIFT_PIPE_F32 = 1 };
 int cusift_pipe_create(cusift_pipe **out, int device, int n_images, int w, int h, const cusift_params *prm,

@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "cusift_amd.h"
 
 #define CHECK(call)                                                                 \
@@ -95,6 +97,12 @@ int main(int argc, char **argv) {
   std::vector<float> base;
   int bw = 0, bh = 0;
   if (!read_pgm(argv[4], base, bw, bh) || world < 1 || rank < 0 || rank >= world || K < 1 || B < 1 || E < 1 || W % 4) return 2;
+
+  // Rank 0 prints exactly ONE line on stdout.  Libraries write there too (RCCL prints a banner when a communicator is
+  // created), so from here on file descriptor 1 is stderr and the JSON line goes to a duplicate of the original stdout.
+  std::fflush(stdout);
+  const int json_fd = dup(1);
+  dup2(2, 1);
 
   int n_dev = 0;
   CHECK(cusift_device_count(&n_dev));
@@ -259,6 +267,8 @@ int main(int argc, char **argv) {
       std::snprintf(b, sizeof(b), "%s%.4f", r ? ", " : "", ms[r] / K);
       by_rank += b;
     }
+    std::fflush(stdout);
+    dup2(json_fd, 1);
     std::printf(
         "{\"metric\": \"Mpix/s pyramid + keypoints/s end-to-end, 1920x1080 batch\", \"value\": %.2f, \"unit\": \"Mpix/s\", "
         "\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": "

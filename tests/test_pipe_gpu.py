@@ -85,6 +85,31 @@ def check(rec, off, want):
         assert same_set(got, w_i), i
 
 
+def test_pipe_collected_view_survives_submits_at_full_depth(ctx, gray1):
+    """The contract of cusift_pipe_collect's pointers: valid until the NEXT collect, through any number of submits in
+    between.  At full depth the first submit after a collect re-uses the DEVICE slot just collected -- the pinned host
+    buffers are one more than the slots, so the view handed out must not change under it (round 4's header said "until
+    depth further submits", which the slot-indexed buffers did not hold: the advisor's finding)."""
+    prm = capi.default_params(num_octaves=4, init_blur=0.0, peak_thresh=1.0, max_pts=4096)
+    frames = [np.ascontiguousarray(np.stack([np.roll(gray1, (13 * k + i, 29 * k + 3 * i), axis=(0, 1)) for i in range(2)]),
+                                   dtype=np.uint8) for k in range(7)]
+    depth = 2
+    with capi.Pipe(0, 2, 640, 480, prm, capi.PIPE_U8, depth=depth) as pipe:
+        for k in range(depth):
+            pipe.submit(frames[k])
+        for k in range(depth, len(frames)):
+            rec, off = pipe.collect()  # views, not copies
+            snap_rec, snap_off = rec.copy(), off.copy()
+            assert len(rec) > 500
+            pipe.submit(frames[k])  # full again: re-uses the device slot of the batch just collected
+            # let the new batch's offsets copy and records copy land before looking (they are what would tear the view)
+            import time
+            time.sleep(0.05)
+            assert np.array_equal(off, snap_off) and rec.tobytes() == snap_rec.tobytes()
+        while pipe.in_flight():
+            pipe.collect()
+
+
 def test_pipe_capacity_overflow_is_an_error(ctx, gray1):
     prm = capi.default_params(num_octaves=3, init_blur=0.0, peak_thresh=0.5, max_pts=4096)
     frames = np.stack([gray1, gray1[::-1].copy()]).astype(np.uint8)
