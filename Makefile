@@ -31,7 +31,7 @@ LIB        := $(ROOT)/cusift_amd/libcusift_amd.so
 LIB_LAB    := $(ROOT)/cusift_amd/libcusift_amd_lab.so
 LIB_STAMPS := $(ROOT)/cusift_amd/libcusift_amd_stamps.so
 
-.PHONY: all lab stamps oracle cpp-tests check install clean
+.PHONY: all lab stamps ab oracle cpp-tests check install clean
 all: $(LIB)
 lab: $(LIB_LAB)
 stamps: $(LIB_STAMPS)
@@ -48,6 +48,13 @@ endef
 $(eval $(call variant,product,,$(LIB)))
 $(eval $(call variant,lab,-DCUSIFT_LAB,$(LIB_LAB)))
 $(eval $(call variant,stamps,-DCUSIFT_STAMPS,$(LIB_STAMPS)))
+
+# an experiment's build for a same-box A/B (tools/ab_libs.sh): make ab NAME=x DEFS="-DCUSIFT_SOMETHING" -> tools/ab/x.so
+NAME ?= variant
+$(eval $(call variant,ab_$(NAME),$(DEFS),$(ROOT)/tools/ab/$(NAME).so))
+ab:
+	@mkdir -p $(ROOT)/tools/ab
+	$(MAKE) -f $(lastword $(MAKEFILE_LIST)) $(ROOT)/tools/ab/$(NAME).so NAME=$(NAME) DEFS="$(DEFS)"
 
 oracle:
 	$(MAKE) -C $(ROOT)/oracle

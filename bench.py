@@ -888,14 +888,17 @@ def main():
                                             waves_per_simd=mix["waves_per_simd"],
                                             bound_ms_per_step=round(bound_ms[0], 4),
                                             frac_of_issue_bound=round(bound_ms[0] / (ms / K), 4),
-                                            bound_ms_per_step_at_occupancy=round(bound_ms[1], 4),
-                                            frac_at_own_occupancy=round(bound_ms[1] / (ms / K), 4),
+                                            model_ms_per_step_at_own_occupancy=round(bound_ms[1], 4),
                                             note="bound_ms / measured ms: 1.0 = the vector pipes issue back to back.  "
                                                  "frac_of_issue_bound prices each class at the best the SIMD does for "
-                                                 "it (eight resident waves), frac_at_own_occupancy at its cost with "
-                                                 "this kernel's resident waves (two waves: a slow-class instruction "
-                                                 "4.6-5.7 cycles by run, 5.1 used); the mix is a static estimate "
-                                                 "(profiles/isa_mix.json)")
+                                                 "it (eight resident waves): a BOUND.  model_ms_per_step_at_own_occupancy "
+                                                 "prices the classes at what independent chains cost with this kernel's "
+                                                 "resident waves (two waves: a slow-class instruction 4.6-5.7 cycles by "
+                                                 "run, 5.1 used) -- a MODEL, not a bound: round 4 printed its ratio to the "
+                                                 "measurement as `frac_at_own_occupancy` and it came out at 1.06 for the "
+                                                 "description kernel (its LDS and memory instructions interleave with the "
+                                                 "vector ones better than the microbenchmark's chains do); the field is "
+                                                 "gone.  The mix is a static estimate (profiles/isa_mix.json)")
                 return r
 
             rk = []

@@ -1,4 +1,5 @@
-"""Builds libcusift_amd.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc.
+"""Builds libcusift_amd.so (HIP kernels + C ABI) for gfx950 in-tree with hipcc -- by running the top-level Makefile, the
+one recipe of this repository (a C++ caller needs no Python: `make`, or the CMakeLists.txt next to it).
 
     python -m cusift_amd.build [--force] [--lab] [--stamps]
 
@@ -19,12 +20,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcusift_amd.so")
-SOURCES = ["sift_context.hip", "sift_stages.hip", "sift_driver.hip", "sift_stencils.hip", "sift_keypoints.hip", "sift_match.hip",
-           "sift_frontend.hip", "sift_homography.hip", "sift_comm.hip", "sift_tiled.hip", "sift_pipe.hip"]
-HEADERS = [os.path.join(CSRC, "detect_chunk.inc"), os.path.join(CSRC, "sift_types.h"), os.path.join(CSRC, "sift_device.h"), os.path.join(CSRC, "sift_math.h"), os.path.join(CSRC, "sift_internal.h"), os.path.join(CSRC, "sift_host.h"),
-           os.path.join(HERE, "..", "include", "cusift_amd.h")]
 
-# -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).
+# The flags of the Makefile (HIPFLAGS there), for the tools that compile a translation unit to assembly themselves
+# (tools/isa_mix.py, tools/kernel_regs.py).  -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls (see sift_types.h).
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -50,47 +48,29 @@ def find_hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
-
-
+ROOT = os.path.dirname(HERE)
 LAB_LIB = os.path.join(HERE, "libcusift_amd_lab.so")
 STAMPS_LIB = os.path.join(HERE, "libcusift_amd_stamps.so")  # --stamps: -DCUSIFT_STAMPS, for tools/describe_stamps.py
 
 
+def is_stale():
+    """make's own judgement (`make -q`): objects older than their sources or headers, or no library yet."""
+    return subprocess.call(["make", "-q", "-C", ROOT, "all", "HIPCC=" + find_hipcc()], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL) != 0
+
+
 def build(force=False, verbose=False, lab=False, stamps=False):
-    """Compile the HIP extension for gfx950 if missing or older than its sources. Returns the path."""
-    if stamps:
-        cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DCUSIFT_STAMPS", "-o", STAMPS_LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return STAMPS_LIB
-    if lab:
-        cmd = [find_hipcc()] + HIPCC_FLAGS + ["-DCUSIFT_LAB", "-o", LAB_LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return LAB_LIB
-    if not force and not is_stale():
-        return LIB
-    # build into a temporary file and rename it onto LIB: a concurrent rank that loads the library (or builds it too)
-    # never sees a half-written shared object
-    tmp = "%s.%d.tmp" % (LIB, os.getpid())
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    """Compile the HIP extension for gfx950 if missing or older than its sources (make decides). Returns the path.
+    One object per translation unit under build/obj, compiled in parallel; the link goes to a temporary file that is
+    renamed onto the library, so a concurrent rank that loads (or builds) it never sees a half-written shared object."""
+    target, lib = ("stamps", STAMPS_LIB) if stamps else (("lab", LAB_LIB) if lab else ("all", LIB))
+    cmd = ["make", "-C", ROOT, "-j%d" % max(1, min(8, os.cpu_count() or 1)), target, "HIPCC=" + find_hipcc()]
+    if force:
+        cmd.insert(1, "-B")
     if verbose:
         print(" ".join(cmd))
-    try:
-        subprocess.check_call(cmd)
-        os.replace(tmp, LIB)
-    finally:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-    return LIB
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return lib
 
 
 if __name__ == "__main__":

@@ -309,9 +309,14 @@ bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_imag
 // o's detection writes octave o + 1's image from its own row window, so the ScaleDown launches -- 0.2 ms of HBM-bound
 // re-reading per 64 x 1080p, a fifth of a lone caller's step -- disappear for ~5 % more vector instructions in the
 // detection, and the octaves are searched finest first (lists per octave).  What it costs is the one-launch detection
-// of the coarser octaves: a chain of dependent launches has a tail per octave.  So by default: calls of at least
-// kPyramidInDetectMinPixels, every octave.  0: never; 1: octave 0 only; 2: every octave.
-constexpr size_t kPyramidInDetectMinPixels = 6u << 20;
+// of the coarser octaves: a chain of dependent launches has a tail per octave, which a caller with several batches in
+// flight fills with the other batches' kernels and a lone caller does not.  Measured on MI355X (tools/ab_pyramid.py,
+// profiles/r05/ab_pyramid_by_size.txt; 1080p frames per call, ms per call, ScaleDown chain first -> every octave):
+//   four calls in flight  1: 0.0409 -> 0.0390   3: 0.0776 -> 0.0725   8: 0.1645 -> 0.1450   16: 0.288 -> 0.267   64: 1.033 -> 0.976
+//   a lone caller         1: 0.0649 -> 0.0973  16: 0.342 -> 0.392    32: 0.645 -> 0.662    48: 0.941 -> 0.932   64: 1.241 -> 1.153
+// So by default: a pipelining caller (concurrent_batches >= 2) from one 1080p frame's worth of pixels up, a lone caller
+// from 96 Mpixel per call (46 frames).  0: never; 1: octave 0 only; 2: every octave.
+constexpr size_t kPyramidInDetectMinPixelsPipelined = 2u << 20, kPyramidInDetectMinPixelsLone = 96u << 20;
 int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h) {
   const int mode = ctx->knobs.pyramid_in_detect;
   if (mode == 0 || ctx->knobs.force_generic || ctx->knobs.stage_all == 0) return 0;
@@ -319,7 +324,8 @@ int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int
   // (the stage timers do not change this: every launch of the finest-first sequence is a detection launch and is
   // bracketed as one -- the ScaleDown stage then simply reports no launches)
   if (mode > 0) return std::min(mode, 2);
-  return (size_t)n_images * (size_t)w * (size_t)h >= kPyramidInDetectMinPixels ? 2 : 0;
+  const size_t px = (size_t)n_images * (size_t)w * (size_t)h;
+  return px >= (prm->concurrent_batches >= 2 ? kPyramidInDetectMinPixelsPipelined : kPyramidInDetectMinPixelsLone) ? 2 : 0;
 }
 
 // OPT-IN since round 4 (cusift_ctx_set_policy(ctx, CUSIFT_POLICY_SIDE_STREAM, 1 | 2), or CUSIFT_OCTAVE_OVERLAP=1 | 2 in the

@@ -183,8 +183,24 @@ __global__ void __launch_bounds__(256) laplace_multi_kernel(const float *__restr
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#ifdef CUSIFT_BLUR_BPERMUTE
+// experiment (tools/ab_libs.sh): the blur's neighbour exchange on the LDS crossbar (ds_bpermute_b32: no VALU issue slot)
+// instead of DPP moves (slow-class VALU instructions, 18 % of the blur's)
+__device__ __forceinline__ float bperm(int addr, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f2 dpp_prev2(f2 v) {
+  const int a = (((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) - 1) & 63) * 4;
+  return f2{bperm(a, v.x), bperm(a, v.y)};
+}
+__device__ __forceinline__ f2 dpp_next2(f2 v) {
+  const int a = (((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + 1) & 63) * 4;
+  return f2{bperm(a, v.x), bperm(a, v.y)};
+}
+#else
 __device__ __forceinline__ f2 dpp_prev2(f2 v) { return f2{from_prev_lane(v.x), from_prev_lane(v.y)}; }
 __device__ __forceinline__ f2 dpp_next2(f2 v) { return f2{from_next_lane(v.x), from_next_lane(v.y)}; }
+#endif
 
 template <int kStoreAux>
 __global__ void __launch_bounds__(256) laplace_multi_fast_kernel(const float *__restrict__ img,

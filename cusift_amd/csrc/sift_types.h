@@ -8,7 +8,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "../../include/cusift_amd.h"
+#include "../../include/cusift_amd_all.h"
 
 namespace cusift {
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "cuSIFT.h"
+#include "cusift_amd_extras.h"
 
 // Returns the elapsed milliseconds like the reference.  homography: 9 floats (row-major 3x3, h[8] = 1);
 // *numMatches: inliers of the winning hypothesis among ALL numPts points of `data`.

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "cuSIFT.h"
+#include "cusift_amd_extras.h"
 
 typedef enum { MatchSiftDistanceDotProduct, MatchSiftDistanceL2 } MatchSiftDistance;
 typedef enum { MatchType2D, MatchType3D } MatchType;

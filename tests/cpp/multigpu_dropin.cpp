@@ -18,6 +18,7 @@
 #include "cuImage.h"
 #include "cuSIFT.h"
 #include "cusift_amd.h"
+#include "cusift_amd_multigpu.h"
 
 #define CHECK(call)                                                              \
   do {                                                                           \

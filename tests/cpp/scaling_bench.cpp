@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include "cusift_amd.h"
+#include "cusift_amd_multigpu.h"
 
 #define CHECK(call)                                                                 \
   do {                                                                              \

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cusift_amd.h"
+#include "cusift_amd_multigpu.h"
 
 #define CHECK(call)                                                                    \
   do {                                                                                 \

@@ -50,8 +50,11 @@ sys.path.insert(0, ROOT)
 from cusift_amd import build as B  # noqa: E402
 
 KERNELS = {  # name -> (source, mangled-name needle, block selector)
-    "detect_fused_kernel": ("sift_stencils.hip", "detect_fused_kernelILb1E", "detect"),  # <kIdent0>: the benchmark's octave 0
-    "detect_fused_kernel<false>": ("sift_stencils.hip", "detect_fused_kernelILb0E", "detect"),
+    # the instantiations the benchmark's step launches since round 5 (heads to a list per octave, the next octave's image
+    # as a by-product): <kIdent0 = true, 64, kDown = true> is octave 0, <false, 64, true> octaves 1 .. 3
+    "detect_fused_kernel": ("sift_stencils.hip", "detect_fused_kernelILb1ELi64ELb1E", "detect"),
+    "detect_fused_kernel<false>": ("sift_stencils.hip", "detect_fused_kernelILb0ELi64ELb1E", "detect"),
+    "detect_fused_kernel<true, 588, false> (round 4's octave 0)": ("sift_stencils.hip", "detect_fused_kernelILb1ELi588ELb0E", "detect"),
     "describe_all_kernel": ("sift_keypoints.hip", "describe_all_kernel", "loop"),
     "laplace_multi_fast_kernel": ("sift_stencils.hip", "laplace_multi_fast_kernelILi2E", "loop"),
 }
@@ -60,7 +63,8 @@ BEST = {"fast": 2.65, "slow": 4.2, "transcendental": 8.2}
 CYCLES = {"best": BEST,
           2: {"fast": 3.0, "slow": 5.1, "transcendental": 8.7},   # slow: 4.6-5.7 by run, fast: 2.8-3.2
           4: {"fast": 2.75, "slow": 4.5, "transcendental": 8.3}}
-WAVES = {"detect_fused_kernel": 2, "detect_fused_kernel<false>": 2, "describe_all_kernel": 4,
+WAVES = {"detect_fused_kernel": 2, "detect_fused_kernel<false>": 2,
+         "detect_fused_kernel<true, 588, false> (round 4's octave 0)": 2, "describe_all_kernel": 4,
          "laplace_multi_fast_kernel": 4}
 TRANSCENDENTAL = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
 FAST = ("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32",
