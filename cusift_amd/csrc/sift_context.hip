@@ -20,8 +20,10 @@ int cusift_fail(int code, const char *fmt, ...) {
 
 Knobs read_knobs() {
   Knobs k;
-  if (const char *e = getenv("CUSIFT_OCTAVE_OVERLAP")) k.octave_overlap = std::max(0, std::min(3, atoi(e)));
+  // (the product build reads NO environment variable here: CUSIFT_OCTAVE_OVERLAP, the one it read until round 5 for
+  // unchanged callers of the C++ shim, is now read by that shim -- include/cuSIFT.h -- and set through cusift_ctx_set_policy)
 #ifdef CUSIFT_LAB
+  if (const char *e = getenv("CUSIFT_OCTAVE_OVERLAP")) k.octave_overlap = std::max(0, std::min(3, atoi(e)));
   auto text = [](const char *name) -> const char * { return getenv(name); };
   auto num = [&](const char *name, int unset) { const char *e = text(name); return e ? atoi(e) : unset; };
   k.rows_per_wave = num("CUSIFT_ROWS_PER_WAVE", 0);
@@ -350,6 +352,13 @@ __global__ void __launch_bounds__(64) spin_kernel(long ticks) {
 }
 
 int ensure_side_stream(cusift_ctx *ctx) {
+  // (policy value 2 is "after the probe": a stream taken without it -- under value 1 or 3 -- does not qualify; it is
+  // let go, once idle, and the probe runs)
+  if (ctx->side && ctx->knobs.octave_overlap == 2 && !ctx->side_probed) {
+    HIP_TRY(hipStreamSynchronize(ctx->side));
+    HIP_TRY(hipStreamDestroy(ctx->side));
+    ctx->side = nullptr;
+  }
   if (ctx->side) return CUSIFT_OK;
   if (ctx->side_failed) return fail(CUSIFT_ERR_HIP, "no side stream runs beside the context's stream");
   if (!ctx->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -361,6 +370,7 @@ int ensure_side_stream(cusift_ctx *ctx) {
   constexpr long kShort = 500, kLong = 12000;  // 5 us, 120 us
   int rc = CUSIFT_OK;
   if (ctx->knobs.octave_overlap != 2) {  // 1 / 3: no probe -- the caller says a second stream is worth having
+    ctx->side_probed = false;
     hipError_t e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -409,9 +419,10 @@ int ensure_side_stream(cusift_ctx *ctx) {
     if (ctx->knobs.side_debug)
       fprintf(stderr, "cusift: side stream candidate %d: probe chain alone %.1f us, beside the candidate %.1f us -> %s\n",
               attempt, alone * 1e3f, beside_ms * 1e3f, beside ? "kept" : "rejected");
-    if (beside)
+    if (beside) {
       ctx->side = cand;
-    else
+      ctx->side_probed = true;
+    } else
       rejected[n_rejected++] = cand;
   }
   for (int i = 0; i < n_rejected; ++i) (void)hipStreamDestroy(rejected[i]);

@@ -101,8 +101,8 @@ struct TimedSpan {
   int stage;
 };
 
-// Launch policy of a context.  The PRODUCT build reads exactly one environment variable (CUSIFT_OCTAVE_OVERLAP, so that
-// an unchanged caller of the C++ shim can opt in to the side stream); everything a test needs to force a driver path is
+// Launch policy of a context.  The PRODUCT build reads no environment variable for it (CUSIFT_OCTAVE_OVERLAP, for an
+// unchanged caller of the C++ shim, is read by the shim: include/cuSIFT.h); everything a test needs to force a driver path is
 // set per context through cusift_ctx_set_policy; the tuning overrides of the A/B tools (rows per wave, waves per
 // workgroup, cache policy of the DoG stores, ...) exist only in a -DCUSIFT_LAB build, which reads them from the
 // environment ONCE, when a context is created -- nothing on a launch path looks at the environment in either build.
@@ -159,6 +159,7 @@ struct cusift_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_failed = false;  // no stream was found that runs beside the context's stream: never fork
+  bool side_probed = false;  // `side` passed the concurrency probe (policy value 2 accepts no other)
   bool recording = false;  // inside cusift_graph_create's capture
   unsigned long forks = 0;  // extractions that took the side stream
   // the lists' counters in the arena that the last extraction's join_counts_kernel left zero (stream order): the next

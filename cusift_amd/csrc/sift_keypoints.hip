@@ -619,7 +619,9 @@ __device__ __forceinline__ int desc_elem(int lane) { return 8 * (lane & 15) + (l
 __device__ __forceinline__ float desc_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
 // The descriptor's angle coordinate 4/3.1415f * atan2f(dy, dx) + 4 (cuSIFT_D.cu:231-233).  The share a sample hands to
 // its two angle bins is continuous in this value, so it need not be sm_atan2f's to the ulp: atan t = t + t s Q(s) with Q
-// of degree 4 (Lawson fit as tools/fit_math_polys.py's: 2.4e-6 rad = 3.1e-6 of a bin, which reaches the descriptor as
+// of degree 4 in s = t^2 (Lawson fit as tools/fit_math_polys.py's: 2.4e-6 rad = 3.1e-6 of a bin; with v_rcp_f32's last
+// ulp on t the value is within 4e-6 OF A BIN of the oracle's -- THE bound, the one include/cusift_amd_stages.h states and
+// tests/test_gpu_parity.py::test_descriptor_angle_coordinate asserts (measured 3.8e-6) -- which reaches the descriptor as
 // ~4e-6 of its norm against the 1e-4 bar) and no low-order word on pi/2 -- 30 instructions per sample where the form
 // exact to the ulp took 38.  What is kept operation for operation is the ONE place where the value decides something: at
 // 8.0 the reference's index becomes 8 and the share lands in the next cell (cuSIFT_D.cu:233-255) -- a jump, at |atan2f| =

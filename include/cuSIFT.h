@@ -58,7 +58,17 @@ inline cusift_ctx *&ctx_slot() {
 }
 inline cusift_ctx *ctx() {
   cusift_ctx *&c = ctx_slot();
-  if (!c) safeCall(cusift_ctx_create(&c, device_slot(), nullptr));
+  if (!c) {
+    safeCall(cusift_ctx_create(&c, device_slot(), nullptr));
+    // An unchanged caller of the reference's API has no handle on the launch policy; the one knob such a caller may
+    // want -- octave 0's detection on a second stream, for large single batches -- is read HERE, in the shim that is
+    // compiled into the caller, from CUSIFT_OCTAVE_OVERLAP (0..3 = CUSIFT_POLICY_SIDE_STREAM's values).  The library
+    // itself reads no environment variable on the extraction path (until round 5 it read this one).
+    if (const char *e = std::getenv("CUSIFT_OCTAVE_OVERLAP")) {
+      const int v = std::atoi(e);
+      if (v >= 0 && v <= 3) safeCall(cusift_ctx_set_policy(c, CUSIFT_POLICY_SIDE_STREAM, v));
+    }
+  }
   return c;
 }
 inline void shutdown() {

@@ -131,8 +131,9 @@ size_t cusift_ctx_arena_bytes(cusift_ctx *ctx);
 /* Launch policy of a context (new; the reference has one fixed launch sequence, cuSIFT.cu:175-270).  Results never
  * depend on it -- only which kernels run on which stream in which order.  The defaults are deterministic functions of
  * the call's size and of cusift_params.concurrent_batches; nothing is decided by timing unless asked for (value 2 of
- * the first key).  The only environment variable the library's extraction code reads is CUSIFT_OCTAVE_OVERLAP (= the
- * first key's value, read when a context is created) so that an unchanged caller of the C++ shim can opt in. */
+ * the first key).  The library's extraction code reads NO environment variable (sift_comm.hip reads CUSIFT_RCCL_LIB to
+ * find the collective library): an unchanged caller of the C++ shim opts in to the first key through
+ * CUSIFT_OCTAVE_OVERLAP, which the shim itself reads (include/cuSIFT.h) and hands to cusift_ctx_set_policy. */
 enum {
   /* Octave 0's detection on a second stream of the context beside the ScaleDown chain and the coarser octaves, for
    * callers that keep ONE batch in flight (concurrent_batches < 2) and calls of >= 6 Mpixel: 0 never (default),
@@ -157,6 +158,9 @@ enum {
    * cuSIFT.cu:175-192), 1 octave 0 only (then the chain and the coarser octaves as with 0), 2 every octave. */
   CUSIFT_POLICY_PYRAMID_IN_DETECT = 6
 };
+/* (Changing a policy may change the launch plan and with it the size of the scratch arena: the next extraction then
+ * re-allocates it once -- a stream synchronisation -- unless cusift_ctx_reserve is called again first.  A recorded
+ * cusift_graph refuses to replay after such a re-allocation.) */
 int cusift_ctx_set_policy(cusift_ctx *ctx, int key, int value);
 int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value);
 /* An event on a context's stream: record, then the GPU time between two of them (blocks until `stop` has happened).

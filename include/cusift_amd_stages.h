@@ -98,7 +98,8 @@ int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h
  * 3 sincosf(a) -> (out, out2).  They are written out in IEEE operations (cusift_amd/csrc/sift_math.h) so that a host
  * build of the same header gives the same bits; this entry point exists so that callers and tests can verify that
  * on their device.  op 4: the descriptor stage's angle coordinate 4/3.1415f * atan2f(a, b) + 4 as its kernel forms it
- * (a degree-4 fit, within 4e-6 of the exact form, with the reference's operations where the value decides -- index 8).
+ * (a fit of degree 4 in t^2, within 4e-6 of a bin of the exact form -- the bound the kernel's comment states and the
+ * tests assert --, with the reference's operations where the value decides: index 8).
  * Asynchronous. */
 int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b, float *d_out, float *d_out2,
                      size_t n);

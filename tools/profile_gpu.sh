@@ -9,17 +9,25 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp 2>/dev/null && cd - >/dev/null
 export TMPDIR=/tmp
+# The benchmark sets these with os.environ.setdefault() -- too late under `rocprofv3 --pmc`, whose preloaded library
+# initialises the GPU before Python runs: until round 5 the PMC passes ran on 4 hardware queues and the un-profiled bench
+# on 8.  Every pass below runs with 8 (profiles/README.md says so per pass).
+export GPU_MAX_HW_QUEUES=8 HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES HSA_ENABLE_IPC_MODE_LEGACY=$HSA_ENABLE_IPC_MODE_LEGACY (every pass)" > "$OUT/environment.txt"
 BENCH_ARGS="--steps 5 --warmup 2 --legs single,two_stage --profile-run $*"
 echo "bench args: $BENCH_ARGS" > "$OUT/command.txt"
+echo "progress: un-profiled bench" 
 python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "progress: kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/trace.log" 2>&1
 # ONE stream only (timed region and single-stream leg both on one stream): kernel spans do not overlap, so this table's
 # averages are the HIP-event figures of bench.py's stage_ms_per_step (the pass above mixes overlapped and lone launches)
+echo "progress: one-stream kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 bench.py --steps 10 --warmup 3 --streams 1 --legs single --profile-run $* > "$OUT/trace_single.log" 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq2.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$OUT/pmc_lds" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_lds.log" 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_tcc.log" 2>&1
+echo "progress: pmc pass"; rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq.log" 2>&1
+echo "progress: pmc pass"; rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq2.log" 2>&1
+echo "progress: pmc pass"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1
+echo "progress: pmc pass"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_write.log" 2>&1
+echo "progress: pmc pass"; rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$OUT/pmc_lds" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_lds.log" 2>&1
+echo "progress: pmc pass"; rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_tcc.log" 2>&1
 du -sh "$OUT"
