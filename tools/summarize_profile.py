@@ -72,11 +72,14 @@ def main():
                 lines.append("  describe_all_kernel: trace average %.1f us per launch (HIP events bracket the launch: + dispatch)"
                              % (sum(c * a for c, a in da) / sum(c for c, a in da)))
             df = by.get("detect_fused_kernel")
-            if df and len(df) >= 2:
-                big = max(df, key=lambda t: t[1])
-                small = min(df, key=lambda t: t[1])
-                lines.append("  detect_fused_kernel: octave 0 %.1f us + 4 coarser octaves x %.1f us = %.1f us per step in the trace "
-                             "(the stage table adds five dispatches)" % (big[1], small[1], big[1] + 4 * small[1]))
+            if df and da:
+                # one row per template instantiation: since round 5 <ident, 64, down> (octave 0), <general, 64, down>
+                # (octaves 1 .. n-2) and <general, 64, no down> (the last octave)
+                steps = sum(c for c, a in da)
+                parts = sorted(df, key=lambda t: -t[1])
+                lines.append("  detect_fused_kernel: %s = %.1f us per step in the trace (the stage table adds one dispatch per launch)"
+                             % (" + ".join("%d x %.1f us" % (c // steps if c % steps == 0 else c, a) for c, a in parts),
+                                sum(c * a for c, a in parts) / steps))
         except Exception as e:  # noqa: BLE001
             lines.append("(no bench line found in trace_single.log: %s)" % e)
     # PMC passes
