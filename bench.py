@@ -289,7 +289,9 @@ def gather_model(kp_per_rank_step, rec_bytes, step_ms, lag_steps):
                            "at 8 ranks: ~0.1 ms of HBM time)" % (shard * 7 / 1e9))
     out["options"] = {"compact 160-byte wire record (--gather-compact; 8-bit descriptor, lossy)":
                       round(kp_per_rank_step * 160 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3, 4),
-                      "trimmed 540-byte wire record (--gather-trimmed; the 135 floats extraction writes, EXACT)":
+                      "trimmed 540-byte wire record (the N > 1 default since round 5: the 135 floats extraction writes, EXACT, "
+                      "expanded on arrival to 588-byte SiftPoint records; --gather-exact keeps 588 on the wire: %.4f ms)"
+                      % (kp_per_rank_step * 588 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3):
                       round(kp_per_rank_step * 540 / (XGMI_LINK_GBPS_PER_DIRECTION * 1e9) * 1e3, 4),
                       "unit": "exchange ms per step at link peak"}
     return out
@@ -660,7 +662,9 @@ def main():
             "keypoints_per_s_in_hbm": round(total_kp / (elapsed / K), 1),
             "keypoints_per_step": total_kp,
         }
-        rec_b = gatherer.record_bytes if gatherer is not None else 588
+        # (N = 1: the prediction is for the wire format an N > 1 run of this command line would use)
+        rec_b = gatherer.record_bytes if gatherer is not None else (
+            160 if args.gather_compact else (588 if args.gather_exact else 540))
         out["gather_model"] = gather_model(local_kp, rec_b, extraction_only_ms if use_dist else ms_per_step,
                                            LAG if use_dist else E)
         if use_dist:

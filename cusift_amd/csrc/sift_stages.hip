@@ -283,12 +283,22 @@ bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t img_str
 
 // Chunk height of the fused detection: centre rows per wave (see the comment in detect_impl).
 int detect_rows(const cusift_ctx *ctx, int rows_total, int strips, int n_images, int concurrent) {
-  int rows_lo = 2, rows_hi = concurrent >= 2 ? 112 : 64;
+  int rows_lo = 2, rows_hi = concurrent >= 3 ? 240 : (concurrent >= 2 ? 112 : 64);
   rows_bounds(ctx, kKnobDetect, rows_lo, rows_hi);
   const double wave_rows = (double)rows_total * strips * n_images;
   double coef = concurrent >= 2 ? 0.09 : 0.05;
   if (ctx->knobs.detect_rows_coef > 0.0) coef = ctx->knobs.detect_rows_coef;  // tuning experiments only
-  return std::max(rows_lo, std::min(rows_hi, (int)lround(coef * sqrt(wave_rows))));
+  double r = coef * sqrt(wave_rows);
+  // Three or more batches in flight (round 5, the detections of one batch are a chain of launches now): the other batches'
+  // kernels fill whatever a launch leaves idle, so a LARGE launch is best cut into about as many chunks as the chip holds
+  // waves at once -- 1.17 x (CUs x 4 SIMDs x 2 waves) = 2400 on MI355X -- i.e. chunk height proportional to the work, not
+  // to its square root: the window fill and the two extra rows of a chunk are then paid ~5 times per strip instead of ~16.
+  // tools/ab_pyramid.py with the lab build's CUSIFT_DETECT_ROWS_COEF / _HI, four streams, ms per call, rows of octave 0:
+  // 64 frames 67: 0.977, 119: 0.955, 164: 0.947, 223: 0.945, 298: 0.952, 446: 1.000;  32 frames 47: 0.505, 105: 0.489,
+  // 158: 0.489;  16 frames 33: 0.274, 74: 0.271, 111: 0.287;  8 frames 24: 0.154, 79: 0.182;  three streams, 64 frames
+  // 67: 0.982, 134: 0.960, 186: 0.959;  two streams 67: 1.018, 119: 1.059, 223: 1.103 (stays on the square-root rule).
+  if (concurrent >= 3 && ctx->knobs.detect_rows_coef <= 0.0) r = std::max(r, wave_rows / (1.17 * ctx->num_cus * 8.0));
+  return std::max(rows_lo, std::min(rows_hi, (int)lround(r)));
 }
 
 int detect_impl(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, size_t img_stride, float init_blur,
