@@ -244,7 +244,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
       hipLaunchKernelGGL(join_counts_kernel, dim3(1), dim3(256), 0, ctx->stream, d_counters, G, seg_end, n_images,
                          prm->max_pts, queue, join_clears ? 1 : 0);
       TRY(check_launch("join_counts"));
-      if (join_clears) {
+      if (join_clears && !ctx->recording) {  // (a recording enqueues nothing: the counters are as they were)
         ctx->seg_clean_ptr = seg_counts;
         ctx->seg_clean_bytes = seg_bytes;
       }

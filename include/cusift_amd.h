@@ -88,13 +88,13 @@ typedef struct cusift_params {
                           leaves as a TODO (cuSIFT.cu:122-134,376-379); same bits as extract + cusift_rootsift() */
   int concurrent_batches; /* scheduling hint, results do not depend on it: how many extractions the caller keeps in
                           flight on this device at once (one context + stream each).  1 (default): this call has the
-                          GPU to itself -- the detection launches use short row chunks so that their tails stay
-                          short; >= 2: other batches fill the tails, so tall chunks (less redundant blurring at chunk
-                          borders) are faster.  cusift_amd.batch.PipelinedExtractor sets it to its stream count.
-                          With 1 the driver searches all octaves with ONE launch whenever a keypoint list per octave
-                          fits the arena (with >= 2: up to eight 1080p frames' worth of pixels per call), and a call of
-                          three 1080p frames' worth of pixels or more also runs octave 0's detection on a second stream
-                          of the context, beside the ScaleDown chain (cusift_ctx_forks).  Same SiftData either way,
+                          GPU to itself -- short row chunks in the detection launches (their tails stay short), all
+                          octaves searched by ONE launch whenever a keypoint list per octave fits the arena, and from
+                          96 Mpixel per call the pyramid as a by-product of the detections (CUSIFT_POLICY_PYRAMID_IN_DETECT).
+                          >= 2: other batches fill the tails -- taller chunks (less redundant blurring at chunk borders),
+                          the pyramid in the detections from 2 Mpixel per call; >= 3: chunk height proportional to the
+                          work (about as many chunks per launch as the chip holds waves).
+                          cusift_amd.batch.PipelinedExtractor sets it to its stream count.  Same SiftData either way,
                           coarsest octave first. */
 } cusift_params;
 

@@ -257,6 +257,8 @@ def test_list_counters_left_clean_survive_any_interleaving(ctx, one_stream):
     d_pts = DeviceBuffer(ctx, 2 * prm.max_pts * 588)
     d_cnt = DeviceBuffer(ctx, 8)
     g = ctx.record_graph(d_imgs.ptr, 2, 320, 240, src.shape[2], 240 * src.shape[2], prm, d_pts.ptr, d_cnt.ptr)
+    check("small", small)  # a recording runs nothing: it must not be taken for a join that left the counters clean
+    check("other", other)
     for _ in range(2):
         g.launch()
         ctx.synchronize()
