@@ -356,6 +356,13 @@ def main():
                     help="CUSIFT_POLICY_PYRAMID_IN_DETECT of every extraction context: -1 the library's default (calls of "
                          ">= 6 Mpixel: every detection writes the next octave's image, no ScaleDown launches), 0 the "
                          "ScaleDown chain first (the reference's order, cuSIFT.cu:175-192), 1 octave 0 only, 2 every octave")
+    ap.add_argument("--preflight", type=int, default=7,
+                    help="untimed set-up rounds before the W warm-up steps, each one batch per extractor output slot: the "
+                         "first round is CHECKED (all extractors must report identical keypoint counts), the others only "
+                         "keep the device loaded so that the W + K steps do not start from idle clocks (after any idle "
+                         "gap the first ~20 ms of load run 5-12 %% slow: tools/probe_rampup.py).  0: no pre-flight at all "
+                         "-- the timed region then measures the ramp (config.preflight_steps says what ran; the line "
+                         "also carries ms_per_step_spread.ms_per_step_from_idle)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="rehearse the launch only: ranks rendezvous over gloo on the CPU, shard the batch, barrier, "
                          "reduce a time and rank 0 prints a line -- no GPU, no extraction (tests the --gpus N spawn)")
@@ -540,19 +547,20 @@ def main():
     # steady state; staggering the streams' starts changes nothing, a region that follows another without a gap starts
     # at the steady rate).  W = 5 steps is 5 ms.  config.preflight_steps says how many ran; the repeat leg reports the
     # same region started from idle (`ms_per_step_from_idle`) beside it.
-    PREFLIGHT = 7 * E * n_slots
-    for _ in range(E * n_slots):
-        pipe.submit(d_imgs)
-    pipe.synchronize()
-    ref_counts = exs[0].slots[0][1].clone()
-    for x in exs:
-        for _, cnt_t in x.slots:
-            if not torch.equal(cnt_t, ref_counts):
-                raise SystemExit("bench.py: pre-flight: extractors disagree on the keypoint counts of the same batch")
+    PREFLIGHT = max(0, args.preflight) * E * n_slots
+    if PREFLIGHT:
+        for _ in range(E * n_slots):
+            pipe.submit(d_imgs)
+        pipe.synchronize()
+        ref_counts = exs[0].slots[0][1].clone()
+        for x in exs:
+            for _, cnt_t in x.slots:
+                if not torch.equal(cnt_t, ref_counts):
+                    raise SystemExit("bench.py: pre-flight: extractors disagree on the keypoint counts of the same batch")
     # (the comparison above is torch's first work in the process -- tens of milliseconds of lazy initialisation during
     # which the device idles -- so the load that takes it out of its idle clocks comes AFTER it, with nothing but
     # enqueueing between here and the timed region's fence)
-    for _ in range(PREFLIGHT - E * n_slots):
+    for _ in range(max(0, PREFLIGHT - E * n_slots)):
         pipe.submit(d_imgs)
     for _ in range(args.warmup):
         step()
@@ -780,7 +788,11 @@ def main():
                                          "in_order": [round(elapsed / K * 1e3, 4)] + [round(r, 4) for r in reps_in_order],
                                          "note": "the timed region (`ms_per_step`) and 4 repeats of it, K steps each"}
             time.sleep(0.05)  # what a region costs that starts from an idle device (no pre-flight, no warm-up)
-            out["ms_per_step_spread"]["ms_per_step_from_idle"] = round(run_pipelined(d_imgs, K, warm=0), 4)
+            idle_ms = run_pipelined(d_imgs, K, warm=0)
+            out["ms_per_step_spread"]["ms_per_step_from_idle"] = round(idle_ms, 4)
+            # beside `value`, at the top level: the same K steps started from an idle device, no pre-flight, no warm-up
+            out["ms_per_step_from_idle"] = round(idle_ms, 4)
+            out["value_from_idle_mpix_per_s"] = round(total_pix / idle_ms / 1e3, 1)
             # same box, same images, the reference's order (ScaleDown chain first, coarsest octave searched first):
             # what the pyramid-in-detection sequence is worth here
             if args.pyramid_in_detect == -1:
