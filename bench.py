@@ -8,10 +8,17 @@
 
 Workload (BASELINE.json configs[2]/[3]): a batch of 64 synthetic 1920x1080 8-bit-valued images per GPU
 (seeded `tile` images pre-blurred to sigma 1.0), 5 octaves, initBlur=1.0, thresh=3.0, edge=10.
-One "step" = one pass of the whole hot path over that batch: ScaleDown pyramid, 8 blurs + 7 DoG per
+One "step" = one pass of the whole hot path over that batch: ScaleDown pyramid (since round 5 written by the
+detection launches themselves: CUSIFT_POLICY_PYRAMID_IN_DETECT, --pyramid-in-detect), 8 blurs + 7 DoG per
 octave, extrema + refinement, orientation, 128-D descriptors -- SiftData left in HBM; with N>1 ranks the
 step ends with the RCCL all-gatherv of SiftData (C ABI: cusift_allgatherv_*, ncclAllGather of the counts + one
-ncclGroup of ncclSend/ncclRecv) so every rank holds all N*64 images' keypoints.
+ncclGroup of ncclSend/ncclRecv; 540-byte trimmed records expanded on arrival to 588-byte SiftPoint records unless
+--gather-exact) so every rank holds all N*64 images' keypoints.
+Before the W warm-up steps an untimed PRE-FLIGHT runs (--preflight, default 7 rounds = 28 steps): every extractor runs
+the batch and all must report identical keypoint counts; the remaining rounds keep the device loaded so that the W + K
+steps do not start from idle clocks (tools/probe_rampup.py: after any idle gap the first ~20 ms of load run 5-12 % slow).
+The line says what ran (config.preflight_steps) and carries the same K steps started from idle beside `value`
+(ms_per_step_from_idle, value_from_idle_mpix_per_s); --preflight 0 measures without it.
 Inputs are resident in HBM before the timed region.  Weak scaling: 64 images per GPU at every N.
 Consecutive steps rotate over --streams HIP streams (default 4, one extractor each), so that the HBM-bound
 ScaleDown chain and the launch tails of one batch overlap the VALU-bound kernels of the others (and the detection can
