@@ -316,9 +316,12 @@ bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_imag
 // profiles/r05/ab_pyramid_by_size.txt; 1080p frames per call, ms per call, ScaleDown chain first -> every octave):
 //   four calls in flight  1: 0.0409 -> 0.0390   3: 0.0776 -> 0.0725   8: 0.1645 -> 0.1450   16: 0.288 -> 0.267   64: 1.033 -> 0.976
 //   a lone caller         1: 0.0649 -> 0.0973  16: 0.342 -> 0.392    32: 0.645 -> 0.662    48: 0.941 -> 0.932   64: 1.241 -> 1.153
-// So by default: a pipelining caller (concurrent_batches >= 2) from one 1080p frame's worth of pixels up, a lone caller
-// from 96 Mpixel per call (46 frames).  0: never; 1: octave 0 only; 2: every octave.
-constexpr size_t kPyramidInDetectMinPixelsPipelined = 2u << 20, kPyramidInDetectMinPixelsLone = 96u << 20;
+// A lone caller's middle ground is "octave 0 only" (1): octave 0's detection hands octave 1 over -- the large ScaleDown is
+// the one worth saving -- and the coarser octaves keep their short ScaleDown chain and their ONE launch: 32 frames
+// 0.645 -> 0.640, 48: 0.941 -> 0.910 (every octave: 0.932), 64: 1.241 -> 1.152 (every octave: 1.154); 24: 0.496 -> 0.505.
+// So by default: a pipelining caller (concurrent_batches >= 2) every octave from one 1080p frame's worth of pixels up, a
+// lone caller octave 0 only from 64 Mpixel per call (31 frames).  0: never; 1: octave 0 only; 2: every octave.
+constexpr size_t kPyramidInDetectMinPixelsPipelined = 2u << 20, kPyramidInDetectMinPixelsLone = 64u << 20;
 int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h) {
   const int mode = ctx->knobs.pyramid_in_detect;
   if (mode == 0 || ctx->knobs.force_generic || ctx->knobs.stage_all == 0) return 0;
@@ -327,7 +330,8 @@ int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int
   // bracketed as one -- the ScaleDown stage then simply reports no launches)
   if (mode > 0) return std::min(mode, 2);
   const size_t px = (size_t)n_images * (size_t)w * (size_t)h;
-  return px >= (prm->concurrent_batches >= 2 ? kPyramidInDetectMinPixelsPipelined : kPyramidInDetectMinPixelsLone) ? 2 : 0;
+  if (prm->concurrent_batches >= 2) return px >= kPyramidInDetectMinPixelsPipelined ? 2 : 0;
+  return px >= kPyramidInDetectMinPixelsLone ? 1 : 0;
 }
 
 // OPT-IN since round 4 (cusift_ctx_set_policy(ctx, CUSIFT_POLICY_SIDE_STREAM, 1 | 2), or CUSIFT_OCTAVE_OVERLAP=1 | 2 in the

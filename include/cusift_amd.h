@@ -90,7 +90,7 @@ typedef struct cusift_params {
                           flight on this device at once (one context + stream each).  1 (default): this call has the
                           GPU to itself -- short row chunks in the detection launches (their tails stay short), all
                           octaves searched by ONE launch whenever a keypoint list per octave fits the arena, and from
-                          96 Mpixel per call the pyramid as a by-product of the detections (CUSIFT_POLICY_PYRAMID_IN_DETECT).
+                          64 Mpixel per call octave 1 as a by-product of octave 0's detection (CUSIFT_POLICY_PYRAMID_IN_DETECT).
                           >= 2: other batches fill the tails -- taller chunks (less redundant blurring at chunk borders),
                           the pyramid in the detections from 2 Mpixel per call; >= 3: chunk height proportional to the
                           work (about as many chunks per launch as the chip holds waves).
@@ -152,9 +152,9 @@ enum {
   /* The pyramid as a by-product of the detection: the fused detection of octave o writes octave o + 1's image from the
    * row window it streams through anyway (ScaleDown's arithmetic, cuSIFT_D.cu:37-182, bit for bit), so the octaves are
    * searched finest first -- into lists of their own, which therefore must fit (CUSIFT_POLICY_OCTAVE_LISTS) -- and no
-   * ScaleDown launch re-reads the images.  -1 by size (default: a caller with cusift_params.concurrent_batches >= 2 from
-   * 2 Mpixel per call, a lone caller from 96 Mpixel -- below that its one-launch detection of the coarser octaves is
-   * worth more than the ScaleDown launches), 0 never (the ScaleDown chain first, as the reference:
+   * ScaleDown launch re-reads the images.  -1 by size (default: a caller with cusift_params.concurrent_batches >= 2 every
+   * octave from 2 Mpixel per call; a lone caller octave 0 only from 64 Mpixel -- its one-launch detection of the coarser
+   * octaves is worth more than their short ScaleDown launches, and below 64 Mpixel more than octave 0's too), 0 never (the ScaleDown chain first, as the reference:
    * cuSIFT.cu:175-192), 1 octave 0 only (then the chain and the coarser octaves as with 0), 2 every octave. */
   CUSIFT_POLICY_PYRAMID_IN_DETECT = 6
 };
