@@ -822,7 +822,18 @@ def main():
         # ---- single-stream leg: per-stage table, VALU rooflines of the two kernels that own the step ----
         stage = None
         if "single" in legs:
+            # the TIMED REGION's launch sequence (every detection writes the next octave: five detect_fused_kernel launches,
+            # the join, the description) on ONE stream, with the chunk heights of a caller that has the GPU to itself
+            # (concurrent_batches = 1: the timed region's tall chunks only pay with other batches filling the tails -- on one
+            # stream they cost 1.07 against 0.83 ms).  profiles/valu.json counts exactly these launches (tools/profile_gpu.sh,
+            # the one-stream PMC pass).  What a lone caller gets by DEFAULT (octave 1 from octave 0's detection, one launch for
+            # the coarser octaves) is measured right below as lone_caller_ms_per_step
+            ex.params.concurrent_batches = 1
+            if args.pyramid_in_detect == -1:
+                ex.ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, 2)
             single_ms, stage = run_single_stream(ex, d_imgs, K)
+            if args.pyramid_in_detect == -1:
+                ex.ctx.set_policy(capi.POLICY_PYRAMID_IN_DETECT, -1)
             out["stage_ms_per_step"] = stage_table(stage, K)
             # a lone caller: one batch at a time on one stream, no stage timers -- the driver then runs octave 0's
             # detection on the context's second stream beside the ScaleDown chain and the coarser octaves
@@ -851,10 +862,11 @@ def main():
                 "lone_caller_side_stream_ms_per_step": round(lone_forked_ms, 4) if lone_steps else None,
                 "lone_caller_forked_steps": max(0, ex.ctx.forks() - forks0 - 2),
                 "note": "the timed region alternates steps over %d streams; stage_ms_per_step, the VALU rooflines and "
-                        "pyramid_mpix_per_s are measured on the same steps run on one stream (HIP events per launch), "
+                        "pyramid_mpix_per_s are measured on the same steps -- the same launch sequence (every detection "
+                        "writes the next octave), chunk heights of concurrent_batches = 1 -- run on one stream (HIP events per launch), "
                         "where kernel spans do not overlap.  lone_caller_ms_per_step: the same calls without the stage "
                         "timers and with concurrent_batches = 1 -- what a caller that keeps ONE batch in flight gets by "
-                        "default; lone_caller_side_stream_ms_per_step: with CUSIFT_POLICY_SIDE_STREAM = 2 (octave 0's "
+                        "default (octave 1 from octave 0's detection, one launch for the coarser octaves, short chunks); lone_caller_side_stream_ms_per_step: with CUSIFT_POLICY_SIDE_STREAM = 2 (octave 0's "
                         "detection on the context's second stream beside the ScaleDown chain and the coarser octaves)" % E}
             sd_ms = stage["scale_down"][0]
             det_ms, det_n = stage["detect_multi"]

@@ -23,7 +23,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 
 # ONE stream only (timed region and single-stream leg both on one stream): kernel spans do not overlap, so this table's
 # averages are the HIP-event figures of bench.py's stage_ms_per_step (the pass above mixes overlapped and lone launches)
 echo "progress: one-stream kernel trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 bench.py --steps 10 --warmup 3 --streams 1 --legs single --profile-run $* > "$OUT/trace_single.log" 2>&1
+# (--pyramid-in-detect 2: a lone caller's default would be "octave 0 only"; these two passes are about the timed region's kernels)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 bench.py --steps 10 --warmup 3 --streams 1 --pyramid-in-detect 2 --legs single --profile-run $* > "$OUT/trace_single.log" 2>&1
+# the same one-stream command under the instruction counters: every detect_fused_kernel / describe_all_kernel launch of this
+# pass is one the single-stream leg of bench.py times (same launch sequence, same chunk heights) -> profiles/valu.json
+echo "progress: pmc pass (one stream)"; rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_single" -- python3 bench.py --steps 10 --warmup 3 --streams 1 --pyramid-in-detect 2 --legs single --profile-run $* > "$OUT/pmc_single.log" 2>&1
 echo "progress: pmc pass"; rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq.log" 2>&1
 echo "progress: pmc pass"; rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_sq2.log" 2>&1
 echo "progress: pmc pass"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS > "$OUT/pmc_fetch.log" 2>&1

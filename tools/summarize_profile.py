@@ -85,8 +85,12 @@ def main():
     # PMC passes
     per_kernel = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [values per dispatch]
     per_dispatch = defaultdict(dict)  # (pass, dispatch) -> info
+    single_valu = defaultdict(lambda: defaultdict(list))  # the one-stream PMC pass, kept apart: kernel -> counter -> values
+    for f in glob.glob(os.path.join(src, "pmc_single", "**", "*_counter_collection.csv"), recursive=True):
+        for r in read_csv(f):
+            single_valu[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        if not os.path.isdir(d):
+        if not os.path.isdir(d) or os.path.basename(d) == "pmc_single":
             continue
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in read_csv(f):
@@ -167,6 +171,15 @@ def main():
             continue
         insts = sum(pk["SQ_INSTS_VALU"]) / len(pk["SQ_INSTS_VALU"])
         entry = {"valu_wave_insts_per_launch": insts, "launches_profiled": len(pk["SQ_INSTS_VALU"])}
+        sv = single_valu.get(kern)
+        if sv and "SQ_INSTS_VALU" in sv:
+            # bench.py prices the launches of its ONE-STREAM leg: take the counts of the one-stream PMC pass (same launch
+            # sequence, same chunk heights); the all-pass average above mixes in the four-stream region's taller chunks
+            entry["valu_wave_insts_per_launch_all_passes"] = insts
+            insts = sum(sv["SQ_INSTS_VALU"]) / len(sv["SQ_INSTS_VALU"])
+            entry["valu_wave_insts_per_launch"] = insts
+            entry["launches_profiled"] = len(sv["SQ_INSTS_VALU"])
+            entry["counted_in"] = "the one-stream pass (--streams 1 --pyramid-in-detect 2 --legs single)"
         if "SQ_LDS_IDX_ACTIVE" in pk and "GRBM_GUI_ACTIVE" in pk:  # only when tools/pmc_lds.sh passes are present
             gui = sum(pk["GRBM_GUI_ACTIVE"]) / len(pk["GRBM_GUI_ACTIVE"])
             entry["lds_busy"] = round(sum(pk["SQ_LDS_IDX_ACTIVE"]) / len(pk["SQ_LDS_IDX_ACTIVE"]) / (256.0 * gui / 8.0), 4)
