@@ -108,7 +108,8 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
   if (stage_all && !ctx->knobs.no_multi)
     for (int o = first_rest; o < pl.n_oct && n_one_launch < kMaxMultiOctaves; ++o) n_one_launch += searched(o) ? 1 : 0;
   const bool one_launch = n_one_launch >= 2;
-  const bool self_join = stage_all && one_launch;              // no join_counts_kernel: describe_all_kernel joins
+  // no join_counts_kernel: describe_all_kernel joins (small calls: wants_self_join)
+  const bool self_join = stage_all && one_launch && wants_self_join(ctx, n_images, w, h);
   const bool pyramid_clears = small_pyramid && stage_all && !forked;  // (a forked octave 0 may count before the pyramid runs)
   // cuSIFT.cu:69: point counter = 0 (with every octave staged the join writes it instead)
   if (!stage_all) HIP_TRY(hipMemsetAsync(d_counters, 0, sizeof(unsigned int) * n_images, ctx->stream));

@@ -258,6 +258,7 @@ int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool borrow)
 size_t bands_arena_bytes(int n_bands, int max_pts);
 int scale_down_impl(cusift_ctx *ctx, float *d_dst, int dst_pitch, size_t dst_stride, const float *d_src, int w, int h, int src_pitch, size_t src_stride, int n_images, float variance, RowWindow src_rw, int dst_row0, int r_begin, int r_end, bool band);
 bool wants_small_pyramid(const cusift_ctx *ctx, int n_images, int w, int h);
+bool wants_self_join(const cusift_ctx *ctx, int n_images, int w, int h);
 int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const int *w, const int *h, const int *pitch, const size_t *stride, int n_levels, int n_images, float variance, unsigned int *d_zero, int n_zero);
 bool detect_fused_ok(const float *d_img, int w, int h, int pitch, size_t img_stride);
 int detect_rows(const cusift_ctx *ctx, int rows_total, int strips, int n_images, int concurrent);

@@ -111,6 +111,14 @@ bool wants_small_pyramid(const cusift_ctx *ctx, int n_images, int w, int h) {
   return !ctx->timing && (size_t)n_images * (size_t)w * (size_t)h <= kPyramidSmallPixels;
 }
 
+// describe_all_kernel may form the lists' running sums itself (no join_counts_kernel: a small call saves the dispatch) --
+// but it then finds every keypoint's list by a walk over the lists' counters, which a large call pays per keypoint
+// (64 x 1080p of `blobs`, 581 k keypoints, one stream: 2.066 ms with the self-join against 1.99 with the 5-us join kernel and
+// its precomputed ends).  So: small calls only.
+bool wants_self_join(const cusift_ctx *, int n_images, int w, int h) {
+  return (size_t)n_images * (size_t)w * (size_t)h <= kPyramidSmallPixels;
+}
+
 int pyramid_small_impl(cusift_ctx *ctx, const float *const *base, const int *w, const int *h, const int *pitch,
                               const size_t *stride, int n_levels, int n_images, float variance, unsigned int *d_zero,
                               int n_zero) {
