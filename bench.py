@@ -14,9 +14,9 @@ octave, extrema + refinement, orientation, 128-D descriptors -- SiftData left in
 step ends with the RCCL all-gatherv of SiftData (C ABI: cusift_allgatherv_*, ncclAllGather of the counts + one
 ncclGroup of ncclSend/ncclRecv; 540-byte trimmed records expanded on arrival to 588-byte SiftPoint records unless
 --gather-exact) so every rank holds all N*64 images' keypoints.
-Before the W warm-up steps an untimed PRE-FLIGHT runs (--preflight, default 7 rounds = 28 steps): every extractor runs
-the batch and all must report identical keypoint counts; the remaining rounds keep the device loaded so that the W + K
-steps do not start from idle clocks (tools/probe_rampup.py: after any idle gap the first ~20 ms of load run 5-12 % slow).
+Before the W warm-up steps an untimed PRE-FLIGHT runs (--preflight, default 7 rounds = 28 steps, then blocks of 8 steps
+until the step rate is steady: 52 steps in practice): every extractor runs the batch and all must report identical keypoint
+counts; the rest keeps the device loaded so that the W + K steps do not start from idle clocks (tools/probe_rampup.py: after any idle gap the first ~20 ms of load run 5-12 % slow).
 The line says what ran (config.preflight_steps) and carries the same K steps started from idle beside `value`
 (ms_per_step_from_idle, value_from_idle_mpix_per_s); --preflight 0 measures without it.
 Inputs are resident in HBM before the timed region.  Weak scaling: 64 images per GPU at every N.
@@ -569,6 +569,24 @@ def main():
     # enqueueing between here and the timed region's fence)
     for _ in range(max(0, PREFLIGHT - E * n_slots)):
         pipe.submit(d_imgs)
+    # ... and, because how long the ramp takes depends on how deep the device slept (one run in six of the driver's form read
+    # 1.04 ms behind the fixed 28 steps where the others read 0.95), load continues in blocks of 2 E steps until two
+    # consecutive blocks run within 2 % of each other and of the fastest block seen -- at most 24 more blocks.  The blocks'
+    # ms per step are in the line (config.preflight_blocks_ms_per_step): what the device did before the W + K steps is on record.
+    preflight_blocks = []
+    if PREFLIGHT:
+        pipe.synchronize()
+        for _ in range(24):
+            t_b = time.perf_counter()
+            for _ in range(2 * E):
+                pipe.submit(d_imgs)
+            pipe.synchronize()
+            preflight_blocks.append((time.perf_counter() - t_b) / (2 * E) * 1e3)
+            PREFLIGHT += 2 * E
+            if len(preflight_blocks) >= 3:
+                a, b, best = preflight_blocks[-1], preflight_blocks[-2], min(preflight_blocks)
+                if abs(a - b) <= 0.02 * best and max(a, b) <= 1.02 * best:
+                    break
     for _ in range(args.warmup):
         step()
     fence()
@@ -666,6 +684,7 @@ def main():
                 "timed_region_timers": False,
                 "timed_region_forks": int(forks_timed),
                 "preflight_steps": PREFLIGHT,
+                "preflight_blocks_ms_per_step": [round(x, 4) for x in preflight_blocks],
                 "preflight_note": "untimed set-up check before the W warm-up steps: every extractor runs the batch, all "
                                   "must report identical keypoint counts; it also takes the device out of its idle clocks "
                                   "(ms_per_step_spread.ms_per_step_from_idle = the same region started 50 ms after idle)",
