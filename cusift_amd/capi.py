@@ -129,6 +129,7 @@ SIGNATURES = {
     "cusift_ctx_reserve_bands": (_i, [_vp, _i, _i]),
     "cusift_event_create": (_i, [_vp, C.POINTER(_vp)]),
     "cusift_event_record": (_i, [_vp, _vp]),
+    "cusift_event_wait": (_i, [_vp, _vp]),
     "cusift_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "cusift_event_destroy": (_i, [_vp]),
     "cusift_pipe_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _PP, _i, _i, _sz]),

@@ -640,6 +640,14 @@ extern "C" int cusift_event_record(cusift_event *ev, cusift_ctx *ctx) {
   return CUSIFT_OK;
 }
 
+extern "C" int cusift_event_wait(cusift_event *ev, cusift_ctx *ctx) {
+  if (!ev) return fail(CUSIFT_ERR_INVALID, "event is NULL");
+  TRY(enter(ctx));
+  if (ev->device != ctx->device) return fail(CUSIFT_ERR_INVALID, "event and context are on different devices");
+  HIP_TRY(hipStreamWaitEvent(ctx->stream, ev->ev, 0));
+  return CUSIFT_OK;
+}
+
 extern "C" int cusift_event_elapsed_ms(cusift_event *start, cusift_event *stop, float *ms) {
   if (!start || !stop || !ms) return fail(CUSIFT_ERR_INVALID, "event / ms is NULL");
   HIP_TRY(hipSetDevice(stop->device));

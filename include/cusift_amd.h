@@ -8,8 +8,8 @@
  * (SiftPoint / SiftData / cuImage / ExtractSift ...) on top of exactly these functions; Python binds
  * them with ctypes (cusift_amd/capi.py).  See INTEGRATION.md.
  *
- * Map of the C ABI (110 entry points in four headers; cusift_amd_all.h includes them all):
- *   cusift_amd.h (THIS FILE, 45): the drop-in boundary -- everything include/cuSIFT.h is built on (process / device,
+ * Map of the C ABI (111 entry points in four headers; cusift_amd_all.h includes them all):
+ *   cusift_amd.h (THIS FILE, 46): the drop-in boundary -- everything include/cuSIFT.h is built on (process / device,
  *     context, device memory helpers, cusift_extract / _extract_host / _scale_down / _rootsift / _sort_points_host,
  *     cusift_event_* for TimerGPU), the batch driver a throughput caller needs (cusift_extract_batch, cusift_graph_*,
  *     cusift_ctx_wait / _reserve / _set_policy) and the host-to-host pipeline (cusift_pipe_*).
@@ -168,6 +168,10 @@ int cusift_ctx_get_policy(cusift_ctx *ctx, int key, int *value);
 typedef struct cusift_event cusift_event;
 int cusift_event_create(cusift_ctx *ctx, cusift_event **out);
 int cusift_event_record(cusift_event *ev, cusift_ctx *ctx);
+/* Everything enqueued on `ctx` after this call waits for the work that preceded the event's last record (no host wait):
+ * the fine-grained form of cusift_ctx_wait -- e.g. "the next extraction into these records waits for the pack that read
+ * them", not for everything else the other context has queued since (tests/cpp/scaling_bench.cpp). */
+int cusift_event_wait(cusift_event *ev, cusift_ctx *ctx);
 int cusift_event_elapsed_ms(cusift_event *start, cusift_event *stop, float *ms);
 int cusift_event_destroy(cusift_event *ev);
 

@@ -11,6 +11,8 @@
 // steps between two barriers (an empty all-gatherv + a stream synchronisation on every rank), the MAX over the ranks'
 // times (through <id-file>.t<rank>), and rank 0 prints ONE JSON line on stdout.  With world == 1 the shard still
 // travels through ncclSend / ncclRecv (self p2p): that is how tests/test_cpp_dropin.py runs it on one GPU.
+// (No pre-flight here: the device leaves its idle clocks during the first ~30 steps -- bench.py's docstring -- so pass a
+// warm-up of 40 or more to time the steady state.)
 // Images: the fixture mirror-tiled with a per-image shift, low-passed to sigma 1.0 and re-quantised -- the SHAPE of
 // cusift_amd.synth.tile, not bit for bit (this program measures; tests/ verify).
 #include <chrono>
@@ -180,6 +182,13 @@ int main(int argc, char **argv) {
   CHECK(cusift_malloc((void **)&d_zero, sizeof(unsigned int) * B));
   CHECK(cusift_memset(cctx, d_zero, 0, sizeof(unsigned int) * B));
 
+  // per extraction slot: an event behind the begin() that packed its records -- the slot's NEXT extraction waits for exactly
+  // that (cusift_ctx_wait(ctx[e], cctx) would wait for everything the exchange stream has queued since, i.e. for the pack
+  // of the step before, i.e. for that step's extraction: the streams would run one after the other -- 2.06 ms per step
+  // measured that way against 1.1 with the events)
+  std::vector<cusift_event *> packed(E, nullptr);
+  std::vector<char> packed_valid(E, 0);
+  for (int e = 0; e < E; ++e) CHECK(cusift_event_create(cctx, &packed[e]));
   long begun = 0, finished = 0;
   size_t gathered_last = 0;
   auto finish_one = [&]() -> int {
@@ -193,9 +202,11 @@ int main(int argc, char **argv) {
   };
   auto step = [&](long i) -> int {
     const int e = (int)(i % E);
-    CHECK(cusift_ctx_wait(ctx[e], cctx));  // the pack of this slot's previous batch has read pts[e] / cnt[e]
+    if (packed_valid[e]) CHECK(cusift_event_wait(packed[e], ctx[e]));  // the pack of this slot's previous batch has read pts[e] / cnt[e]
     CHECK(cusift_extract_batch(ctx[e], d_imgs, B, W, H, W, img_floats, &prm, pts[e], cnt[e]));
     CHECK(cusift_allgatherv_begin(comm, ctx[e], pts[e], cnt[e], B, prm.max_pts, B, wire[begun % n_out], region_cap));
+    CHECK(cusift_event_record(packed[e], cctx));
+    packed_valid[e] = 1;
     ++begun;
     if (begun - finished > LAG) return finish_one();
     return 0;
@@ -298,6 +309,7 @@ int main(int argc, char **argv) {
     cusift_free(cnt[e]);
     cusift_ctx_destroy(ctx[e]);
   }
+  for (int e = 0; e < E; ++e) cusift_event_destroy(packed[e]);
   cusift_free(d_zero);
   cusift_free(d_imgs);
   cusift_comm_destroy(comm);
