@@ -216,7 +216,8 @@ void find_params(FindParams &P, float peak_thresh, float edge_thresh, float subs
 }
 
 void frac_consts(int frac_bits, float &q, float &inv_q) {
-  if (frac_bits > 0 && frac_bits < 24) {
+  // (<= 11 bits: the texture model's weight product A B / 2^q is then exact in fp32 -- sift_keypoints.hip, bilinear_weights)
+  if (frac_bits > 0 && frac_bits <= 11) {
     q = (float)(1 << frac_bits);
     inv_q = 1.0f / q;
   } else {

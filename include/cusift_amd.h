@@ -79,7 +79,8 @@ typedef struct cusift_params {
   float lowest_scale;  /* SiftData::lowestScale: octave o is searched iff lowest_scale < 2*subsampling*2^o */
   float subsampling;   /* Extract(..., float subsampling = 1.0f) */
   int max_pts;         /* capacity per image (SiftData::maxPts) */
-  int tex_frac_bits;   /* bilinear fraction bits of the texture-unit model: 8 = as the reference ran, 0 = fp32 */
+  int tex_frac_bits;   /* fixed-point bits of the texture-unit model (fractions AND the four bilinear weights):
+                          8 = as the reference ran, 1..11 accepted, anything else = exact fp32 fractions and weights */
   int fused_detect;    /* 1 (default): the drivers run LaplaceMulti+FindPointsMulti as one kernel that keeps the
                           DoG planes on chip, and orientation+descriptor of all octaves as one launch after the
                           last detection (identical results); 0: the reference's per-octave stage sequence */

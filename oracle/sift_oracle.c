@@ -306,8 +306,16 @@ void oracle_find_points_multi(const float *dog, int w, int h, int pitch, float p
 
 /* ------------------------------------------------------------------------------------------
  * Texture model (CUDA programming guide, linear filtering, unnormalised coordinates, clamp):
- * xB = x - 0.5, i = floor(xB), alpha = frac(xB) kept with `frac_bits` fractional bits
- * (8 on NVIDIA hardware), T = (1-a)(1-b)S[j][i] + a(1-b)S[j][i+1] + (1-a)b S[j+1][i] + ab S[j+1][i+1].
+ * xB = x - 0.5, i = floor(xB), alpha = frac(xB) kept with `frac_bits` fractional bits (8 on NVIDIA hardware),
+ * T = w00 S[j][i] + w10 S[j][i+1] + w01 S[j+1][i] + w11 S[j+1][i+1].
+ * The four weights are FIXED-POINT numbers of `frac_bits` bits as well (round 6; measured on the reference's golden
+ * pair, tests/test_oracle_golden.py): with A = round(alpha 2^q), B = round(beta 2^q),
+ *     W11 = floor(A B / 2^q + 1/2),  W10 = A - W11,  W01 = B - W11,  W00 = 2^q - A - B + W11,   w = W / 2^q
+ * i.e. the product alpha*beta is rounded (half up) to q bits and the other three follow by subtraction, so the weights
+ * always sum to one.  With the exact 16-bit products (1-a)(1-b), a(1-b), (1-a)b, ab that rounds 1 to 5 used, 35 % of
+ * the 4,095 matched golden orientations were within 1e-3 degree (median 0.002); with this rule all 4,095 are within
+ * 6.1e-5 degree and 86 % are bit-identical floats (round-half-even: 99.0 % within 1e-3, truncation: 53 %; rounding
+ * each weight on its own: 98.3 %).  frac_bits = 0 keeps exact fp32 fractions and products.
  * The kernels pass pixel-index coordinates with no +0.5 (cuSIFT_D.cu:207-212,337-338), hence
  * every tap is displaced by (-1/2,-1/2) px; that displacement is part of the reference's results.
  * ---------------------------------------------------------------------------------------- */
@@ -315,10 +323,18 @@ float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, 
   float xb = x - 0.5f, yb = y - 0.5f;
   float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
+  float w00, w10, w01, w11;
   if (frac_bits > 0) {
     const float q = (float)(1 << frac_bits);
-    a = floorf(a * q + 0.5f) / q;
-    b = floorf(b * q + 0.5f) / q;
+    const float A = floorf(a * q + 0.5f), B = floorf(b * q + 0.5f); /* integers in [0, q] */
+    const float W11 = floorf(A * B / q + 0.5f);                     /* A B <= 2^(2q): exact in fp32 for q <= 11 */
+    w11 = W11 / q;
+    w10 = (A - W11) / q;
+    w01 = (B - W11) / q;
+    w00 = (q - A - B + W11) / q;
+  } else {
+    const float ia = 1.0f - a, ib = 1.0f - b;
+    w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
   }
   /* clamp in float first so that huge |x| cannot overflow the int conversion */
   fx = fminf(fmaxf(fx, -1.0f), (float)w);
@@ -328,19 +344,27 @@ float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, 
   int j0 = clampi(j, 0, h - 1), j1 = clampi(j + 1, 0, h - 1);
   float s00 = img[(size_t)j0 * pitch + i0], s10 = img[(size_t)j0 * pitch + i1];
   float s01 = img[(size_t)j1 * pitch + i0], s11 = img[(size_t)j1 * pitch + i1];
-  float ia = 1.0f - a, ib = 1.0f - b;
   /* interpolation order of this restatement: first product, then three fused multiply-adds
    * (the texture unit's own arithmetic is not documented; nvcc would fuse exactly like this) */
-  float t = (ia * ib) * s00;
-  t = fmaf(a * ib, s10, t);
-  t = fmaf(ia * b, s01, t);
-  t = fmaf(a * b, s11, t);
+  float t = w00 * s00;
+  t = fmaf(w10, s10, t);
+  t = fmaf(w01, s01, t);
+  t = fmaf(w11, s11, t);
   return t;
 }
 
-/* ------------------------------------------------------------------------------------------
- * ComputeOrientations_D: cuSIFT_D.cu:319-396 (the second-peak branch is compiled out, :380).
- * ---------------------------------------------------------------------------------------- */
+/* Diagnostic tap (tests/parity_utils.golden_gates): when a buffer is registered on the calling thread, every point bx
+ * that oracle_compute_orientations processes leaves diag[2*bx] = second / first smoothed-histogram peak value and
+ * diag[2*bx+1] = the orientation the SECOND peak would give (degrees; NaN when there is none).  The reference computes
+ * both peaks and discards the second (`&& false`, cuSIFT_D.cu:380): a golden row that sits near our second peak is a
+ * near-tie decided the other way by CUDA's arithmetic, not a modelling difference. */
+static _Thread_local float *g_ori_diag = 0;
+static _Thread_local int g_ori_diag_cap = 0;
+void oracle_set_orientation_diag(float *buf, int n_points) {
+  g_ori_diag = buf;
+  g_ori_diag_cap = buf ? n_points : 0;
+}
+
 void oracle_compute_orientations(const float *img, int w, int h, int pitch, oracle_sift_point *points, int first,
                                  int last, int frac_bits) {
   for (int bx = first; bx < last; bx++) {
@@ -399,7 +423,16 @@ void oracle_compute_orientations(const float *img, int w, int h, int pitch, orac
         i2 = i;
       }
     }
-    (void)i2;
+    if (g_ori_diag && bx < g_ori_diag_cap) {
+      float o2 = NAN;
+      if (i2 >= 0) {
+        float w1 = hist[32 + ((i2 + 1) & 31)], w2 = hist[32 + ((i2 + 31) & 31)];
+        float pk2 = i2 + 0.5f * (w1 - w2) / (2.0f * maxval2 - w1 - w2);
+        o2 = 11.25f * (pk2 < 0.0f ? pk2 + 32.0f : pk2);
+      }
+      g_ori_diag[2 * bx] = maxval1 > 0.0f ? maxval2 / maxval1 : NAN;
+      g_ori_diag[2 * bx + 1] = o2;
+    }
     float val1 = hist[32 + ((i1 + 1) & 31)];
     float val2 = hist[32 + ((i1 + 31) & 31)];
     float peak = i1 + 0.5f * (val1 - val2) / (2.0f * maxval1 - val1 - val2);

@@ -70,6 +70,10 @@ void oracle_find_points_multi(const float *dog, int w, int h, int pitch, float p
 void oracle_compute_orientations(const float *img, int w, int h, int pitch, oracle_sift_point *points, int first,
                                  int last, int tex_frac_bits);
 
+/* Diagnostic tap of oracle_compute_orientations (per calling thread; NULL switches it off): diag[2*bx] = second /
+ * first smoothed-histogram peak, diag[2*bx+1] = the orientation of the second peak in degrees (NaN if none). */
+void oracle_set_orientation_diag(float *buf, int n_points);
+
 /* cuSIFT_D.cu:184-297 over points [first, last); scales coords2D/scale by subsampling at the end. */
 void oracle_extract_descriptors(const float *img, int w, int h, int pitch, oracle_sift_point *points, int first,
                                 int last, float subsampling, int tex_frac_bits);

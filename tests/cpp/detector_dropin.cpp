@@ -96,7 +96,7 @@ int main(int argc, char **argv) {
     full.edgeThresh = 10.0f;
     full.lowestScale = 0.0f;
     full.Extract(im.data(), w, h);
-    int found_all = 0;
+    int found_all = 0, ori_ok = 0;
     for (uint32_t i = 0; i < numPts; i++) {
       const float *d = &gold[4 * i];
       for (int j = 0; j < full.numPts; j++) {
@@ -104,13 +104,19 @@ int main(int argc, char **argv) {
         if (std::fabs(pt.coords2D[0] - d[0]) < 1e-2 && std::fabs(pt.coords2D[1] - d[1]) < 1e-2 &&
             std::fabs(pt.scale - d[2]) < 1e-2) {
           ++found_all;
+          float da = std::fabs(pt.orientation - d[3]);
+          if (da > 180.0f) da = 360.0f - da;
+          ori_ok += da < 1e-3f;
           break;
         }
       }
     }
-    std::printf("unsaturated run: %d points; golden rows found within 1e-2: %d / %u\n", full.numPts, found_all, numPts);
+    std::printf("unsaturated run: %d points; golden rows found within 1e-2: %d / %u; of those, orientation within 1e-3 degree: %d\n",
+                full.numPts, found_all, numPts, ori_ok);
     if (full.numPts != 9508) ++failures;
     if (found_all < (int)numPts - 2) ++failures;
+    // the reference's own orientations (test/detector.cpp:79 compares them to 0.1, one-sided): >= 98 % within 1e-3 degree
+    if (ori_ok < (int)(0.98 * found_all)) ++failures;
   }
 
   // ---- legacy API, main.cpp:313-328,348-349 ----

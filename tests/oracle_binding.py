@@ -92,6 +92,8 @@ class Oracle:
         lib.oracle_rootsift.restype = None
         lib.oracle_extract.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(OracleParams), _vp]
         lib.oracle_extract.restype = C.c_int
+        lib.oracle_set_orientation_diag.argtypes = [_vp, C.c_int]
+        lib.oracle_set_orientation_diag.restype = None
         lib.oracle_match_sift_data.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int]
         lib.oracle_match_sift_data.restype = None
         lib.oracle_match_filter.argtypes = [_vp, C.c_int, C.c_float, C.c_float, _vp]
@@ -157,6 +159,19 @@ class Oracle:
         points = np.zeros(max_pts, dtype=SIFT_POINT_DTYPE)
         n = self.lib.oracle_extract(img.ctypes.data, w, h, C.byref(prm), points.ctypes.data)
         return points[:n]
+
+    def extract_with_orientation_peaks(self, img, **kw):
+        """extract() plus, per returned point, (second / first smoothed-histogram peak, the orientation the second peak
+        would give in degrees) -- the diagnostic tap of oracle_compute_orientations (cuSIFT_D.cu:362-394 computes both
+        peaks and keeps the first)."""
+        max_pts = kw.get("max_pts", 32768)
+        diag = np.full((max_pts, 2), np.nan, dtype=np.float32)
+        self.lib.oracle_set_orientation_diag(diag.ctypes.data, max_pts)
+        try:
+            pts = self.extract(img, **kw)
+        finally:
+            self.lib.oracle_set_orientation_diag(None, 0)
+        return pts, diag[:len(pts)]
 
     def match(self, sift1, sift2, distance=1):
         """MatchSiftData: fills score/ambiguity/match/match_xpos/match_ypos of sift1 in place."""

@@ -11,7 +11,7 @@ are compared strictly and octave 0 as "every golden row is one of ours".
 import numpy as np
 import pytest
 
-from parity_utils import ang_diff, canonical_order, golden_gates, match_nearest, xys
+from parity_utils import ang_diff, canonical_order, golden_gates, match_nearest, orientation_outliers, xys
 
 
 @pytest.fixture(scope="module", params=["", "libm"], ids=["shared-math", "glibc"])
@@ -60,10 +60,12 @@ def test_oracle_orientation_vs_golden(oracle, gray1, golden_check):
     gold = golden_check.astype(np.float64)
     idx, dist = match_nearest(gold[:N_COARSE, :3], xys(pts), 1e-2)
     d = ang_diff(gold[:N_COARSE, 3], pts["orientation"][idx].astype(np.float64))
-    # distributional gate (hard histogram binning amplifies ulp noise; SURVEY.md hard part 1)
-    assert (d < 0.1).mean() >= 0.90, (d < 0.1).mean()
-    assert (d < 1.0).mean() >= 0.97, (d < 1.0).mean()
-    assert np.median(d) < 0.01
+    # the north star's 1e-3 (degrees) against the reference's OWN run, since the texture model's weights are fixed point
+    # too (oracle_tex2d; SURVEY.md hard part 1 expected no better than 94 % within 0.1 degree)
+    assert (d < 1e-3).mean() >= 0.99, (d < 1e-3).mean()
+    assert (d < 0.1).mean() >= 0.995, (d < 0.1).mean()
+    assert (d < 1.0).mean() >= 0.999, (d < 1.0).mean()
+    assert np.median(d) < 1e-4
 
 
 @pytest.mark.parametrize("which", ["cusift1_check", "cusift1"])
@@ -71,10 +73,51 @@ def test_oracle_vs_all_of_the_golden_file(oracle, gray1, golden_check, golden_ru
     """Everything the reference's two runs hold -- 2 x 4096 rows of x, y, scale AND orientation -- against the oracle:
     the octave-0 rows (1555..4095) are gated on orientation too, and `cusift1` (the second run) gets the same gates as
     `cusift1_check`, not only a location check.  The achieved fractions are in the assertion message / test properties."""
-    pts = oracle.extract(gray1, **REF_PARAMS)
-    got = golden_gates(golden_check if which == "cusift1_check" else golden_run2, pts, "oracle")
+    pts, peaks = oracle.extract_with_orientation_peaks(gray1, **REF_PARAMS)
+    gold = golden_check if which == "cusift1_check" else golden_run2
+    got = golden_gates(gold, pts, "oracle")
     for k, v in got.items():
         record_property(k, v)
+    # the orientation tail, explained: every golden row more than 1 degree from ours must sit at the oracle's SECOND
+    # histogram peak with the two peaks nearly tied (the reference computes both and keeps the larger, cuSIFT_D.cu:362-394:
+    # a tie decided the other way by the order of its LDS atomics) -- one row of 4,095 on this fixture, peak ratio 0.983
+    tail = orientation_outliers(gold, pts, peaks)
+    for k, v in tail.items():
+        record_property("ori_tail_" + k, str(v))
+    assert tail["outliers_gt_1_deg"] <= 3 and tail["outliers_unexplained"] == 0, tail
+    assert tail["outliers_within_a_bin_of_first_peak"] == 0, tail
+    assert tail["outliers_at_second_peak"] == tail["outliers_at_second_peak_ratio_gt_0.90"], tail
+
+
+def test_texture_weights_are_fixed_point(oracle, gray1, golden_check):
+    """The rule itself, at the GOLDEN locations (so that no difference in x, y or scale is in the way): orientations
+    recomputed by the oracle's stage function at the golden x, y, scale of every matched row equal the golden
+    orientations to 1e-4 degree -- all of them -- and most are the same float."""
+    from oracle_binding import SIFT_POINT_DTYPE, pitched
+
+    pts = oracle.extract(gray1, **REF_PARAMS)
+    gold = golden_check.astype(np.float64)
+    idx, dist = match_nearest(gold[:, :3], xys(pts), 1e-2)
+    ok = dist < 1e-2
+    assert ok.sum() >= 4090
+    sub = pts["subsampling"][idx]
+    h, w = gray1.shape
+    imgs, dims = [pitched(gray1)], [(w, h)]
+    for _ in range(5):
+        ww, hh = dims[-1]
+        imgs.append(oracle.scale_down(imgs[-1], ww, hh))
+        dims.append((ww // 2, hh // 2))
+    re = np.zeros(len(gold), dtype=SIFT_POINT_DTYPE)
+    re["coords2D"] = (golden_check[:, :2] / sub[:, None]).astype(np.float32)  # exact: powers of two
+    re["scale"] = (golden_check[:, 2] / sub).astype(np.float32)
+    for k in range(6):
+        sel = np.flatnonzero(sub == 2.0 ** k)
+        tmp = re[sel].copy()
+        oracle.compute_orientations(imgs[k], dims[k][0], dims[k][1], tmp, 0, len(tmp))
+        re["orientation"][sel] = tmp["orientation"]
+    d = ang_diff(gold[ok, 3], re["orientation"][ok].astype(np.float64))
+    assert d.max() < 1e-4, (d.max(), int((d >= 1e-4).sum()))
+    assert (re["orientation"][ok] == golden_check[ok, 3]).mean() > 0.8  # bit-identical floats
 
 
 def test_two_reference_runs_differ_only_in_octave0_order(golden_check, golden_run2):
