@@ -1,0 +1,73 @@
+"""The reference's two-stage pipeline (LaplaceMulti -> DoG planes in HBM -> FindPointsMulti): `roofline`, the blur + DoG
+kernel's algorithmic bytes over its HIP-event time against 8 TB/s -- the north-star gate."""
+from .common import HBM_PEAK_GBS
+
+
+def run(R):
+    args, torch, out, ex, d_imgs, K, legs = R.args, R.torch, R.out, R.ex, R.d_imgs, R.args.steps, R.legs
+    B, w, h, E, dev = R.B, R.w, R.h, R.E, R.dev
+    traffic, blur_b, find_b, stage_overlapped = R.traffic, R.blur_b, R.find_b, R.stage_overlapped
+    run_single_stream, stage_table = R.run_single_stream, R.stage_table
+    if "two_stage" in legs and ex.params.fused_detect:
+        ex.params.fused_detect = 0
+        two_ms, stage2 = run_single_stream(ex, d_imgs, K)
+        ex.params.fused_detect = 1
+        lap_ms, lap_n = stage2["laplace_multi"]
+        if lap_n > 0 and lap_ms > 0:
+            # per launch: mean algorithmic bytes / mean HIP-event duration over the launches (5 octaves x K steps)
+            achieved = (blur_b * K / lap_n) / (lap_ms * 1e-3 / lap_n) / 1e9
+            out["roofline"] = {
+                "kernel": "laplace_multi_fast_kernel (8 blurs + 7 DoG planes, 32 B/px algorithmic)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic.get("laplace_multi_fast_kernel", {}).get("hbm_bytes_per_launch"),
+                "traffic_source": "profiles/traffic.json (the builder's FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                  "gfx950 corrections applied; committed, not collected in this run)",
+                "algorithmic_bytes_per_launch": int(blur_b * K / lap_n),
+                "avg_launch_ms": round(lap_ms / lap_n, 5),
+                "launches": lap_n,
+                "note": "measured in the two-stage leg of this run (same inputs, HIP events on the launching "
+                        "stream); the timed region itself uses the fused kernel, whose roofline is VALU "
+                        "(roofline_kernels)",
+            }
+            # the octave-0 launch on its own (3/4 of the bytes): the same kernel through the stage entry point,
+            # DoG planes of the whole batch in a buffer of their own
+            try:
+                if args.profile_run:
+                    raise RuntimeError("skipped (--profile-run)")
+                dog0 = torch.empty((B, 7, h, ex.pitch), dtype=torch.float32, device=dev)
+                ex.ctx.timing_enable(True)
+                for rep in range(2 + max(3, K // 2)):
+                    if rep == 2:
+                        torch.cuda.synchronize()
+                        ex.ctx.timing_reset()
+                    ex.ctx.laplace_multi(d_imgs.data_ptr(), w, h, ex.pitch, args.init_blur, dog0.data_ptr(),
+                                         n_images=B, img_stride=h * ex.pitch, dog_stride=7 * h * ex.pitch)
+                torch.cuda.synchronize()
+                l0_ms, l0_n = ex.ctx.timing_read()["laplace_multi"]
+                ex.ctx.timing_enable(False)
+                del dog0
+                b0 = 32.0 * w * h * B
+                out["roofline"]["octave0_launch"] = {
+                    "algorithmic_bytes": int(b0), "avg_launch_ms": round(l0_ms / l0_n, 5),
+                    "achieved": round(b0 / (l0_ms / l0_n * 1e-3) / 1e9, 1),
+                    "frac": round(b0 / (l0_ms / l0_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "the largest launch alone; `achieved` above averages it with the four smaller octaves"}
+            except Exception as e:  # noqa: BLE001 -- an extra, never the reason to lose the line
+                out["roofline"]["octave0_launch"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        fp_ms = stage2["find_points_multi"][0]
+        out["two_stage_leg"] = {"ms_per_step": round(two_ms, 4), "stage_ms_per_step": stage_table(stage2, K),
+                                "find_points_GBps": round(find_b / (fp_ms / K * 1e-3) / 1e9, 1) if fp_ms > 0 else None,
+                                "find_points_traffic_bytes_per_launch":
+                                    traffic.get("find_points_fast_kernel", {}).get("hbm_bytes_per_launch")}
+    elif "two_stage" in legs and stage_overlapped is not None:  # --two-stage: the timed region itself
+        lap_ms, lap_n = stage_overlapped["laplace_multi"]
+        if lap_n:
+            achieved = (blur_b * K / lap_n) / (lap_ms * 1e-3 / lap_n) / 1e9
+            out["roofline"] = {"kernel": "laplace_multi_fast_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                               "traffic": traffic.get("laplace_multi_fast_kernel", {}).get("hbm_bytes_per_launch"),
+                               "note": "measured over the timed region (kernel spans of %d streams)" % E}

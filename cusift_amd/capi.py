@@ -810,6 +810,34 @@ class DeviceBuffer:
             pass
 
 
+class HostBuffer:
+    """Pinned host memory made through the C ABI (cusift_malloc_host / cusift_free_host): what include/cuSIFT.h's
+    SiftData keeps its host records in -- a read-back into it is one DMA, not a staged copy."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().cusift_malloc_host(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def as_numpy(self, dtype, count):
+        dtype = np.dtype(dtype)
+        assert count * dtype.itemsize <= self.nbytes
+        raw = (C.c_char * (count * dtype.itemsize)).from_address(self.ptr)
+        return np.frombuffer(raw, dtype=dtype, count=count)  # a view: valid until free()
+
+    def free(self):
+        if self.ptr:
+            check(lib().cusift_free_host(C.c_void_p(self.ptr)))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 PIPE_U8, PIPE_F32 = 0, 1
 
 

@@ -480,8 +480,10 @@ int ctx_create_impl(cusift_ctx **out, int device, void *hip_stream, bool borrow)
   }
   hipError_t e = hipMalloc((void **)&ctx->d_counter1, 256);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_queue, kQueueShards * 128);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_counter1, 256, hipHostMallocDefault);
   if (e != hipSuccess) {
     if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return fail(CUSIFT_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -514,6 +516,7 @@ extern "C" int cusift_ctx_destroy(cusift_ctx *ctx) {
   if (ctx->match_scratch) (void)hipFree(ctx->match_scratch);
   if (ctx->d_counter1) (void)hipFree(ctx->d_counter1);
   if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+  if (ctx->h_counter1) (void)hipHostFree(ctx->h_counter1);
   if (ctx->side) {
     (void)hipStreamSynchronize(ctx->side);
     (void)hipStreamDestroy(ctx->side);

@@ -360,16 +360,27 @@ extern "C" int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h,
   if (!num_pts) return fail(CUSIFT_ERR_INVALID, "num_pts is NULL");
   *num_pts = 0;
   TRY(cusift_extract_batch(ctx, d_img, 1, w, h, pitch, (size_t)h * pitch, prm, d_points, ctx->d_counter1));
-  unsigned int cnt = 0;
-  HIP_TRY(hipMemcpyAsync(&cnt, ctx->d_counter1, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+  // The count travels to a pinned word of the context (a pageable destination is a staged copy under a runtime-wide
+  // lock: callers on several threads serialise on it), and the records the caller most likely wants travel WITH it: as
+  // many as the context's previous call returned plus an eighth, copied before the count is known -- one wait for the
+  // device instead of two (the reference's order, cuSIFT.cu:107-114: count, then Synchronize()).  Whatever the guess
+  // missed follows in a second copy.  Rows at and beyond numPts of the caller's buffer are unspecified, as after the
+  // reference's malloc (cuSIFT.cu:24); never beyond its max_pts rows.
+  HIP_TRY(hipMemcpyAsync(ctx->h_counter1, ctx->d_counter1, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+  const int guess = h_points ? (ctx->extract_guess < prm->max_pts ? ctx->extract_guess : prm->max_pts) : 0;
+  if (guess > 0)
+    HIP_TRY(hipMemcpyAsync(h_points, d_points, sizeof(cusift_point) * (size_t)guess, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const unsigned int cnt = *(volatile unsigned int *)ctx->h_counter1;
   // cuSIFT.cu:107-110
   const int n = cnt < (unsigned int)prm->max_pts ? (int)cnt : prm->max_pts;
   *num_pts = n;
-  if (h_points && n > 0) {  // SiftData::Synchronize, cuSIFT.cu:52-59
-    HIP_TRY(hipMemcpyAsync(h_points, d_points, sizeof(cusift_point) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (h_points && n > guess) {  // SiftData::Synchronize, cuSIFT.cu:52-59
+    HIP_TRY(hipMemcpyAsync(h_points + guess, d_points + guess, sizeof(cusift_point) * (size_t)(n - guess),
+                           hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
+  if (h_points) ctx->extract_guess = n + n / 8 + 16;
   return CUSIFT_OK;
 }
 

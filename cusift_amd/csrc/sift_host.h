@@ -153,6 +153,8 @@ struct cusift_ctx {
   size_t u8_stage_bytes = 0;
   // small persistent device scratch for the blocking single-image entry points
   unsigned int *d_counter1 = nullptr;
+  unsigned int *h_counter1 = nullptr;  // pinned mailbox the count of cusift_extract is copied to (no staged pageable copy)
+  int extract_guess = 0;  // records cusift_extract copies back BEFORE it knows the count (the previous call's, + 1/8)
   unsigned int *d_queue = nullptr;  // kQueueShards work cursors of describe_all_kernel, 128 bytes apart
   int describe_grid = 0;  // resident blocks of describe_all_kernel on this device (occupancy query, cached)
   // octave 0's detection beside the coarser octaves (cusift_extract_batch): a second stream and its fork / join events

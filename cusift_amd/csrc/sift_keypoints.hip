@@ -32,19 +32,15 @@ __device__ __forceinline__ float tex2d(const float *__restrict__ img, int w, int
   const int j0 = local_row(j, h, rw), j1 = local_row(j + 1, h, rw);
   const float s00 = img[(long)j0 * pitch + i0], s10 = img[(long)j0 * pitch + i1];
   const float s01 = img[(long)j1 * pitch + i0], s11 = img[(long)j1 * pitch + i1];
-  float w00, w10, w01, w11;
-  if (q > 0.0f) {  // fixed-point weights: the product is rounded to the fractions' precision (bilinear_weights<true>)
-    w11 = floorf(fmaf(a * b, q, 0.5f)) * inv_q;
-    w10 = a - w11;
-    w01 = b - w11;
-    w00 = (1.0f - a) - w01;
-  } else {
-    const float ia = 1.0f - a, ib = 1.0f - b;
-    w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
-  }
-  float t = w00 * s00;
-  t = fmaf(w10, s10, t);
-  t = fmaf(w01, s01, t);
+  // The four weights: the products of exact fractions, or (quantised) bilinear_weights<true>'s fixed-point ones -- there the
+  // products are exact too (multiples of 2^-16) and W11 = round(a b) differs from a b by d, |d| <= 2^-9, which the other
+  // three take up: a (1-b) + d == a - W11 and so on, every operation exact.  With exact fractions d is +0.
+  const float ia = 1.0f - a, ib = 1.0f - b, ab = a * b;
+  const float w11 = q > 0.0f ? floorf(fmaf(ab, q, 0.5f)) * inv_q : ab;
+  const float d = ab - w11;
+  float t = (ia * ib - d) * s00;
+  t = fmaf(a * ib + d, s10, t);
+  t = fmaf(ia * b + d, s01, t);
   t = fmaf(w11, s11, t);
   return t;
 }
@@ -186,21 +182,26 @@ __device__ __forceinline__ float tex2d_patch_desc(const float *lds, int x0, int 
   const f2 pb = p - f2{0.5f, 0.5f};
   const f2 fl = f2{floorf(pb.x), floorf(pb.y)};
   f2 ab = pb - fl;
-  if (kQuant) {
+  if (kQuant) {  // A, B: the fractions as integers in [0, q] -- the weights below stay integers too (see the return)
     const f2 t = __builtin_elementwise_fma(ab, f2{q, q}, f2{0.5f, 0.5f});
-    ab = f2{floorf(t.x), floorf(t.y)} * f2{inv_q, inv_q};
+    ab = f2{floorf(t.x), floorf(t.y)};
   }
   const int e = (int)fmaf(fl.y, (float)kStride, fl.x) - (y0 * kStride + x0);
   const float *p0 = lds + e;
   const float *p1 = p0 + kStride;
   const float s00 = p0[0], s10 = p0[1], s01 = p1[0], s11 = p1[1];
   float w00, w10, w01, w11;
-  if (kQuant) {  // bilinear_weights<true>, the two middle subtractions as one packed operation
-    w11 = floorf(fmaf(ab.x * ab.y, q, 0.5f)) * inv_q;
+  if (kQuant) {
+    // bilinear_weights<true> times q: W11 = floor(A B / q + 1/2), W10 = A - W11, W01 = B - W11, W00 = q - A - B + W11
+    // (every step exact), the two middle subtractions as one packed operation.  The tap then comes out as q TIMES the
+    // texture value -- the same four operations on operands scaled by a power of two, so exactly q times the oracle's
+    // bits -- and the caller folds the 1/q into a factor it multiplies with anyway (PatchSampler::desc_scale): one
+    // instruction more per tap than the exact-product weights of rounds 1-5 instead of three.
+    w11 = floorf(fmaf(ab.x * ab.y, inv_q, 0.5f));
     const f2 wm = ab - f2{w11, w11};
     w10 = wm.x;
     w01 = wm.y;
-    w00 = (1.0f - ab.x) - w01;
+    w00 = (q - ab.x) - w01;
   } else {
     bilinear_weights<false>(ab.x, ab.y, q, inv_q, w00, w10, w01, w11);
   }
@@ -252,7 +253,8 @@ struct PatchSampler {
   __device__ __forceinline__ float operator()(float x, float y) const {
     return tex2d_patch<kStride, kQuant>(patch, x0, y0, x, y, q, inv_q);
   }
-  // a descriptor tap at p = (x, y): the same operations with x and y as a register pair (tex2d_patch_desc)
+  // a descriptor tap at p = (x, y): the same operations with x and y as a register pair (tex2d_patch_desc) -- quantised:
+  // q times the texture value (the weights are left as integers; desc_lane_consts folds the 1 / q)
   __device__ __forceinline__ float desc(f2 p) const { return tex2d_patch_desc<kStride, kQuant>(patch, x0, y0, p, q, inv_q); }
 };
 struct GlobalSampler {
@@ -266,7 +268,11 @@ struct GlobalSampler {
   __device__ __forceinline__ float operator()(float x, float y) const {
     return tex2d(img, w, h, pitch, rw, x, y, q, inv_q);
   }
-  __device__ __forceinline__ float desc(f2 p) const { return tex2d(img, w, h, pitch, rw, p.x, p.y, q, inv_q); }
+  // (the descriptor's taps are q times the value for a quantised model, as the patch sampler's: desc_lane_consts)
+  __device__ __forceinline__ float desc(f2 p) const {
+    const float t = tex2d(img, w, h, pitch, rw, p.x, p.y, q, inv_q);
+    return q > 0.0f ? t * q : t;
+  }
 };
 
 // A value every lane loaded from the same address, declared wave-uniform: it then lives in an SGPR and whatever
@@ -608,11 +614,16 @@ struct DescLaneConsts {
   float gy1[4];
 };
 
-__device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane) {
+// The descriptor's taps come back as q TIMES the texture value when the texture model is quantised (q > 0: the samplers
+// leave their weights as integers, tex2d_patch_desc) -- a power of two.  The gradient's direction does not see it
+// (quotient, reciprocal and comparisons scale exactly) and its magnitude sqrt(dx^2 + dy^2) scales by exactly q, so the
+// 1/q goes into the column's Gaussian weight here, once per lane and launch: gy * (gx / q) * (q m) is gy * gx * m bit for
+// bit.
+__device__ __forceinline__ DescLaneConsts desc_lane_consts(int lane, float q, float inv_q) {
   // sample idx = lane + 64*step -> column tx = lane%16, row y = lane/16 + 4*step
   DescLaneConsts c;
   c.tx1 = lane & 15;
-  c.gx1 = sm_expf(-(c.tx1 - 7.5f) * (c.tx1 - 7.5f) / 128.0f);
+  c.gx1 = sm_expf(-(c.tx1 - 7.5f) * (c.tx1 - 7.5f) / 128.0f) * (q > 0.0f ? inv_q : 1.0f);
 #pragma unroll
   for (int step = 0; step < 4; ++step) {
     const int y = (lane >> 4) + 4 * step;
@@ -699,7 +710,7 @@ __device__ __forceinline__ void kp_descriptor(KpShared &S, const TEX &tex, const
   const float ssina = scale * sina;
   const float scosa = scale * cosa;
 
-  // ---- phase 1: samples ----
+  // ---- phase 1: samples (the taps are q times the texture value; C.gx1 carries the 1 / q: desc_lane_consts) ----
   unsigned int codes = 0;
 #pragma unroll
   for (int step = 0; step < 4; ++step) {
@@ -921,7 +932,7 @@ __global__ void __launch_bounds__(64) descriptors_kernel(const float *__restrict
   const unsigned int fst = first ? first[blockIdx.y] : 0u;
   const unsigned int cnt = counters[blockIdx.y];
   const unsigned int last = cnt < (unsigned int)max_pts ? cnt : (unsigned int)max_pts;
-  const DescLaneConsts C = desc_lane_consts(lane);
+  const DescLaneConsts C = desc_lane_consts(lane, q, inv_q);
 
   for (unsigned int bx = fst + blockIdx.x; bx < last; bx += gridDim.x) {
     cusift_point *pt = points + bx;
@@ -1035,7 +1046,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   running_sums_in_place(s_prefix, n_images, lane);
   wave_sync();
   const unsigned int total = s_prefix[n_images];
-  const DescLaneConsts C = desc_lane_consts(lane);
+  const DescLaneConsts C = desc_lane_consts(lane, q, inv_q);
   const int exp0 = (__float_as_int(T.sub[0]) >> 23) & 0xff;
 
   // Items are handed out dynamically: the first one is the workgroup's index, every further one comes from a global
@@ -1268,7 +1279,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   __shared__ KpShared S;
   const int lane = threadIdx.x;
   const unsigned int total = seg_end[G.n_seg - 1];
-  const DescLaneConsts C = desc_lane_consts(lane);
+  const DescLaneConsts C = desc_lane_consts(lane, q, inv_q);
   const int exp0 = (__float_as_int(T.sub[0]) >> 23) & 0xff;
   for (unsigned int k = seg_end[0] + blockIdx.x; k < total; k += gridDim.x) {  // wave-uniform
     int r = 1;

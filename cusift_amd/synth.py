@@ -82,9 +82,7 @@ def _mirror_tiled(ny, nx):
     return _tiled_cache[(ny, nx)]
 
 
-def tile(seed, w=1920, h=1080, preblur=0.0):
-    """preblur > 0: the image is low-passed to that sigma and re-quantised to 8 bit, so that it really
-    carries the blur a caller declares with initBlur (BASELINE config: initBlur = 1.0)."""
+def _tile_plain(seed, w, h, preblur):
     g = fixture_image()
     gh, gw = g.shape
     ny, nx = -(-h // gh) + 1, -(-w // gw) + 1
@@ -99,6 +97,65 @@ def tile(seed, w=1920, h=1080, preblur=0.0):
     if preblur > 0:
         out = gaussian_blur(out, preblur)
     return np.clip(np.rint(out), 0, 255).astype(np.float32)
+
+
+def tile(seed, w=1920, h=1080, preblur=0.0):
+    """preblur > 0: the image is low-passed to that sigma and re-quantised to 8 bit, so that it really
+    carries the blur a caller declares with initBlur (BASELINE config: initBlur = 1.0).
+
+    Large blurred images (BASELINE configs[4]: 8192 x 8192) are assembled from ONE period of the pattern: away from its
+    border -- and from the rows / columns where the cyclic shift wraps around a plane with an odd number of tiles -- the
+    mirror-tiled image is periodic with period (2 gh, 2 gw), so is its blur, and every pixel's sum is formed from the same
+    values in the same order: bit for bit _tile_plain's result (tests/test_frontend.py) in 2 s instead of 20."""
+    g = fixture_image()
+    gh, gw = g.shape
+    ph, pw = 2 * gh, 2 * gw
+    if preblur <= 0 or h < 4 * ph or w < 4 * pw:
+        return _tile_plain(seed, w, h, preblur)
+    r = int(np.ceil(4 * preblur))
+    ny, nx = -(-h // gh) + 1, -(-w // gw) + 1
+    big = _mirror_tiled(ny, nx)
+    st, r0 = splitmix64(seed)
+    st, r1 = splitmix64(st)
+    sy, sx = int(r1 % gh), int(r0 % gw)
+    rows = (np.arange(h) - sy) % big.shape[0]
+    cols = (np.arange(w) - sx) % big.shape[1]
+    scale = np.float32(255.0 / 144.0)
+
+    def raw(y0, y1, x0, x1):
+        return big[rows[y0:y1]][:, cols[x0:x1]] * scale
+
+    # frame: r pixels at every border (replicated edges) plus, at the top / left, the rows / columns that come from the
+    # far end of a plane with an odd number of tiles (there the wrap-around breaks the mirror pattern)
+    mt = r + (sy if ny % 2 else 0)
+    ml = r + (sx if nx % 2 else 0)
+    out = np.empty((h, w), dtype=np.float32)
+    core = gaussian_blur_valid(raw(mt - r, mt + ph + r, ml - r, ml + pw + r), preblur)  # pixels [mt, mt+ph) x [ml, ml+pw)
+    reps_y, reps_x = -(-(h - mt) // ph), -(-(w - ml) // pw)
+    out[mt:, ml:] = np.tile(core, (reps_y, reps_x))[:h - mt, :w - ml]
+    # the frame, with the plain blur on strips that carry r true neighbours beyond what is kept
+    out[:mt, :] = gaussian_blur(raw(0, mt + r, 0, w), preblur)[:mt, :]
+    out[h - r:, :] = gaussian_blur(raw(h - 2 * r, h, 0, w), preblur)[r:, :]
+    out[:, :ml] = gaussian_blur(raw(0, h, 0, ml + r), preblur)[:, :ml]
+    out[:, w - r:] = gaussian_blur(raw(0, h, w - 2 * r, w), preblur)[:, r:]
+    return np.clip(np.rint(out), 0, 255).astype(np.float32)
+
+
+def gaussian_blur_valid(img, sigma):
+    """gaussian_blur's sums without the padding: output pixel (y, x) is the blur of img centred at (y + r, x + r), formed
+    from the same taps in the same order; shape (H - 2 r, W - 2 r)."""
+    r = int(np.ceil(4 * sigma))
+    k = np.exp(-np.arange(-r, r + 1, dtype=np.float64) ** 2 / (2.0 * sigma * sigma))
+    k = (k / k.sum()).astype(np.float32)
+    a = img.astype(np.float32)
+    h, w = a.shape[0] - 2 * r, a.shape[1] - 2 * r
+    tmp = np.zeros((a.shape[0], w), dtype=np.float32)
+    for i in range(2 * r + 1):
+        tmp += k[i] * a[:, i:i + w]
+    out = np.zeros((h, w), dtype=np.float32)
+    for i in range(2 * r + 1):
+        out += k[i] * tmp[i:i + h, :]
+    return out
 
 
 def blobs(seed, w=1920, h=1080):

@@ -15,6 +15,7 @@
 #ifndef CUSIFT_AMD_DROPIN_H
 #define CUSIFT_AMD_DROPIN_H
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -47,34 +48,68 @@ inline void cusift_check_(int rc, const char *what, const char *file, int line) 
 
 namespace cusift_dropin {
 // The reference keeps one implicit global context (default stream + file-scope device symbols,
-// cuSIFT_D.cu:13-20).  Here it is one lazily created cusift_ctx on the device chosen by InitCuda().
-inline int &device_slot() {
-  static int dev = 0;
+// cuSIFT_D.cu:13-20), so one extraction at a time per process.  Here the implicit context is one lazily created
+// cusift_ctx PER CALLING THREAD (its own stream and scratch arena) on the device chosen by InitCuda(): a
+// single-threaded program behaves exactly as before, and a program that calls SiftData::Extract / ExtractSift from N
+// host threads -- each with its own SiftData and cuImage objects, nothing else changed -- has N extractions in
+// flight on the device (tests/cpp/threads_dropin.cpp).  Objects may cross threads: buffers belong to the device, not
+// to a context.  A thread's context is destroyed when the thread ends; the first thread's lives as long as the
+// process (the reference's global state is never torn down either), unless shutdown() is called on that thread.
+inline std::atomic<int> &device_slot() {
+  static std::atomic<int> dev{0};
   return dev;
 }
-inline cusift_ctx *&ctx_slot() {
-  static cusift_ctx *c = nullptr;
-  return c;
+struct thread_ctx {
+  cusift_ctx *c = nullptr;
+  int dev = -1;
+  bool keep = false;  // the process's first context: not destroyed at thread exit
+  ~thread_ctx() {
+    if (c && !keep) cusift_ctx_destroy(c);
+  }
+};
+inline thread_ctx &thread_slot() {
+  static thread_local thread_ctx t;
+  return t;
 }
+inline cusift_ctx *&ctx_slot() { return thread_slot().c; }
 inline cusift_ctx *ctx() {
-  cusift_ctx *&c = ctx_slot();
-  if (!c) {
-    safeCall(cusift_ctx_create(&c, device_slot(), nullptr));
+  thread_ctx &t = thread_slot();
+  const int dev = device_slot().load(std::memory_order_relaxed);
+  if (t.c && t.dev != dev) {  // InitCuda() chose another device since this thread last extracted
+    cusift_ctx_destroy(t.c);
+    t.c = nullptr;
+  }
+  if (!t.c) {
+    static std::atomic<bool> first{true};
+    safeCall(cusift_ctx_create(&t.c, dev, nullptr));
+    t.dev = dev;
+    t.keep = first.exchange(false);
     // An unchanged caller of the reference's API has no handle on the launch policy; the one knob such a caller may
     // want -- octave 0's detection on a second stream, for large single batches -- is read HERE, in the shim that is
     // compiled into the caller, from CUSIFT_OCTAVE_OVERLAP (0..3 = CUSIFT_POLICY_SIDE_STREAM's values).  The library
     // itself reads no environment variable on the extraction path (until round 5 it read this one).
     if (const char *e = std::getenv("CUSIFT_OCTAVE_OVERLAP")) {
       const int v = std::atoi(e);
-      if (v >= 0 && v <= 3) safeCall(cusift_ctx_set_policy(c, CUSIFT_POLICY_SIDE_STREAM, v));
+      if (v >= 0 && v <= 3) safeCall(cusift_ctx_set_policy(t.c, CUSIFT_POLICY_SIDE_STREAM, v));
     }
   }
-  return c;
+  return t.c;
 }
-inline void shutdown() {
-  cusift_ctx *&c = ctx_slot();
-  if (c) cusift_ctx_destroy(c);
-  c = nullptr;
+inline void shutdown() {  // the calling thread's context
+  thread_ctx &t = thread_slot();
+  if (t.c) cusift_ctx_destroy(t.c);
+  t.c = nullptr;
+}
+// SiftData's host records: pinned memory (the reference: malloc, cuSIFT.cu:24).  The class owns and frees the
+// buffer (cuSIFT.cu:34-50), callers only index it (test/detector.cpp:56) -- pinned, the read-back at the end of
+// every Extract is one DMA instead of a staged copy, and it does not serialise with other threads' transfers.
+inline void *host_alloc(size_t bytes) {
+  void *p = nullptr;
+  safeCall(cusift_malloc_host(&p, bytes));
+  return p;
+}
+inline void host_free(void *p) {
+  if (p) cusift_free_host(p);
 }
 }  // namespace cusift_dropin
 
@@ -88,8 +123,7 @@ inline void InitCuda(int devNum) {
   }
   if (devNum > n - 1) devNum = n - 1;
   if (devNum < 0) devNum = 0;
-  if (cusift_dropin::ctx_slot() && cusift_dropin::device_slot() != devNum) cusift_dropin::shutdown();
-  cusift_dropin::device_slot() = devNum;
+  cusift_dropin::device_slot().store(devNum);  // for every thread: each re-creates its context on its next call
   safeCall(cusift_init(devNum));
 }
 
@@ -207,7 +241,7 @@ class cuImage {
       d_internalAlloc = true;
     }
     if (withHost && h_data == nullptr) {
-      h_data = static_cast<float *>(std::malloc(sizeof(float) * (size_t)pitch * (size_t)height));
+      h_data = static_cast<float *>(cusift_dropin::host_alloc(sizeof(float) * (size_t)pitch * (size_t)height));
       h_internalAlloc = true;
     }
   }
@@ -229,7 +263,7 @@ class cuImage {
  private:
   void release() {
     if (d_internalAlloc && d_data != nullptr) cusift_free(d_data);
-    if (h_internalAlloc && h_data != nullptr) std::free(h_data);
+    if (h_internalAlloc) cusift_dropin::host_free(h_data);
     d_data = h_data = t_data = nullptr;
     d_internalAlloc = h_internalAlloc = false;
   }
@@ -255,6 +289,17 @@ class SiftPoint {
   float coords3D[3];
 };
 static_assert(sizeof(SiftPoint) == sizeof(cusift_point) && sizeof(SiftPoint) == 588, "SiftPoint is a 588-byte record");
+
+// The reference times every Extract with a TimerGPU and prints the result (cuSIFT.cu:64,117-119).  With CUSIFT_QUIET
+// nothing is printed, so nothing is timed either: two event creations, two records, a wait and two destructions per
+// call are runtime-wide locks that callers on several threads would queue on.
+#ifndef CUSIFT_QUIET
+#define CUSIFT_REPORT_TIMER(name) TimerGPU name
+#define CUSIFT_REPORT_READ(name) (name).read()
+#else
+#define CUSIFT_REPORT_TIMER(name) (void)0
+#define CUSIFT_REPORT_READ(name) 0.0
+#endif
 
 // ---- cuSIFT.h:32-74, cuSIFT.cu:13-120 ---------------------------------------------------------------
 class SiftData {
@@ -306,16 +351,16 @@ class SiftData {
 
   // cuSIFT.cu:61-120: dense host image -> numPts, d_data, h_data
   void Extract(float *im, int width, int height, float subsampling = 1.0f) {
-    TimerGPU timer;
+    CUSIFT_REPORT_TIMER(timer);
     require_device("Extract");
     cusift_params p = params(subsampling);
     safeCall(cusift_extract_host(cusift_dropin::ctx(), im, width, height, &p, as_c(d_data), as_c(h_data), &numPts));
-    report(timer.read());
+    report(CUSIFT_REPORT_READ(timer));
   }
 
   // legacy ExtractSift on a device-resident cuImage (main.cpp:102-103,327-328)
   void Extract(cuImage &img, float subsampling = 1.0f) {
-    TimerGPU timer;
+    CUSIFT_REPORT_TIMER(timer);
     require_device("ExtractSift");
     if (img.d_data == nullptr) {
       std::printf("ExtractSift: missing data\n");
@@ -324,7 +369,7 @@ class SiftData {
     cusift_params p = params(subsampling);
     safeCall(cusift_extract(cusift_dropin::ctx(), img.d_data, img.width, img.height, img.pitch, &p, as_c(d_data),
                             as_c(h_data), &numPts));
-    report(timer.read());
+    report(CUSIFT_REPORT_READ(timer));
   }
 
   // cuSIFT.cu:383-395 (always returns 0.0 like every launch wrapper of the reference)
@@ -342,7 +387,7 @@ class SiftData {
     numPts = 0;
     maxPts = maxPts_;
     const size_t bytes = sizeof(SiftPoint) * (size_t)(maxPts_ > 0 ? maxPts_ : 0);
-    if (host && bytes) h_data = static_cast<SiftPoint *>(std::malloc(bytes));
+    if (host && bytes) h_data = static_cast<SiftPoint *>(cusift_dropin::host_alloc(bytes));
     if (dev && bytes) {
       void *ptr = nullptr;
       safeCall(cusift_malloc(&ptr, bytes));
@@ -352,7 +397,7 @@ class SiftData {
   void release() {
     if (d_data != nullptr) cusift_free(d_data);
     d_data = nullptr;
-    if (h_data != nullptr) std::free(h_data);
+    cusift_dropin::host_free(h_data);
     h_data = nullptr;
     numPts = 0;
     maxPts = 0;

@@ -267,7 +267,9 @@ int cusift_graph_destroy(cusift_graph *g);
 /* The legacy ExtractSift(siftData, cuImage&, numOctaves, initBlur, thresh, lowestScale, subsampling)
  * (main.cpp:99-103,324-328; cuSIFT.cu:123-134): image already on the device.  Blocking; writes
  * *num_pts = min(count, max_pts) (cuSIFT.cu:107-110) and, if h_points != NULL, copies that many
- * records to the host (SiftData::Synchronize, cuSIFT.cu:52-59). */
+ * records to the host (SiftData::Synchronize, cuSIFT.cu:52-59).  h_points must hold max_pts records (the
+ * reference's SiftData does): rows [num_pts, max_pts) are unspecified afterwards -- the copy starts before the
+ * count is known, sized by the context's previous call.  Pinned h_points (cusift_malloc_host) make it one DMA. */
 int cusift_extract(cusift_ctx *ctx, const float *d_img, int w, int h, int pitch, const cusift_params *p,
                    cusift_point *d_points, cusift_point *h_points, int *num_pts);
 /* SiftData::Extract(float *im, w, h, subsampling), cuSIFT.cu:61-120: dense host image in, uploads

@@ -32,9 +32,9 @@ inline void AddSiftData(SiftData &data, SiftPoint *h_data, int numPts) {
     while (newNum > newMax) newMax *= 2;
     const size_t bytes = sizeof(SiftPoint) * (size_t)newMax, used = sizeof(SiftPoint) * (size_t)data.numPts;
     if (data.h_data != nullptr) {
-      SiftPoint *grown = static_cast<SiftPoint *>(std::malloc(bytes));
+      SiftPoint *grown = static_cast<SiftPoint *>(cusift_dropin::host_alloc(bytes));
       if (used) std::memcpy(grown, data.h_data, used);
-      std::free(data.h_data);
+      cusift_dropin::host_free(data.h_data);
       data.h_data = grown;
     }
     if (data.d_data != nullptr) {
@@ -125,7 +125,7 @@ inline int ReadMATLABMatchIndices(const char *indices_filename, uint32_t *indice
 // extras/debug.cpp:26-73: one block of text per keypoint; a SiftData without host records gets them first.
 inline void PrintSiftData(SiftData &data) {
   if (data.h_data == nullptr && data.d_data != nullptr && data.maxPts > 0) {
-    data.h_data = static_cast<SiftPoint *>(std::malloc(sizeof(SiftPoint) * (size_t)data.maxPts));
+    data.h_data = static_cast<SiftPoint *>(cusift_dropin::host_alloc(sizeof(SiftPoint) * (size_t)data.maxPts));
     data.Synchronize();
   }
   const SiftPoint *h = data.h_data;

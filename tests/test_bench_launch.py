@@ -24,6 +24,11 @@ def test_gpus_2_spawns_its_own_ranks_and_prints_one_line():
     assert len(lines) == 1, out.stdout  # exactly ONE line on stdout: everything else went to stderr
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_launch"] is True and d["images_total"] == 128 and d["steps"] == 3
+    # the N > 1 leg of BASELINE configs[4] (one 8192 x 8192 image strip-tiled over the ranks that are up): plan + halo
+    # exchange rehearsed over gloo, every rank's halos checked row by row
+    t = d["tiled_leg"]
+    assert t["ranks"] == 2 and t["halo_exchange_correct_on_every_rank"] is True and t["rows_owned_octave0"] == [4096, 4096]
+    assert t["tiled_octaves"] == 5 and t["collapse_octave"] is None
 
 
 def test_gpus_8_dry_launch():
@@ -35,6 +40,14 @@ def test_gpus_8_dry_launch():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["dry_launch"] is True and d["images_total"] == 512 and d["steps"] == 2
+    # ... and BASELINE configs[4] over the same eight ranks: 1024 base rows each, octaves 0..4 tiled (64 rows >= the 48-row
+    # halo in octave 4), halos exchanged with both neighbours in every octave and correct on every rank; the committed
+    # prediction for eight ranks rides along
+    t = d["tiled_leg"]
+    assert t["ranks"] == 8 and t["rows_owned_octave0"] == [1024] * 8 and t["tiled_octaves"] == 5
+    assert t["halo_exchange_correct_on_every_rank"] is True
+    pred = [v for k, v in t.items() if k.startswith("predicted")][0]
+    assert pred["exchanges_in_the_chain"] == 5 and pred["halo_bytes_per_neighbour_per_direction_by_octave"][0] == 48 * 8192 * 4
 
 
 def test_under_torchrun_the_ranks_are_not_spawned_again():

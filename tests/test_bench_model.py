@@ -52,3 +52,39 @@ def test_algorithmic_bytes_follow_the_survey(bench):
     # C2 per image blur 88,385,280 B, downsample 13,769,760 B, extrema 77,337,120 B
     blur, down, find = bench.algorithmic_bytes(1920, 1080, 5, 1)
     assert (blur, down, find) == (88385280, 13769760, 77337120)
+
+
+def test_tiled_model_arithmetic(bench):
+    """The committed prediction of BASELINE configs[4] (one 8192 x 8192 image over P ranks): bytes and the chain."""
+    m = bench.tiled_model(8192, 8192, 5, 0.70, 89469)
+    r8 = m["ranks"]["8"]
+    assert r8["tiled_octaves"] == 5 and r8["collapse_octave"] is None and r8["exchanges_in_the_chain"] == 5
+    assert r8["halo_bytes_per_neighbour_per_direction_by_octave"] == [48 * (8192 >> o) * 4 for o in range(5)]
+    assert r8["merge_bytes_per_rank"] == int(89469 / 8 * 540)
+    best, worst = r8["latency_20us_eff_1.0"], r8["latency_60us_eff_0.7"]
+    halo_ms = sum(0.020 + b / 76.8e9 * 1e3 for b in r8["halo_bytes_per_neighbour_per_direction_by_octave"])
+    assert best["halo_exchange_ms"] == pytest.approx(halo_ms, abs=2e-4)
+    assert best["merge_ms"] == pytest.approx(0.020 + r8["merge_bytes_per_rank"] / 76.8e9 * 1e3, abs=2e-4)
+    assert best["predicted_ms_per_image"] == pytest.approx(r8["kernel_ms_per_rank"] + best["halo_exchange_ms"] + best["merge_ms"], abs=2e-4)
+    assert worst["predicted_ms_per_image"] > best["predicted_ms_per_image"]
+    # latency-bound: nowhere near 8x, and the verdict says so
+    assert 1.0 < best["predicted_speedup_over_one_gpu"] < 3.0 and "latency-bound" in m["verdict"]
+    # more ranks than rows / halo: the thin octaves collapse onto rank 0 and cost one more exchange
+    deep = bench.tiled_model(8192, 8192, 7, 0.70, 89469)["ranks"]["8"]
+    assert deep["tiled_octaves"] == 5 and deep["collapse_octave"] == 5 and deep["exchanges_in_the_chain"] == 6
+    assert deep["collapse_bytes_per_rank"] == (1024 >> 5) * (8192 >> 5) * 4
+
+
+def test_model_plan_agrees_with_the_tiling_plan():
+    """tiled_model's collapse rule is cusift_amd.tiling.StripPlan's (the Python twin of cusift_tiled_plan)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench_legs.models import tiled_model
+    from cusift_amd.tiling import StripPlan
+
+    for n_oct in (5, 7, 9):
+        for P in (2, 4, 8):
+            plan = StripPlan(8192, 8192, P, n_oct)
+            row = tiled_model(8192, 8192, n_oct, 0.7, 1000)["ranks"][str(P)]
+            assert row["tiled_octaves"] == plan.collapse, (n_oct, P)

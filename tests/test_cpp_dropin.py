@@ -16,17 +16,19 @@ BIN_PIPE = os.path.join(CPP, "pipeline_dropin")
 BIN_TILED = os.path.join(CPP, "tiled_dropin")
 BIN_HOSTPIPE = os.path.join(CPP, "hostpipe_dropin")
 BIN_SCALING = os.path.join(CPP, "scaling_bench")
+BIN_THREADS = os.path.join(CPP, "threads_dropin")
 
 
 def build():
     subprocess.check_call(["make", "-C", CPP, "all"], stdout=subprocess.DEVNULL)
     assert os.path.exists(BIN) and os.path.exists(BIN_MATCH) and os.path.exists(BIN_HOMO) and os.path.exists(BIN_MULTI)
     assert os.path.exists(BIN_PIPE) and os.path.exists(BIN_TILED) and os.path.exists(BIN_HOSTPIPE)
+    assert os.path.exists(BIN_THREADS)
 
 
 def test_dropin_header_compiles_and_links_with_gxx():
     """No HIP/CUDA headers on the include path: cuSIFT.h + cusift_amd.h must be self-contained C++."""
-    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED, BIN_HOSTPIPE, BIN_SCALING):
+    for b in (BIN, BIN_MATCH, BIN_HOMO, BIN_MULTI, BIN_PIPE, BIN_TILED, BIN_HOSTPIPE, BIN_SCALING, BIN_THREADS):
         if os.path.exists(b):
             os.remove(b)
     build()
@@ -137,6 +139,20 @@ def test_dropin_pipeline_program_runs_on_gpu():
         assert m, out.stdout
         counts.append(int(m.group(4)))
     assert counts[0] == counts[1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads,frames,w,h", [(4, 3, 640, 480), (3, 2, 1366, 768)])
+def test_dropin_threads_program_equals_single_thread(threads, frames, w, h):
+    """An unchanged cuSIFT program called from several host threads (each its own SiftData + cuImage, the reference's
+    calls only): include/cuSIFT.h gives every calling thread its own implicit context, and every image's SiftData equals
+    the single-thread run's bit for bit."""
+    build()
+    out = subprocess.run([BIN_THREADS, os.path.join(ROOT, "tests", "golden", "gray1.pgm"), str(threads), str(frames), "2",
+                          str(w), str(h)], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert re.search(r"threads: %d threads x %d frames %dx%d: .* all equal" % (threads, frames, w, h), out.stdout), out.stdout
 
 
 @pytest.mark.gpu

@@ -118,3 +118,12 @@ def test_extract_from_u8_equals_extract_from_float(ctx, gray1):
     a, b = canonical_order(h_a[:na]), canonical_order(h_b[:nb])
     for f in ("coords2D", "scale", "orientation", "data"):
         np.testing.assert_array_equal(a[f], b[f])
+
+
+def test_large_tile_images_equal_the_plain_generator():
+    """synth.tile assembles large pre-blurred images (BASELINE configs[4]) from one period of the mirror-tiled pattern;
+    the result must be the plain generator's bit for bit -- even and odd tile counts, several shifts."""
+    from cusift_amd import synth
+
+    for seed, w, h in ((7, 5300, 3900), (9, 5120, 3840), (11, 5800, 3841)):
+        assert np.array_equal(synth.tile(seed, w, h, preblur=1.0), synth._tile_plain(seed, w, h, 1.0)), (seed, w, h)

@@ -589,7 +589,11 @@ def test_hip_descriptors_vs_float64_anchor(ctx, oracle, gray1, frac_bits):
     if frac_bits == 0:
         assert np.median(l2[smooth]) < 3e-5 and l2[smooth].max() < 3e-4, (np.median(l2[smooth]), l2[smooth].max())
     else:
-        assert np.median(l2[smooth]) < 5e-4 and l2[smooth].max() < 3e-2, (np.median(l2[smooth]), l2[smooth].max())
+        # (the bars of tests/test_float64_anchor.py::test_descriptor_restatement_vs_float64: with fixed-point weights a
+        # flipped fraction is worth 1/256 of a pixel difference, and at most two keypoints may combine it with a 180-degree
+        # sample that the float64 flag cannot see -- one exists on the fixture, 0.059 away)
+        top = np.sort(l2[smooth])
+        assert np.median(top) < 5e-4 and top[-3] < 3e-3 and top[-1] < 0.1, (np.median(top), top[-5:])
     assert l2[ok].max() < 0.2
     # and the oracle is no closer to the float64 value than the kernel is (same keypoints, same bars)
     ref = pts.copy()
