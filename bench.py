@@ -118,7 +118,8 @@ def parse_args(argv=None):
                          "5-octave cycle, so that per-launch PMC averages are over whole steps")
     ap.add_argument("--pyramid-in-detect", type=int, default=-1, choices=(-1, 0, 1, 2),
                     help="CUSIFT_POLICY_PYRAMID_IN_DETECT of every extraction context: -1 the library's default (calls of "
-                         ">= 6 Mpixel: every detection writes the next octave's image, no ScaleDown launches), 0 the "
+                         "pipelining callers from 2 million pixels per call: every detection writes the next octave's image, no ScaleDown "
+                         "launches; lone callers from 64 million: octave 0's detection only), 0 the "
                          "ScaleDown chain first (the reference's order, cuSIFT.cu:175-192), 1 octave 0 only, 2 every octave")
     ap.add_argument("--preflight", type=int, default=7,
                     help="rounds of untimed load between the literal W + K region and the timed one, each one batch per "

@@ -284,9 +284,10 @@ def run(R):
                               "(value_no_preflight_mpix_per_s) -> a FIXED number of untimed steps (preflight_steps) -> W "
                               "warm-up + K timed steps at steady clocks (`value`); --preflight 0 runs the W + K steps alone",
             "pyramid_in_detect": ex.ctx.get_policy(capi.POLICY_PYRAMID_IN_DETECT),
-            "pyramid_in_detect_note": "-1 = the library's default: a call of >= 6 Mpixel searches its octaves finest "
-                                      "first and every detection launch also writes the next octave's image "
-                                      "(ScaleDown's arithmetic, bit for bit) -- no ScaleDown launch, no memset",
+            "pyramid_in_detect_note": "-1 = the library's default (include/cusift_amd.h): a pipelining caller's call of >= 2 "
+                                      "million pixels searches its octaves finest first and every detection launch also "
+                                      "writes the next octave's image (ScaleDown's arithmetic, bit for bit) -- no "
+                                      "ScaleDown launch, no memset",
         },
         # the contract's W + K steps with nothing before them but the set-up check (the like-for-like figure of rounds 1-4)
         "value_no_preflight_mpix_per_s": round(R.total_pix / (elapsed_literal / K) / 1e6, 2),

@@ -62,14 +62,25 @@ def is_stale():
 def build(force=False, verbose=False, lab=False, stamps=False):
     """Compile the HIP extension for gfx950 if missing or older than its sources (make decides). Returns the path.
     One object per translation unit under build/obj, compiled in parallel; the link goes to a temporary file that is
-    renamed onto the library, so a concurrent rank that loads (or builds) it never sees a half-written shared object."""
+    renamed onto the library, so a process that LOADS the library never sees a half-written shared object.  Builders are
+    serialised: the objects and the link's temporary file have fixed names, so two ranks running this at once would
+    otherwise link each other's half-written objects -- the whole make runs under an exclusive flock on build/.lock (the
+    second builder then finds everything up to date)."""
+    import fcntl
+
     target, lib = ("stamps", STAMPS_LIB) if stamps else (("lab", LAB_LIB) if lab else ("all", LIB))
     cmd = ["make", "-C", ROOT, "-j%d" % max(1, min(8, os.cpu_count() or 1)), target, "HIPCC=" + find_hipcc()]
     if force:
         cmd.insert(1, "-B")
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    with open(os.path.join(ROOT, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return lib
 
 

@@ -320,9 +320,11 @@ bool wants_stage_all(const cusift_ctx *ctx, const cusift_params *prm, int n_imag
 // A lone caller's middle ground is "octave 0 only" (1): octave 0's detection hands octave 1 over -- the large ScaleDown is
 // the one worth saving -- and the coarser octaves keep their short ScaleDown chain and their ONE launch: 32 frames
 // 0.645 -> 0.640, 48: 0.941 -> 0.910 (every octave: 0.932), 64: 1.241 -> 1.152 (every octave: 1.154); 24: 0.496 -> 0.505.
-// So by default: a pipelining caller (concurrent_batches >= 2) every octave from one 1080p frame's worth of pixels up, a
-// lone caller octave 0 only from 64 Mpixel per call (31 frames).  0: never; 1: octave 0 only; 2: every octave.
-constexpr size_t kPyramidInDetectMinPixelsPipelined = 2u << 20, kPyramidInDetectMinPixelsLone = 64u << 20;
+// So by default: a pipelining caller (concurrent_batches >= 2) every octave from one 1080p frame's worth of pixels up
+// (2,000,000: a single 1920 x 1080 frame, 2,073,600 pixels, qualifies -- until round 6 the limit was 2 << 20 = 2,097,152
+// and it did not), a lone caller octave 0 only from 64,000,000 pixels per call (31 frames of 1080p).  0: never; 1: octave 0
+// only; 2: every octave.
+constexpr size_t kPyramidInDetectMinPixelsPipelined = 2000000, kPyramidInDetectMinPixelsLone = 64000000;
 int wants_pyramid_in_detect(const cusift_ctx *ctx, const cusift_params *prm, int n_images, int w, int h) {
   const int mode = ctx->knobs.pyramid_in_detect;
   if (mode == 0 || ctx->knobs.force_generic || ctx->knobs.stage_all == 0) return 0;

@@ -59,6 +59,12 @@ class SiftGatherer:
     588] SiftPoint regions exactly as the exact format does -- every rank ends the step holding SiftData of all images --
     for 8 % fewer bytes per xGMI link (the 12 floats dropped are never written by extraction and uninitialised in the
     reference, cuSIFT.cu:24,29; they arrive as zeros).
+    `expand=True` is an EXTRACTION-ONLY format: score, ambiguity, match, match_xpos, match_ypos, match_error, empty and
+    coords3D are not carried -- match results written into the records before the gather (MatchSiftData) arrive zeroed,
+    and the gathered SiftData is byte-identical to the producer's only in the 135 floats extraction writes.  Gather records
+    that carry match results with wire_format="exact" (bench.py --gather-exact, the format to compare metrics of rounds
+    1-4 with).  It also keeps a second ring of exact-size output buffers (world * region_cap * 588 bytes * n_out) beside
+    the trimmed arrival buffers.
     The records and counters handed to begin() must stay untouched until the pack enqueued by begin() has run: begin()
     returns an event recorded behind it -- `producer_stream.wait_event(ev)` (or `producer_ctx.wait(comm.ctx)`) orders
     the producer's next write after the pack without a host wait.  The tensors themselves are kept alive by this object

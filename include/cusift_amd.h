@@ -91,9 +91,9 @@ typedef struct cusift_params {
                           flight on this device at once (one context + stream each).  1 (default): this call has the
                           GPU to itself -- short row chunks in the detection launches (their tails stay short), all
                           octaves searched by ONE launch whenever a keypoint list per octave fits the arena, and from
-                          64 Mpixel per call octave 1 as a by-product of octave 0's detection (CUSIFT_POLICY_PYRAMID_IN_DETECT).
+                          64 million pixels per call (31 frames of 1080p) octave 1 as a by-product of octave 0's detection (CUSIFT_POLICY_PYRAMID_IN_DETECT).
                           >= 2: other batches fill the tails -- taller chunks (less redundant blurring at chunk borders),
-                          the pyramid in the detections from 2 Mpixel per call; >= 3: chunk height proportional to the
+                          the pyramid in the detections from 2 million pixels per call (one 1080p frame); >= 3: chunk height proportional to the
                           work (about as many chunks per launch as the chip holds waves).
                           cusift_amd.batch.PipelinedExtractor sets it to its stream count.  Same SiftData either way,
                           coarsest octave first. */

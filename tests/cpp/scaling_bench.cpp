@@ -20,10 +20,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "cusift_amd.h"
@@ -91,7 +93,13 @@ int main(int argc, char **argv) {
     return 2;
   }
   const int rank = g_rank = std::atoi(argv[1]), world = std::atoi(argv[2]);
-  const std::string id_file = argv[3];
+  // Rendezvous files: <id-file> (rank 0 writes the communicator id) and <id-file>.t<rank> (every rank's time).  A crashed
+  // run leaves them behind, so (a) a launcher may set CUSIFT_RUN_NONCE (any string, the same for all ranks of one run): it
+  // becomes part of the names; (b) rank 0 removes whatever is there before it writes; (c) the other ranks only accept an id
+  // file written within the last 30 s before their own start, or after it -- the ranks of one run start together.
+  const char *nonce = std::getenv("CUSIFT_RUN_NONCE");
+  const std::string id_file = std::string(argv[3]) + (nonce && *nonce ? std::string(".") + nonce : std::string());
+  const time_t started = time(nullptr);
   const int K = argc > 5 ? std::atoi(argv[5]) : 20, WARM = argc > 6 ? std::atoi(argv[6]) : 5;
   const int B = argc > 7 ? std::atoi(argv[7]) : 64, W = argc > 8 ? std::atoi(argv[8]) : 1920,
             H = argc > 9 ? std::atoi(argv[9]) : 1080;
@@ -116,6 +124,8 @@ int main(int argc, char **argv) {
   // ---- the communicator on a stream of its own: rank 0 makes the id, everybody reads it ----
   char id[CUSIFT_UNIQUE_ID_BYTES];
   if (rank == 0) {
+    std::remove(id_file.c_str());
+    for (int r = 0; r < world; ++r) std::remove((id_file + ".t" + std::to_string(r)).c_str());
     CHECK(cusift_comm_get_unique_id(id));
     const std::string tmp = id_file + ".tmp";
     FILE *fp = std::fopen(tmp.c_str(), "wb");
@@ -124,8 +134,11 @@ int main(int argc, char **argv) {
     std::rename(tmp.c_str(), id_file.c_str());
   } else {
     FILE *fp = nullptr;
-    for (int tries = 0; tries < 1200 && !(fp = std::fopen(id_file.c_str(), "rb")); ++tries)
-      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    for (int tries = 0; tries < 1200 && !fp; ++tries) {
+      struct stat st;
+      if (stat(id_file.c_str(), &st) == 0 && st.st_mtime >= started - 30) fp = std::fopen(id_file.c_str(), "rb");
+      if (!fp) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
     if (!fp || std::fread(id, 1, sizeof(id), fp) != sizeof(id)) return 1;
     std::fclose(fp);
   }

@@ -15,11 +15,16 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8 HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES HSA_ENABLE_IPC_MODE_LEGACY=$HSA_ENABLE_IPC_MODE_LEGACY (every pass)" > "$OUT/environment.txt"
 BENCH_ARGS="--steps 5 --warmup 2 --legs single,two_stage --profile-run $*"
+# the kernel-trace pass runs the DRIVER's steps (--steps 20 --warmup 5), behind the same set-up check and pre-flight as the
+# un-profiled command: its per-kernel averages are at the clocks the line's numbers are measured at (round 5's pass ran 5
+# steps from a cold start and read the blur + DoG kernel 13 % slower than the driver's line)
+TRACE_ARGS="--steps 20 --warmup 5 --legs single,two_stage --profile-run $*"
 echo "bench args: $BENCH_ARGS" > "$OUT/command.txt"
+echo "trace args: $TRACE_ARGS" >> "$OUT/command.txt"
 echo "progress: un-profiled bench" 
-python3 bench.py $BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 bench.py $TRACE_ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "progress: kernel trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $TRACE_ARGS > "$OUT/trace.log" 2>&1
 # ONE stream only (timed region and single-stream leg both on one stream): kernel spans do not overlap, so this table's
 # averages are the HIP-event figures of bench.py's stage_ms_per_step (the pass above mixes overlapped and lone launches)
 echo "progress: one-stream kernel trace"

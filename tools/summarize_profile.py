@@ -37,9 +37,27 @@ def main():
     if stats:
         cmd = "python3 bench.py --steps 5 --warmup 2 --legs single,two_stage"
         try:
-            cmd = "python3 bench.py " + open(os.path.join(src, "command.txt")).read().split(":", 1)[1].strip()
+            txt = open(os.path.join(src, "command.txt")).read()
+            tr = [l for l in txt.splitlines() if l.startswith("trace args:")]
+            cmd = "python3 bench.py " + (tr[0] if tr else txt).split(":", 1)[1].strip().splitlines()[0]
         except Exception:
             pass
+        # per-kernel averages of the trace pass, for bench.py (roofline.profile_avg_launch_us) -> profiles/kernel_trace.json
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in read_csv(stats[0]):
+            a = agg[short(r["Name"])]
+            a[0] += int(r["Calls"])
+            a[1] += int(r["Calls"]) * float(r["AverageNs"]) / 1e3
+        kt = {k: {"calls": c, "avg_us": t / c, "command": cmd} for k, (c, t) in agg.items() if c and k.endswith("_kernel")}
+        try:  # the HIP-event figure of the SAME (profiled) process, for the record
+            line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{") and '"metric"' in l][-1]
+            rf = json.loads(line).get("roofline", {})
+            if "avg_launch_ms" in rf and "laplace_multi_fast_kernel" in kt:
+                kt["laplace_multi_fast_kernel"]["hip_event_avg_us_same_process"] = rf["avg_launch_ms"] * 1e3
+        except Exception:  # noqa: BLE001
+            pass
+        with open(os.path.join(os.path.dirname(dst) or ".", "kernel_trace.json"), "w") as f:
+            json.dump(kt, f, indent=1)
         lines.append("== rocprofv3 --kernel-trace --stats (%s) ==" % cmd)
         lines.append("%-62s %6s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
         for r in read_csv(stats[0]):
