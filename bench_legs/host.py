@@ -109,6 +109,8 @@ def host_visible_leg(torch, capi, pipe, d_imgs, K, B, max_pts, device_index, dev
     # processor's four compute pipes -- a sixth made the compact leg a lottery (92-131 M keypoints/s by run with 4 + 2
     # streams, depending on which queues shared a pipe; 125 M with 3 + 2).
     all_streams, all_extractors = pipe.streams, pipe.extractors
+    # (round 6, profiles/r06/upload_link.md: four extraction streams here read 48.4 against 47.6 Gpix/s host to host --
+    # within the run-to-run spread; three stay)
     pipe.streams, pipe.extractors = all_streams[:3], all_extractors[:3]
     for x in pipe.extractors:
         x.params.concurrent_batches = len(pipe.streams)
