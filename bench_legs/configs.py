@@ -146,8 +146,9 @@ def fixture_640x480(capi, synth, device, iters=100):
             "cpu_side": "cpu_baseline.configs0: the CPU oracle on one core over the same image, keypoint counts compared"}
 
 
-def whole_8192(R, steps=5):
-    """BASELINE configs[4] on ONE GPU: the image through the ordinary driver (n = 1)."""
+def whole_8192(R, steps=20, warm=20):
+    """BASELINE configs[4] on ONE GPU: the image through the ordinary driver (n = 1), at steady clocks (`warm` untimed
+    calls first: five calls from a cold start read 0.68-0.70 ms where sixty read 0.60, profiles/r06/ab_handover.txt)."""
     from cusift_amd.batch import BatchExtractor
 
     torch, capi, synth = R.torch, R.capi, R.synth
@@ -156,8 +157,8 @@ def whole_8192(R, steps=5):
     ex = BatchExtractor(1, TILED_W, TILED_H, params=prm)
     try:
         d_img = ex.images_from_numpy(img[None])
-        for it in range(steps + 2):
-            if it == 2:
+        for it in range(steps + warm):
+            if it == warm:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             ex.extract(d_img)
@@ -261,7 +262,7 @@ def run_rank0(R, tiled):
                                           host_iters=max(20, K))
     whole = None
     with R.leg_guard("configs[4]"):
-        whole = whole_8192(R, steps=max(3, K // 4))
+        whole = whole_8192(R, steps=max(10, K))
         c4 = {"whole_on_one_gpu": whole}
         if not R.args.profile_run:
             c4["virtual_ranks_on_one_gpu"] = virtual_ranks_8192(R)

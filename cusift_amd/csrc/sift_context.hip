@@ -49,6 +49,7 @@ Knobs read_knobs() {
   k.stage_all = num("CUSIFT_STAGE_ALL", -1);
   k.no_multi = text("CUSIFT_NO_MULTI") != nullptr;
   k.pyramid_in_detect = num("CUSIFT_PYRAMID_IN_DETECT", -1);
+  k.unordered_coarse = text("CUSIFT_UNORDERED_COARSE") != nullptr;
 #endif
   return k;
 }

@@ -142,9 +142,25 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     }
   }
   // the side stream rejoins the context's stream however the work in between ends
+  // CUSIFT_LAB only (CUSIFT_UNORDERED_COARSE; round 6): what would an octave hand-over INSIDE one launch be
+  // worth to a lone caller at best?  Everything behind octave 0's detection -- the short ScaleDown chain and the one
+  // launch that searches octaves 1.. -- is put on the side stream WITHOUT waiting for octave 0's detection: it reads the
+  // octave-1 image the PREVIOUS call left in the arena (the same pixels when the same batch is extracted in a loop, as the
+  // benchmark does -- a timing experiment, not an extraction), so the coarser octaves' waves fill octave 0's tail with
+  // perfect overlap and no synchronisation cost at all.  profiles/r06/lone_caller_handover.md holds the result.
+  bool unordered = false;
+#ifdef CUSIFT_LAB
+  unordered = ctx->knobs.unordered_coarse && !forked && chain_end == 1 && !ctx->timing && !ctx->recording &&
+              ensure_side_stream(ctx) == CUSIFT_OK;
+#endif
+  hipStream_t const main_stream = ctx->stream;
   auto on_main = [&]() -> int {
     // ExtractSiftLoop, cuSIFT.cu:175-192: build the pyramid finest -> coarsest -- a small call's first levels in one launch
     int built = 0;
+    if (unordered) {  // the side stream starts behind whatever this call has enqueued so far (the counters' memset)
+      HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    }
     for (int o = 0; o < chain_end; ++o) {  // finest first: octave o's detection writes octave o + 1
       DownOut dn;
       dn.dst = const_cast<float *>(base[o + 1]);
@@ -156,6 +172,7 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
                       RowWindow{0, pl.h[o]}, 0, pl.h[o], prm->concurrent_batches, true, false, &dn));
       built = o + 1;
     }
+    if (unordered) ctx->stream = ctx->side;  // (the rest of on_main enqueues there; put back below)
     if (small_pyramid) {
       built = std::min(pl.n_oct - 1, kMaxPyramidLevels);
       TRY(pyramid_small_impl(ctx, base, pl.w, pl.h, pl.p, stride, built, n_images, 0.5f,
@@ -207,6 +224,11 @@ extern "C" int cusift_extract_batch(cusift_ctx *ctx, const float *d_imgs, int n_
     return CUSIFT_OK;
   };
   const int rc_main = on_main();
+  if (unordered) {
+    ctx->stream = main_stream;
+    (void)hipEventRecord(ctx->ev_join, ctx->side);
+    (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+  }
   if (forked) {
     const hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
     if (rc_main == CUSIFT_OK) HIP_TRY(e);

@@ -128,6 +128,8 @@ struct Knobs {
   bool side_debug = false;                           // CUSIFT_SIDE_DEBUG: print the side stream's concurrency probe
   int stage_all_mb = 0;                              // CUSIFT_STAGE_ALL_MB: largest staging for all octaves (0: default)
   int small_pyramid = -1;                            // CUSIFT_SMALL_PYRAMID: 0 never, 1 always, default by size
+  bool unordered_coarse = false;                     // CUSIFT_UNORDERED_COARSE: a TIMING experiment, results are wrong unless
+                                                     // the same batch is extracted over and over (sift_driver.hip)
 };
 
 struct cusift_ctx {
