@@ -192,7 +192,7 @@ def main():
 
     # BASELINE configs[4] over the ranks that are up: every rank takes part (N > 1 only; never part of `value`)
     tiled = None
-    if world > 1 and "configs" in legs:
+    if R.use_dist and "configs" in legs:  # (one rank with --force-gather rehearses the leg over RCCL's self send / recv)
         try:
             tiled = configs.tiled_8192_all_ranks(R)
         except Exception as e:  # noqa: BLE001 -- all ranks fail or succeed together (the collectives are matched)

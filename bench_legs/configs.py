@@ -194,18 +194,23 @@ def tiled_8192_all_ranks(R, steps=5):
         del img
         gat = SiftGatherer(R.comm, 1, ext.max_pts, region_cap=ext.max_pts, device=R.dev)
         totals = None
-        for it in range(steps + 2):
-            if it == 2:
-                dist.barrier()
+        multi = R.world > 1  # (one rank + --force-gather: a rehearsal of this leg, RCCL self send / recv, no process group)
+        for it in range(steps + 4):
+            if it == 4:
+                if multi:
+                    dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             pts, cnt = run_distributed(ext, strip)
             _, _, totals = gat.gather(pts, cnt)
         outside = ext.check()
-        dist.barrier()
+        if multi:
+            dist.barrier()
         torch.cuda.synchronize()
         dt = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device=R.dev)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        if multi:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        gat.close()
     finally:
         ext.close()
     if R.rank != 0:
