@@ -324,7 +324,7 @@ float oracle_tex2d(const float *img, int w, int h, int pitch, float x, float y, 
   float fx = floorf(xb), fy = floorf(yb);
   float a = xb - fx, b = yb - fy;
   float w00, w10, w01, w11;
-  if (frac_bits > 0) {
+  if (frac_bits > 0 && frac_bits <= 11) { /* the range the C ABI accepts (cusift_params.tex_frac_bits); else exact */
     const float q = (float)(1 << frac_bits);
     const float A = floorf(a * q + 0.5f), B = floorf(b * q + 0.5f); /* integers in [0, q] */
     const float W11 = floorf(A * B / q + 0.5f);                     /* A B <= 2^(2q): exact in fp32 for q <= 11 */

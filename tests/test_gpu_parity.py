@@ -503,7 +503,9 @@ def oracle_octave_points(oracle, img, w, h, blur, thresh, sub, max_pts=16384):
     return src, pts, n
 
 
-@pytest.mark.parametrize("frac_bits", [8, 0])
+# (8: the reference's texture unit; 0: exact fp32 fractions and products; 4 and 11: the ends of the range in which the
+# fixed-point weight rule's product A B / 2^q is exact in fp32 -- the rule is generic in the bit count on both sides)
+@pytest.mark.parametrize("frac_bits", [8, 0, 4, 11])
 def test_orientations_match_oracle(ctx, oracle, gray1, frac_bits):
     w, h = 640, 480
     src, pts, n = oracle_octave_points(oracle, gray1, w, h, 0.0, 0.5, 1.0)
@@ -523,7 +525,7 @@ def test_orientations_match_oracle(ctx, oracle, gray1, frac_bits):
     np.testing.assert_array_equal(want["coords2D"][:n], got["coords2D"][:n])
 
 
-@pytest.mark.parametrize("frac_bits", [8, 0])
+@pytest.mark.parametrize("frac_bits", [8, 0, 4, 11])
 def test_descriptors_match_oracle(ctx, oracle, gray1, frac_bits):
     w, h = 640, 480
     sub = 2.0
