@@ -190,14 +190,6 @@ def main():
     timed.setup(R)
     timed.run(R)  # `value`; R.out exists on rank 0 from here on
 
-    # BASELINE configs[4] over the ranks that are up: every rank takes part (N > 1 only; never part of `value`)
-    tiled = None
-    if R.use_dist and "configs" in legs:  # (one rank with --force-gather rehearses the leg over RCCL's self send / recv)
-        try:
-            tiled = configs.tiled_8192_all_ranks(R)
-        except Exception as e:  # noqa: BLE001 -- all ranks fail or succeed together (the collectives are matched)
-            tiled = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
-
     # ================================================================================================================
     # Extra legs (rank 0's GPU only; not part of `value`).  With N > 1 the other ranks wait at the final barrier.
     # ================================================================================================================
@@ -236,7 +228,7 @@ def main():
                 content.run_ragged(R)
         if "configs" in legs:
             with R.leg_guard("configs"):
-                configs.run_rank0(R, tiled)
+                configs.run_rank0(R)
         if "match" in legs:
             with R.leg_guard("match"):
                 out["match_leg"] = match.match_leg(capi, ex.ctx, 16384)
@@ -274,10 +266,49 @@ def main():
                 c0 = out.get("config_legs", {}).get("configs[0]")
                 out["cpu_baseline"]["configs0"] = cpu.configs0_cpu(c0["keypoints"] if c0 else None)
 
+    # BASELINE configs[4] over the ranks that are up (N > 1; one rank with --force-gather rehearses it over RCCL's self send
+    # / recv): EVERY rank takes part, after rank 0's own legs -- the line is complete but for this leg -- and under a
+    # watchdog: RCCL has never been entered with more than one rank from the build box, and a leg must never cost the
+    # line.  If the leg (or the teardown's barriers) has not finished in time, rank 0 prints the line as it stands, with
+    # the fact on record, and every rank leaves through os._exit.
+    printed = []
+
+    def emit():
+        if rank == 0 and not printed:
+            printed.append(True)
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    def watchdog(seconds, what):
+        import threading
+
+        def expire():
+            if rank == 0:
+                out.setdefault("leg_errors", {})[what] = "not finished after %d s: the line was printed without it" % seconds
+                emit()
+            os._exit(0)
+
+        t = threading.Timer(seconds, expire)
+        t.daemon = True
+        t.start()
+        return t
+
+    if world > 1:
+        dist.barrier()  # the other ranks waited here while rank 0 ran its legs (no watchdog: the legs take what they take)
+    if R.use_dist and "configs" in legs:
+        dog = watchdog(240, "configs[4] tiled over the ranks")
+        tiled = None
+        try:
+            tiled = configs.tiled_8192_all_ranks(R)
+        except Exception as e:  # noqa: BLE001 -- (a rank that fails alone leaves the others to the watchdog)
+            tiled = {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+        dog.cancel()
+        if rank == 0:
+            configs.merge_tiled(R, tiled)
+    emit()
+    dog = watchdog(120, "teardown")
     timed.teardown(R)
-    sys.stdout.flush()
-    if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dog.cancel()
     os.close(json_fd)
 
 

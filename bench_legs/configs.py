@@ -254,9 +254,10 @@ def virtual_ranks_8192(R, P=8, steps=3):
                     "estimate is total / P"}
 
 
-def run_rank0(R, tiled):
-    """The rank-0 part: configs[0], configs[1], the whole 8192^2 image, the virtual ranks, `tiled_model`; `tiled` is what
-    tiled_8192_all_ranks returned on this rank (None with one GPU)."""
+def run_rank0(R):
+    """The rank-0 part: configs[0], configs[1], the whole 8192^2 image, the virtual ranks, `tiled_model`.  With N > 1 the
+    tiled leg runs AFTER this one (every rank takes part) and merge_tiled() adds its result."""
+    tiled = None
     out, capi, synth = R.out, R.capi, R.synth
     K = R.args.steps
     legs = {}
@@ -298,3 +299,24 @@ def run_rank0(R, tiled):
     if whole is not None:
         out["single_8192_ms"] = whole["ms_per_image"]
         out["single_8192_mpix_per_s"] = whole["Mpix_per_s"]
+
+
+def merge_tiled(R, tiled):
+    """Rank 0, after tiled_8192_all_ranks: the measured N-rank figure beside the whole-image one and the prediction."""
+    out = R.out
+    if tiled is None:
+        return
+    c4 = out.setdefault("config_legs", {}).setdefault("configs[4]", {})
+    c4["tiled_over_the_ranks"] = tiled
+    whole = c4.get("whole_on_one_gpu")
+    if whole and "keypoints_merged" in tiled:
+        tiled["keypoints_equal_whole_image"] = tiled["keypoints_merged"] == whole["keypoints"]
+        tiled["speedup_over_one_gpu"] = round(whole["ms_per_image"] / tiled["ms_per_image"], 3)
+        if not tiled["keypoints_equal_whole_image"]:
+            out.setdefault("leg_errors", {})["configs[4] tiled"] = (
+                "merged keypoint count %d != whole-image count %d" % (tiled["keypoints_merged"], whole["keypoints"]))
+    row = out.get("tiled_model", {}).get("ranks", {}).get(str(R.world))
+    if row and "ms_per_image" in tiled:
+        out["tiled_model"]["measured_ms_per_image_at_%d_ranks" % R.world] = tiled["ms_per_image"]
+        out["tiled_model"]["measured_minus_predicted_ms_best_corner"] = round(
+            tiled["ms_per_image"] - row["latency_20us_eff_1.0"]["predicted_ms_per_image"], 4)
