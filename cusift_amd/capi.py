@@ -467,7 +467,9 @@ class Context:
 
     def math_eval(self, op, d_a, d_b, d_out, d_out2, n):
         """cusift_math_eval: op 0 expf, 1 exp2f, 2 atan2f(a, b), 3 sincosf -> (out, out2), 4 the descriptor's angle
-        coordinate of (dy = a, dx = b); device pointers."""
+        coordinate of (dy = a, dx = b), 5 the orientation bin's shortcut of (dy = a, dx = b): out = bin (+ 64 if the sample
+        is `near` a bin edge: the kernel then evaluates the reference's formula), out2 = that formula's bin; device
+        pointers."""
         check(lib().cusift_math_eval(self.handle, op, d_a, d_b, d_out, d_out2, n))
 
     def rootsift(self, d_points, num_pts):

@@ -405,6 +405,40 @@ __device__ __forceinline__ float wave_sum64(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// The orientation histogram's bin of a gradient, cuSIFT_D.cu:349: bin = (int)(16 atan2f(dy, dx) / 3.1416f + 16.5f), 32 -> 0.
+// The bin is a DISCRETE function of the gradient's direction, so it needs no angle: with a = atan(min / max) of the two
+// magnitudes in [0, pi/4], every octant holds four bin edges, at a = (j - 1/2) 3.1416 / 16 up to the octant's share of
+// (3.1416 - pi) -- the same four edges in all eight octants to within 5.4e-6 rad (2.8e-5 of a bin) -- and the bin is the
+// octant's first bin plus or minus the number of edges below the direction: cnt = #{j : mn > T_j mx}, T_j the tangent of
+// the middle of the eight octants' edges.  No division, no polynomial, no pi: four fused multiply-adds, four compares.
+// EXACTNESS: the oracle evaluates the reference's formula in fp32 (sm_atan2f <= 2 ulp, one division, one rounding at
+// magnitude 32: within 1e-5 of a bin of the real value), the shared edges are within 2.8e-5 of a bin of the true ones;
+// a sample whose direction lies within kOriEdgeEps * mx of an edge in d = mn - T mx -- at least 1.5e-5 rad = 7.6e-5 of a
+// bin on either side of every edge, twice what the two can differ by -- is reported `near`, and the caller sends the
+// whole wave through the reference's formula behind a ballot (3 % of the keypoints hold such a sample).  Outside that
+// margin the two bins are equal by the bound above; tests/test_gpu_parity.py::test_orientation_bin_shortcut checks it
+// on 2^22 random directions and on samples dense at every edge (cusift_math_eval op 5), test_orientations_match_oracle
+// and the fuzz sweep on whole orientations (bit-identical).  Zero gradients (weight 0) are never `near`; NaN and
+// infinite ones are.
+constexpr float kOriEdgeT1 = 0.09848980424854088f, kOriEdgeT2 = 0.3033454482644209f, kOriEdgeT3 = 0.5345102632831631f,
+                kOriEdgeT4 = 0.820678412197299f, kOriEdgeEps = 2.5e-5f;
+__device__ __forceinline__ int ori_bin_shortcut(float dy, float dx, bool &near) {
+  const float ax = sm_abs(dx), ay = sm_abs(dy);
+  const bool swap = ay > ax;
+  const float mx = swap ? ay : ax, mn = swap ? ax : ay;
+  const float d1 = fmaf(-kOriEdgeT1, mx, mn), d2 = fmaf(-kOriEdgeT2, mx, mn), d3 = fmaf(-kOriEdgeT3, mx, mn),
+              d4 = fmaf(-kOriEdgeT4, mx, mn);
+  const int cnt = (int)(d1 > 0.0f) + (int)(d2 > 0.0f) + (int)(d3 > 0.0f) + (int)(d4 > 0.0f);
+  const float m = fminf(fminf(sm_abs(d1), sm_abs(d2)), fminf(sm_abs(d3), sm_abs(d4)));
+  near = !(m > kOriEdgeEps * mx) && !(mx == 0.0f);  // a NaN anywhere: near
+  const bool negx = (sm_bits(dx) & 0x80000000u) != 0u, negy = (sm_bits(dy) & 0x80000000u) != 0u;
+  // position in bins from the positive x axis, as if dy >= 0: 8 h from the quadrant boundary, +- the edges passed
+  const int h = negx ? 2 - (int)swap : (int)swap;
+  const int p = 8 * h + ((swap != negx) ? -cnt : cnt);
+  const int bin = negy ? 16 - p : 16 + p;
+  return bin & 31;  // 32 -> 0 (cuSIFT_D.cu:350-351)
+}
+
 template <typename SH, typename TEX>
 __device__ __forceinline__ OriPrep kp_orientation_prep(SH &S, const TEX &tex, float kx, float ky, float scale, int tx) {
   const float i2sigma2 = -1.0f / (4.5f * scale * scale);
@@ -504,13 +538,26 @@ __device__ __forceinline__ float kp_orientation(SH &S, const TEX &tex, const Ori
       dy[rep] = tex(xf, yf + 1.0f) - tex(xf, yf - 1.0f);
     }
   }
+  bool near_edge = false;
 #pragma unroll
   for (int rep = 0; rep < kReps; ++rep) {
-    int bin = (int)(16.0f * sm_atan2f(dy[rep], dx[rep]) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
-    if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
+    bool near;
+#ifdef CUSIFT_AB_ORI_FORMULA  // (an A/B build: the reference's formula for every sample, as rounds 1-5)
+    near = true;
+#else
+    sbin[rep] = ori_bin_shortcut(dy[rep], dx[rep], near);  // the bin without an angle (see ori_bin_shortcut)
+#endif
+    near_edge = near_edge || near;
     const float grad = sqrtf(dx[rep] * dx[rep] + dy[rep] * dy[rep]);
-    sbin[rep] = bin;
     swgt[rep] = grad * S.gauss[xd[rep]] * S.gauss[yd[rep]];
+  }
+  if (__ballot(near_edge) != 0ull) {  // wave-uniform, ~3 % of the keypoints: some sample sits at a bin edge (or is not finite)
+#pragma unroll
+    for (int rep = 0; rep < kReps; ++rep) {
+      int bin = (int)(16.0f * sm_atan2f(dy[rep], dx[rep]) / 3.1416f + 16.5f);  // 0..32; v_cvt_i32_f32 turns a NaN into 0
+      if ((unsigned int)bin > 31u) bin = 0;  // 32 -> 0 as in the reference (cuSIFT_D.cu:352); also memory safety
+      sbin[rep] = bin;
+    }
   }
   STAMP(S, 4);
   float hist_half;  // this lane's (half, bin) sum
@@ -1526,6 +1573,14 @@ __global__ void __launch_bounds__(256) math_eval_kernel(int op, const float *__r
     else if (op == 1) out[i] = sm_exp2f(a[i]);
     else if (op == 2) out[i] = sm_atan2f(a[i], b[i]);
     else if (op == 4) out[i] = desc_angle_bins(a[i], b[i]);
+    else if (op == 5) {  // the orientation bin's shortcut and its `near` flag; out2 = the reference's formula
+      bool near;
+      const int bin = ori_bin_shortcut(a[i], b[i], near);
+      out[i] = (float)(bin + (near ? 64 : 0));
+      int ref = (int)(16.0f * sm_atan2f(a[i], b[i]) / 3.1416f + 16.5f);
+      if ((unsigned int)ref > 31u) ref = 0;
+      out2[i] = (float)ref;
+    }
     else {
       float s, c;
       sm_sincosf(a[i], &s, &c);

@@ -623,7 +623,7 @@ extern "C" int cusift_rootsift(cusift_ctx *ctx, cusift_point *d_points, int num_
 extern "C" int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b, float *d_out,
                                 float *d_out2, size_t n) {
   TRY(enter(ctx));
-  if (op < 0 || op > 4 || !d_a || !d_out || ((op == 2 || op == 4) && !d_b) || (op == 3 && !d_out2))
+  if (op < 0 || op > 5 || !d_a || !d_out || ((op == 2 || op == 4 || op == 5) && !d_b) || ((op == 3 || op == 5) && !d_out2))
     return fail(CUSIFT_ERR_INVALID, "math_eval: bad argument");
   if (n == 0) return CUSIFT_OK;
   const unsigned int blocks = (unsigned int)std::min<size_t>((n + 255) / 256, 256 * 16);

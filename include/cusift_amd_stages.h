@@ -99,7 +99,11 @@ int cusift_extract_descriptors(cusift_ctx *ctx, const float *d_img, int w, int h
  * build of the same header gives the same bits; this entry point exists so that callers and tests can verify that
  * on their device.  op 4: the descriptor stage's angle coordinate 4/3.1415f * atan2f(a, b) + 4 as its kernel forms it
  * (a fit of degree 4 in t^2, within 4e-6 of a bin of the exact form -- the bound the kernel's comment states and the
- * tests assert --, with the reference's operations where the value decides: index 8).
+ * tests assert --, with the reference's operations where the value decides: index 8).  op 5: the orientation stage's
+ * histogram bin (int)(16 atan2f(a, b) / 3.1416f + 16.5f), 32 -> 0 (cuSIFT_D.cu:349-351) as its kernel finds it -- by
+ * counting the bin edges below the gradient's direction inside its octant, no angle -- out = that bin, + 64 where the
+ * sample lies within the stated margin of an edge (the kernel then evaluates the formula itself), out2 = the formula's
+ * bin: equal wherever out < 64, for every input.
  * Asynchronous. */
 int cusift_math_eval(cusift_ctx *ctx, int op, const float *d_a, const float *d_b, float *d_out, float *d_out2,
                      size_t n);

@@ -89,6 +89,59 @@ def test_math_device_equals_host(ctx, oracle):
             buf.free()
 
 
+def test_orientation_bin_shortcut(ctx, oracle):
+    """The orientation stage's histogram bin without an angle (sift_keypoints.hip: ori_bin_shortcut, cusift_math_eval op 5):
+    edges passed inside the octant instead of (int)(16 atan2f / 3.1416f + 16.5f).  Every sample the shortcut does NOT report
+    `near` an edge must get exactly the reference formula's bin (the kernel sends waves with a `near` sample through the
+    formula itself): random directions over twelve binades, directions dense at each of the 32 edges, integer-valued
+    gradients as an image's are, zeros, signed zeros, equal magnitudes; non-finite gradients must be `near`."""
+    rng = np.random.default_rng(23)
+    n = 1 << 21
+    dy = (rng.normal(0, 1, n) * np.exp(rng.uniform(-6, 6, n))).astype(np.float32)
+    dx = (rng.normal(0, 1, n) * np.exp(rng.uniform(-6, 6, n))).astype(np.float32)
+    # dense at the edges: theta_m = (m - 16.5) 3.1416 / 16, m = 1 .. 32, +- 2e-4 rad (the `near` margin is ~1.5e-5 rad)
+    m = rng.integers(1, 33, n)
+    th = (m - 16.5) * 3.1416 / 16.0 + rng.uniform(-2e-4, 2e-4, n)
+    r = np.exp(rng.uniform(-4, 6, n))
+    ey, ex = (r * np.sin(th)).astype(np.float32), (r * np.cos(th)).astype(np.float32)
+    # what a texture tap difference of an 8-bit image looks like: multiples of 1/256 up to +-255
+    iy = (rng.integers(-65280, 65281, n) / 256.0).astype(np.float32)
+    ix = (rng.integers(-65280, 65281, n) / 256.0).astype(np.float32)
+    sy = np.float32([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, 1.0, -1.0, 0.0, -0.0, 3.0, -3.0, 2.5, 2.5, -2.5, -2.5])
+    sx = np.float32([0.0, 0.0, -0.0, -0.0, 0.0, 0.0, -0.0, -0.0, 2.0, -2.0, 0.0, 0.0, 2.5, -2.5, 2.5, -2.5])
+    bad_y = np.float32([np.nan, 1.0, np.inf, -np.inf, 1.0, np.nan])
+    bad_x = np.float32([1.0, np.nan, 1.0, np.inf, np.inf, np.nan])
+    a = np.concatenate([dy, ey, iy, sy, bad_y])
+    b = np.concatenate([dx, ex, ix, sx, bad_x])
+    d_a, d_b = DeviceBuffer.from_numpy(ctx, a), DeviceBuffer.from_numpy(ctx, b)
+    d_o, d_o2 = DeviceBuffer(ctx, a.nbytes), DeviceBuffer(ctx, a.nbytes)
+    ctx.math_eval(5, d_a.ptr, d_b.ptr, d_o.ptr, d_o2.ptr, a.size)
+    ctx.synchronize()
+    got = d_o.to_numpy(np.float32, a.shape).astype(np.int32)
+    ref_dev = d_o2.to_numpy(np.float32, a.shape).astype(np.int32)
+    for buf in (d_a, d_b, d_o, d_o2):
+        buf.free()
+    near, bins = got >= 64, got & 63
+    # the reference formula as the ORACLE evaluates it (sm_atan2f on the host == on the device, bit for bit)
+    theta = oracle.math_eval("atan2", a, b)
+    with np.errstate(invalid="ignore"):
+        u = np.float32(16.0) * theta / np.float32(3.1416) + np.float32(16.5)
+        want = np.where(np.isfinite(u), u, 0).astype(np.int32)
+    want[(want > 31) | (want < 0)] = 0
+    fin = np.isfinite(a) & np.isfinite(b)
+    np.testing.assert_array_equal(ref_dev[fin], want[fin])  # the device's own evaluation of the formula
+    clear = ~near
+    assert (bins[clear] == want[clear]).all(), int((bins[clear] != want[clear]).sum())
+    assert (bins >= 0).all() and (bins <= 31).all()
+    # how often the kernel pays for the formula: per sample, on random directions / on an image's kind of gradients
+    assert near[:n].mean() < 6e-4 and near[2 * n:3 * n].mean() < 6e-4, (near[:n].mean(), near[2 * n:3 * n].mean())
+    assert 0.03 < near[n:2 * n].mean() < 0.3  # the dense-at-the-edges sample does hit the margin
+    # zero gradients carry weight 0 and never ask for the formula; non-finite ones always do
+    zero = (a == 0) & (b == 0)
+    assert zero.sum() >= 4 and not near[zero].any()
+    assert near[~fin].all()
+
+
 def test_descriptor_angle_coordinate(ctx, oracle):
     """The descriptor stage's angle coordinate (sift_keypoints.hip: desc_angle_bins, cusift_math_eval op 4) is NOT the
     oracle's 4/3.1415f * atan2f + 4 to the ulp -- its effect on a descriptor is continuous, so it is a degree-4 fit -- except
