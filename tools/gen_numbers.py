@@ -100,8 +100,10 @@ def numbers_block():
       % (f(r.get("achieved"), 1), f(r.get("frac"), 3), f((r.get("avg_launch_ms") or 0) * 1e3, 1), r.get("launches"),
          f(rd.get("achieved"), 1), f(rd.get("frac"), 3)))
     a("Committed `rocprofv3 --kernel-trace --stats` pass of the same command (`profiles/r06_final_summary.txt`,")
-    a("`profiles/kernel_trace.json`): %s µs per launch over %s launches (profile ÷ live = %s); PMC traffic %s B per launch ="
-      % (f(r.get("profile_avg_launch_us"), 1), r.get("profile_launches"), f(r.get("profile_over_live"), 3),
+    a("`profiles/kernel_trace.json`): %s µs per launch over %s launches (÷ this line's live figure = %s; ÷ the live figure of the"
+      % (f(r.get("profile_avg_launch_us"), 1), r.get("profile_launches"), f(r.get("profile_over_live"), 3)))
+    a("un-profiled command on the PROFILE's box, %s µs, = %s: boxes differ by 3–7 %%, the method by 0.3 %%); PMC traffic %s B per launch ="
+      % (f(r.get("profile_box_live_avg_launch_us"), 1), f(r.get("profile_over_its_own_box_live"), 3),
          "{:,}".format(int(r.get("traffic") or 0))))
     a("%s × algorithmic. Octave-0 launch alone: %s GB/s = %s."
       % (f((r.get("traffic") or 0) / max(1, r.get("algorithmic_bytes_per_launch", 1)), 2),

@@ -56,6 +56,12 @@ def main():
                 kt["laplace_multi_fast_kernel"]["hip_event_avg_us_same_process"] = rf["avg_launch_ms"] * 1e3
         except Exception:  # noqa: BLE001
             pass
+        try:  # ... and of the UN-profiled run of the same command on the same box (tools/profile_gpu.sh runs it first)
+            rf = json.load(open(os.path.join(src, "bench.json"))).get("roofline", {})
+            if "avg_launch_ms" in rf and "laplace_multi_fast_kernel" in kt:
+                kt["laplace_multi_fast_kernel"]["hip_event_avg_us_same_box_unprofiled"] = rf["avg_launch_ms"] * 1e3
+        except Exception:  # noqa: BLE001
+            pass
         with open(os.path.join(os.path.dirname(dst) or ".", "kernel_trace.json"), "w") as f:
             json.dump(kt, f, indent=1)
         lines.append("== rocprofv3 --kernel-trace --stats (%s) ==" % cmd)
