@@ -57,8 +57,15 @@ int main(int argc, char **argv) {
   cusift_params prm;
   cusift_default_params(&prm);
   prm.num_octaves = 5; prm.init_blur = 1.0f; prm.peak_thresh = 3.0f; prm.max_pts = 32768;
+  const int NB = argc > 3 ? std::atoi(argv[3]) : 1;  // frames per cusift_extract_batch call in mode 2 (the same frame NB times)
+  float *d_batch = nullptr;
+  if (NB > 1) {
+    cusift_malloc((void **)&d_batch, host.size() * 4 * NB);
+    for (int i = 0; i < NB; ++i) cusift_memcpy_h2d(c0, d_batch + (size_t)i * host.size(), host.data(), host.size() * 4);
+    cusift_ctx_synchronize(c0);
+  }
   for (int mode = 0; mode < 3; ++mode)      // 0: count only, 1: records to pinned host, 2: batch entry point, sync per call
-    for (int T : {1, 2, 4, 8}) {
+    for (int T : {1, 2, 4, 8, 16}) {
       std::vector<std::thread> th;
       std::vector<int> kp(T, 0);
       const auto t0 = std::chrono::steady_clock::now();
@@ -68,13 +75,13 @@ int main(int argc, char **argv) {
           cusift_ctx_create(&c, 0, nullptr);
           cusift_point *d_pts = nullptr, *h_pts = nullptr;
           unsigned int *d_cnt = nullptr;
-          cusift_malloc((void **)&d_pts, (size_t)prm.max_pts * sizeof(cusift_point));
+          cusift_malloc((void **)&d_pts, (size_t)prm.max_pts * sizeof(cusift_point) * (mode == 2 ? NB : 1));
           cusift_malloc((void **)&d_cnt, 256);
           cusift_malloc_host((void **)&h_pts, (size_t)prm.max_pts * sizeof(cusift_point));
           int n = 0;
           for (int i = 0; i < N + 20; ++i) {
             if (mode == 2) {
-              cusift_extract_batch(c, d_img, 1, W, H, P, (size_t)P * H, &prm, d_pts, d_cnt);
+              cusift_extract_batch(c, NB > 1 ? d_batch : d_img, NB, W, H, P, (size_t)P * H, &prm, d_pts, d_cnt);
               cusift_ctx_synchronize(c);
             } else {
               cusift_extract(c, d_img, W, H, P, &prm, d_pts, mode == 1 ? h_pts : nullptr, &n);
@@ -88,7 +95,8 @@ int main(int argc, char **argv) {
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       std::printf("mode %d (%s) threads %d: %.4f ms per frame overall (%.1f Gpix/s), %d keypoints\n", mode,
                   mode == 0 ? "count only" : mode == 1 ? "records to pinned host" : "extract_batch + sync", T,
-                  ms / ((double)T * (N + 20)), (double)W * H * T * (N + 20) / (ms * 1e-3) / 1e9, kp[0]);
+                  ms / ((double)T * (N + 20) * (mode == 2 ? NB : 1)),
+                  (double)W * H * T * (N + 20) * (mode == 2 ? NB : 1) / (ms * 1e-3) / 1e9, kp[0]);
     }
   return 0;
 }
