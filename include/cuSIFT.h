@@ -21,7 +21,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
+#include <utility>
+#include <vector>
 
 #include "cusift_amd.h"
 
@@ -53,19 +56,34 @@ namespace cusift_dropin {
 // single-threaded program behaves exactly as before, and a program that calls SiftData::Extract / ExtractSift from N
 // host threads -- each with its own SiftData and cuImage objects, nothing else changed -- has N extractions in
 // flight on the device (tests/cpp/threads_dropin.cpp).  Objects may cross threads: buffers belong to the device, not
-// to a context.  A thread's context is destroyed when the thread ends; the first thread's lives as long as the
-// process (the reference's global state is never torn down either), unless shutdown() is called on that thread.
+// to a context.  Contexts live as long as the process (the reference's global state is never torn down either) unless
+// shutdown() is called.
 inline std::atomic<int> &device_slot() {
   static std::atomic<int> dev{0};
   return dev;
 }
+// A thread's context is PARKED when the thread ends, not destroyed: a destructor of thread-local storage is no place
+// for GPU runtime calls (tools that intercept HIP keep thread-local state of their own, gone by then -- rocprofv3 aborts),
+// and the next thread that needs a context on that device takes a parked one, arena and all: a program has as many
+// contexts as it ever had threads extracting at once.  shutdown() destroys the calling thread's context and every parked one.
+struct ctx_pool {
+  std::mutex m;
+  std::vector<std::pair<int, cusift_ctx *>> parked;
+};
+inline ctx_pool &pool() {
+  static ctx_pool *p = new ctx_pool;  // never destroyed: threads may end during the process's own exit
+  return *p;
+}
 struct thread_ctx {
   cusift_ctx *c = nullptr;
   int dev = -1;
-  bool keep = false;  // the process's first context: not destroyed at thread exit
-  ~thread_ctx() {
-    if (c && !keep) cusift_ctx_destroy(c);
+  void park() {
+    if (!c) return;
+    std::lock_guard<std::mutex> lock(pool().m);
+    pool().parked.emplace_back(dev, c);
+    c = nullptr;
   }
+  ~thread_ctx() { park(); }
 };
 inline thread_ctx &thread_slot() {
   static thread_local thread_ctx t;
@@ -75,30 +93,40 @@ inline cusift_ctx *&ctx_slot() { return thread_slot().c; }
 inline cusift_ctx *ctx() {
   thread_ctx &t = thread_slot();
   const int dev = device_slot().load(std::memory_order_relaxed);
-  if (t.c && t.dev != dev) {  // InitCuda() chose another device since this thread last extracted
-    cusift_ctx_destroy(t.c);
-    t.c = nullptr;
-  }
+  if (t.c && t.dev != dev) t.park();  // InitCuda() chose another device since this thread last extracted
   if (!t.c) {
-    static std::atomic<bool> first{true};
-    safeCall(cusift_ctx_create(&t.c, dev, nullptr));
-    t.dev = dev;
-    t.keep = first.exchange(false);
-    // An unchanged caller of the reference's API has no handle on the launch policy; the one knob such a caller may
-    // want -- octave 0's detection on a second stream, for large single batches -- is read HERE, in the shim that is
-    // compiled into the caller, from CUSIFT_OCTAVE_OVERLAP (0..3 = CUSIFT_POLICY_SIDE_STREAM's values).  The library
-    // itself reads no environment variable on the extraction path (until round 5 it read this one).
-    if (const char *e = std::getenv("CUSIFT_OCTAVE_OVERLAP")) {
-      const int v = std::atoi(e);
-      if (v >= 0 && v <= 3) safeCall(cusift_ctx_set_policy(t.c, CUSIFT_POLICY_SIDE_STREAM, v));
+    {
+      std::lock_guard<std::mutex> lock(pool().m);
+      auto &v = pool().parked;
+      for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].first == dev) {
+          t.c = v[i].second;
+          v.erase(v.begin() + (long)i);
+          break;
+        }
     }
+    if (!t.c) {
+      safeCall(cusift_ctx_create(&t.c, dev, nullptr));
+      // An unchanged caller of the reference's API has no handle on the launch policy; the one knob such a caller may
+      // want -- octave 0's detection on a second stream, for large single batches -- is read HERE, in the shim that is
+      // compiled into the caller, from CUSIFT_OCTAVE_OVERLAP (0..3 = CUSIFT_POLICY_SIDE_STREAM's values).  The library
+      // itself reads no environment variable on the extraction path (until round 5 it read this one).
+      if (const char *e = std::getenv("CUSIFT_OCTAVE_OVERLAP")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 3) safeCall(cusift_ctx_set_policy(t.c, CUSIFT_POLICY_SIDE_STREAM, v));
+      }
+    }
+    t.dev = dev;
   }
   return t.c;
 }
-inline void shutdown() {  // the calling thread's context
+inline void shutdown() {  // the calling thread's context and every parked one (call it where GPU calls are safe)
   thread_ctx &t = thread_slot();
   if (t.c) cusift_ctx_destroy(t.c);
   t.c = nullptr;
+  std::lock_guard<std::mutex> lock(pool().m);
+  for (auto &e : pool().parked) cusift_ctx_destroy(e.second);
+  pool().parked.clear();
 }
 // SiftData's host records: pinned memory (the reference: malloc, cuSIFT.cu:24).  The class owns and frees the
 // buffer (cuSIFT.cu:34-50), callers only index it (test/detector.cpp:56) -- pinned, the read-back at the end of
