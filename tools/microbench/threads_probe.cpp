@@ -64,7 +64,8 @@ int main(int argc, char **argv) {
     for (int i = 0; i < NB; ++i) cusift_memcpy_h2d(c0, d_batch + (size_t)i * host.size(), host.data(), host.size() * 4);
     cusift_ctx_synchronize(c0);
   }
-  for (int mode = 0; mode < 3; ++mode)      // 0: count only, 1: records to pinned host, 2: batch entry point, sync per call
+  for (int mode = 0; mode < 4; ++mode)      // 0: count only, 1: records to pinned host, 2: batch entry point, sync per call,
+                                            // 3: the same launch sequence replayed as a recorded hipGraph, sync per call
     for (int T : {1, 2, 4, 8, 16}) {
       std::vector<std::thread> th;
       std::vector<int> kp(T, 0);
@@ -75,12 +76,18 @@ int main(int argc, char **argv) {
           cusift_ctx_create(&c, 0, nullptr);
           cusift_point *d_pts = nullptr, *h_pts = nullptr;
           unsigned int *d_cnt = nullptr;
-          cusift_malloc((void **)&d_pts, (size_t)prm.max_pts * sizeof(cusift_point) * (mode == 2 ? NB : 1));
+          cusift_malloc((void **)&d_pts, (size_t)prm.max_pts * sizeof(cusift_point) * (mode >= 2 ? NB : 1));
           cusift_malloc((void **)&d_cnt, 256);
           cusift_malloc_host((void **)&h_pts, (size_t)prm.max_pts * sizeof(cusift_point));
           int n = 0;
+          cusift_graph *graph = nullptr;
+          if (mode == 3)
+            cusift_graph_create(c, &graph, NB > 1 ? d_batch : d_img, NB, W, H, P, (size_t)P * H, &prm, d_pts, d_cnt);
           for (int i = 0; i < N + 20; ++i) {
-            if (mode == 2) {
+            if (mode == 3) {
+              cusift_graph_launch(graph);
+              cusift_ctx_synchronize(c);
+            } else if (mode == 2) {
               cusift_extract_batch(c, NB > 1 ? d_batch : d_img, NB, W, H, P, (size_t)P * H, &prm, d_pts, d_cnt);
               cusift_ctx_synchronize(c);
             } else {
@@ -88,15 +95,16 @@ int main(int argc, char **argv) {
             }
           }
           kp[t] = n;
+          if (graph) cusift_graph_destroy(graph);
           cusift_free(d_pts); cusift_free(d_cnt); cusift_free_host(h_pts);
           cusift_ctx_destroy(c);
         });
       for (auto &x : th) x.join();
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       std::printf("mode %d (%s) threads %d: %.4f ms per frame overall (%.1f Gpix/s), %d keypoints\n", mode,
-                  mode == 0 ? "count only" : mode == 1 ? "records to pinned host" : "extract_batch + sync", T,
-                  ms / ((double)T * (N + 20) * (mode == 2 ? NB : 1)),
-                  (double)W * H * T * (N + 20) * (mode == 2 ? NB : 1) / (ms * 1e-3) / 1e9, kp[0]);
+                  mode == 0 ? "count only" : mode == 1 ? "records to pinned host" : mode == 2 ? "extract_batch + sync" : "graph replay + sync", T,
+                  ms / ((double)T * (N + 20) * (mode >= 2 ? NB : 1)),
+                  (double)W * H * T * (N + 20) * (mode >= 2 ? NB : 1) / (ms * 1e-3) / 1e9, kp[0]);
     }
   return 0;
 }
