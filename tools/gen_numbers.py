@@ -204,7 +204,7 @@ def numbers_block():
                  "%.1e" % s["coarse_ori_median"], "%.1e" % s["oct0_ori_median"], s["tail"]["outliers_gt_1_deg"],
                  s["tail"]["outliers_at_second_peak"]))
     a("* `pytest -m gpu`: %s" % last_line("gpu_tests_tail.txt"))
-    a("* `tools/fuzz_parity.py 1500`: %s" % last_line("fuzz_parity.txt"))
+    a("* `tools/fuzz_parity.py` (1,500 + 2,500 + 4,000 cases, three seeds): %s" % last_line("fuzz_parity.txt"))
     a("* `tools/fuzz_tiled.py 40`: %s" % last_line("fuzz_tiled.txt"))
     a("* `tools/fuzz_match.py 100`: %s" % last_line("fuzz_match.txt"))
     return "\n".join(L)
