@@ -11,11 +11,13 @@ def profile_fields(live_ms):
         return {}
     return {"profile_avg_launch_us": round(kt["avg_us"], 2), "profile_launches": kt["calls"],
             "profile_over_live": round(kt["avg_us"] / (live_ms * 1e3), 4),
-            # the profile's box is not this run's box (3-7 % between boxes): what the un-profiled command measured ON the
-            # profile's box, minutes before the trace pass, is the like-for-like check of the method
+            # Like for like: HIP events INSIDE the profiled process bracket the same launches the trace times -- 1.024 x
+            # the trace in every one of five runs (one dispatch per launch; profiles/r06/profile_vs_live_pairs.json).
+            # Between separate runs -- this one against the profile's -- the kernel's average moves by about +-5 % (clocks).
+            "profile_process_hip_event_avg_us": round(kt.get("hip_event_avg_us_same_process") or 0.0, 2) or None,
+            "hip_events_over_trace_same_process": round(kt["hip_event_avg_us_same_process"] / kt["avg_us"], 4)
+            if kt.get("hip_event_avg_us_same_process") else None,
             "profile_box_live_avg_launch_us": round(kt.get("hip_event_avg_us_same_box_unprofiled") or 0.0, 2) or None,
-            "profile_over_its_own_box_live": round(kt["avg_us"] / kt["hip_event_avg_us_same_box_unprofiled"], 4)
-            if kt.get("hip_event_avg_us_same_box_unprofiled") else None,
             "profile_source": "profiles/kernel_trace.json: rocprofv3 --kernel-trace --stats of `%s` (committed; pure kernel "
                               "time -- the HIP events of this run bracket the launch, + one dispatch)" % kt.get("command", "?")}
 

@@ -100,11 +100,20 @@ def numbers_block():
       % (f(r.get("achieved"), 1), f(r.get("frac"), 3), f((r.get("avg_launch_ms") or 0) * 1e3, 1), r.get("launches"),
          f(rd.get("achieved"), 1), f(rd.get("frac"), 3)))
     a("Committed `rocprofv3 --kernel-trace --stats` pass of the same command (`profiles/r06_final_summary.txt`,")
-    a("`profiles/kernel_trace.json`): %s µs per launch over %s launches (÷ this line's live figure = %s; ÷ the live figure of the"
-      % (f(r.get("profile_avg_launch_us"), 1), r.get("profile_launches"), f(r.get("profile_over_live"), 3)))
-    a("un-profiled command on the PROFILE's box, %s µs, = %s: boxes differ by 3–7 %%, the method by 0.3 %%); PMC traffic %s B per launch ="
-      % (f(r.get("profile_box_live_avg_launch_us"), 1), f(r.get("profile_over_its_own_box_live"), 3),
-         "{:,}".format(int(r.get("traffic") or 0))))
+    a("`profiles/kernel_trace.json`): %s µs per launch over %s launches; HIP events inside that profiled process read %s µs"
+      % (f(r.get("profile_avg_launch_us"), 1), r.get("profile_launches"), f(r.get("profile_process_hip_event_avg_us"), 1)))
+    try:
+        pp = load("profile_vs_live_pairs.json")["pairs"]
+        a("= %s × the trace — and %s in the five profile runs of the round (one dispatch per launch): the two ways of timing the"
+          % (f(r.get("hip_events_over_trace_same_process"), 3),
+             " / ".join("%.3f" % (q["live_avg_us_inside_the_profiled_process"] / q["trace_avg_us"]) for q in pp)))
+        a("kernel agree to 0.1 %%. Between separate runs its average moves by ±5 %% (trace %s µs; un-profiled runs on the same boxes"
+          % " / ".join("%.0f" % q["trace_avg_us"] for q in pp))
+        a("%s µs; this line's %s µs): clocks, not method (`profiles/r06/profile_vs_live_pairs.json`). PMC traffic %s B per launch ="
+          % (" / ".join("%.0f" % q["live_avg_us_unprofiled_same_box"] for q in pp), f((r.get("avg_launch_ms") or 0) * 1e3, 0),
+             "{:,}".format(int(r.get("traffic") or 0))))
+    except OSError:
+        a("PMC traffic %s B per launch =" % "{:,}".format(int(r.get("traffic") or 0)))
     a("%s × algorithmic. Octave-0 launch alone: %s GB/s = %s."
       % (f((r.get("traffic") or 0) / max(1, r.get("algorithmic_bytes_per_launch", 1)), 2),
          f(g(r, "octave0_launch", "achieved"), 1), f(g(r, "octave0_launch", "frac"), 3)))
